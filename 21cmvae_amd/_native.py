@@ -1,0 +1,379 @@
+"""ctypes binding of libv21.so (C ABI: include/v21.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or no GPU is
+visible, the first call that needs the engine raises ``EngineUnavailable``.  Loading
+the library and listing its symbols works without a GPU (used by the CPU test suite).
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libv21.so")
+
+PREC_F32, PREC_F16, PREC_BF16 = 0, 1, 2
+PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32,
+              "f16": PREC_F16, "fp16": PREC_F16, "float16": PREC_F16,
+              "bf16": PREC_BF16, "bfloat16": PREC_BF16}
+ACT_LINEAR, ACT_RELU = 0, 1
+FWD_IN_TRANSFORM, FWD_OUT_TRANSFORM, FWD_FORCE_GENERIC = 1, 2, 4
+COMM_ID_BYTES = 128
+
+
+class EngineUnavailable(RuntimeError):
+    """libv21.so cannot be loaded or no MI355X is visible."""
+
+
+class EngineError(RuntimeError):
+    """A v21_* call returned a negative status."""
+
+
+class AffineIn(C.Structure):
+    _fields_ = [("n", C.c_int32), ("log_mask", C.c_int32 * 8), ("zero_floor", C.c_float * 8),
+                ("lo", C.c_float * 8), ("scale", C.c_float * 8)]
+
+
+class AffineOut(C.Structure):
+    _fields_ = [("std", C.c_float), ("mean", C.POINTER(C.c_float)), ("n", C.c_int32)]
+
+
+class Adam(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+
+
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+# name -> (restype, argtypes); every symbol include/v21.h declares
+SIGNATURES = {
+    "v21_last_error": (C.c_char_p, []),
+    "v21_version": (C.c_int, []),
+    "v21_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "v21_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "v21_ctx_destroy": (C.c_int, [_P]),
+    "v21_ctx_sync": (C.c_int, [_P]),
+    "v21_ctx_set_stream": (C.c_int, [_P, _P]),
+    "v21_ctx_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "v21_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "v21_free": (C.c_int, [_P, _P]),
+    "v21_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "v21_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "v21_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
+    "v21_event_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "v21_event_destroy": (C.c_int, [_P, _P]),
+    "v21_event_record": (C.c_int, [_P, _P]),
+    "v21_event_elapsed_ms": (C.c_int, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "v21_mlp_create": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_P)]),
+    "v21_mlp_destroy": (C.c_int, [_P]),
+    "v21_mlp_num_params": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "v21_mlp_set_weights": (C.c_int, [_P, _F, C.c_size_t]),
+    "v21_mlp_get_weights": (C.c_int, [_P, _F, C.c_size_t]),
+    "v21_mlp_set_input_transform": (C.c_int, [_P, C.POINTER(AffineIn)]),
+    "v21_mlp_set_output_transform": (C.c_int, [_P, C.POINTER(AffineOut)]),
+    "v21_mlp_has_fused": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    "v21_mlp_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, _F, C.c_int, C.c_int]),
+    "v21_mlp_forward_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int, C.c_int]),
+    "v21_trainer_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "v21_trainer_destroy": (C.c_int, [_P]),
+    "v21_trainer_set_adam": (C.c_int, [_P, C.POINTER(Adam)]),
+    "v21_trainer_set_lr": (C.c_int, [_P, C.c_float]),
+    "v21_trainer_get_lr": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "v21_trainer_set_data": (C.c_int, [_P, C.c_int, _F, _F, _F, C.c_int64]),
+    "v21_trainer_run_epoch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
+    "v21_trainer_eval": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "v21_trainer_step_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),
+    "v21_trainer_last_step_loss": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "v21_trainer_get_state": (C.c_int, [_P, C.POINTER(C.c_int64), _F, _F, C.c_size_t]),
+    "v21_trainer_set_state": (C.c_int, [_P, C.c_int64, _F, _F, C.c_size_t]),
+    "v21_trainer_get_grad": (C.c_int, [_P, _F, C.c_size_t]),
+    "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
+    "v21_comm_get_unique_id": (C.c_int, [_P, _P]),
+    "v21_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "v21_comm_destroy": (C.c_int, [_P]),
+    "v21_comm_allreduce_f32": (C.c_int, [_P, _P, C.c_size_t]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libv21.so and attach prototypes.  Needs no GPU."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise EngineUnavailable(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C 21cmvae_amd/csrc)" % LIB_PATH)
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # missing libamdhip64 etc.
+            raise EngineUnavailable("cannot load %s: %s" % (LIB_PATH, e)) from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+        return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load_library().v21_last_error()
+        raise EngineError("v21 error %d: %s" % (status, msg.decode() if msg else "?"))
+
+
+def precision_id(p):
+    if isinstance(p, int):
+        return p
+    try:
+        return PRECISIONS[str(p).lower()]
+    except KeyError:
+        raise ValueError("unknown precision %r (use f32, f16 or bf16)" % (p,)) from None
+
+
+def _fptr(a):
+    return a.ctypes.data_as(_F)
+
+
+class Context:
+    """One per device.  Owns a HIP stream; calls on one context are serialised."""
+    _default = {}
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        n = C.c_int(0)
+        st = self.lib.v21_device_count(C.byref(n))
+        if st != 0 or n.value < 1:
+            raise EngineUnavailable("no HIP device visible (v21_device_count -> %d, n=%d): the MI355X "
+                                    "engine has no CPU fallback" % (st, n.value))
+        h = _P()
+        check(self.lib.v21_ctx_create(device, C.byref(h)))
+        self.h, self.device = h, device
+        self.lock = threading.Lock()
+
+    @classmethod
+    def default(cls, device=None):
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("V21_DEVICE_FROM_RANK") else 0
+        if device not in cls._default:
+            cls._default[device] = cls(device)
+        return cls._default[device]
+
+    def sync(self):
+        check(self.lib.v21_ctx_sync(self.h))
+
+    def set_stream(self, hip_stream):
+        check(self.lib.v21_ctx_set_stream(self.h, _P(hip_stream)))
+
+    def malloc(self, nbytes):
+        p = _P()
+        check(self.lib.v21_malloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        check(self.lib.v21_free(self.h, _P(dptr)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self.lib.v21_memcpy_h2d(self.h, _P(dptr), arr.ctypes.data_as(_P), arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags.c_contiguous
+        check(self.lib.v21_memcpy_d2h(self.h, arr.ctypes.data_as(_P), _P(dptr), arr.nbytes))
+
+    def event(self):
+        e = _P()
+        check(self.lib.v21_event_create(self.h, C.byref(e)))
+        return e
+
+    def record(self, ev):
+        check(self.lib.v21_event_record(self.h, ev))
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float(0)
+        check(self.lib.v21_event_elapsed_ms(self.h, a, b, C.byref(ms)))
+        return ms.value
+
+    # data-parallel communicator (RCCL inside the library)
+    def comm_unique_id(self):
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        check(self.lib.v21_comm_get_unique_id(self.h, buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, uid):
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(uid)
+        check(self.lib.v21_comm_init(self.h, nranks, rank, buf))
+
+    def comm_destroy(self):
+        check(self.lib.v21_comm_destroy(self.h))
+
+    def allreduce(self, dptr, n):
+        check(self.lib.v21_comm_allreduce_f32(self.h, _P(dptr), n))
+
+
+class Stack:
+    """A dense stack (v21_mlp): dims[0] -> ... -> dims[-1], per-layer activation."""
+
+    def __init__(self, ctx, dims, act):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.dims, self.act = [int(d) for d in dims], [int(a) for a in act]
+        assert len(self.act) == len(self.dims) - 1
+        L = len(self.act)
+        h = _P()
+        check(self.lib.v21_mlp_create(ctx.h, L, (C.c_int * (L + 1))(*self.dims), (C.c_int * L)(*self.act), C.byref(h)))
+        self.h = h
+        n = C.c_size_t(0)
+        check(self.lib.v21_mlp_num_params(h, C.byref(n)))
+        self.num_params = n.value
+        self._mean_keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.v21_mlp_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_weights(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float32).ravel()
+        check(self.lib.v21_mlp_set_weights(self.h, _fptr(flat), flat.size))
+
+    def get_weights(self):
+        out = np.empty(self.num_params, np.float32)
+        check(self.lib.v21_mlp_get_weights(self.h, _fptr(out), out.size))
+        return out
+
+    def set_input_transform(self, log_mask, zero_floor, lo, hi):
+        if log_mask is None:
+            check(self.lib.v21_mlp_set_input_transform(self.h, None))
+            return
+        t = AffineIn()
+        n = len(lo)
+        t.n = n
+        for j in range(n):
+            t.log_mask[j] = int(bool(log_mask[j]))
+            t.zero_floor[j] = float(zero_floor[j])
+            t.lo[j] = float(lo[j])
+            t.scale[j] = float(2.0 / (float(hi[j]) - float(lo[j])))
+        check(self.lib.v21_mlp_set_input_transform(self.h, C.byref(t)))
+
+    def set_output_transform(self, std, mean):
+        if mean is None:
+            check(self.lib.v21_mlp_set_output_transform(self.h, None))
+            return
+        mean = np.ascontiguousarray(mean, dtype=np.float32)
+        t = AffineOut(float(std), _fptr(mean), mean.size)
+        check(self.lib.v21_mlp_set_output_transform(self.h, C.byref(t)))
+
+    def has_fused(self, precision="f32"):
+        y = C.c_int(0)
+        check(self.lib.v21_mlp_has_fused(self.h, precision_id(precision), C.byref(y)))
+        return bool(y.value)
+
+    def forward(self, x, precision="f32", flags=0):
+        """host (n, in) float32/float64 -> host (n, out) float32"""
+        x = np.asarray(x)
+        if x.dtype == np.float64:
+            dt = 1
+        else:
+            x = x.astype(np.float32, copy=False)
+            dt = 0
+        x = np.ascontiguousarray(x)
+        if x.ndim != 2 or x.shape[1] != self.dims[0]:
+            raise ValueError("expected input of shape (n, %d), got %r" % (self.dims[0], x.shape))
+        y = np.empty((x.shape[0], self.dims[-1]), np.float32)
+        with self.ctx.lock:
+            check(self.lib.v21_mlp_forward(self.h, x.ctypes.data_as(_P), dt, x.shape[0], _fptr(y),
+                                           precision_id(precision), flags))
+        return y
+
+    def forward_dev(self, d_x, ldx, n, d_y, ldy, precision="f32", flags=0):
+        check(self.lib.v21_mlp_forward_dev(self.h, _P(d_x), ldx, n, _P(d_y), ldy, precision_id(precision), flags))
+
+
+class Trainer:
+    """Adam trainer bound to a Stack (v21_trainer)."""
+
+    def __init__(self, stack, precision="f32", max_batch=256):
+        self.stack, self.lib, self.ctx = stack, stack.lib, stack.ctx
+        h = _P()
+        check(self.lib.v21_trainer_create(stack.h, precision_id(precision), int(max_batch), C.byref(h)))
+        self.h = h
+        self.max_batch = int(max_batch)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.v21_trainer_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_adam(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+        cfg = Adam(lr, beta1, beta2, eps)
+        check(self.lib.v21_trainer_set_adam(self.h, C.byref(cfg)))
+
+    def set_lr(self, lr):
+        check(self.lib.v21_trainer_set_lr(self.h, float(lr)))
+
+    def get_lr(self):
+        v = C.c_float(0)
+        check(self.lib.v21_trainer_get_lr(self.h, C.byref(v)))
+        return v.value
+
+    def set_data(self, which, x, y, row_weight):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        rw = np.ascontiguousarray(row_weight, dtype=np.float32)
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float32)
+            assert y.shape[0] == x.shape[0]
+        assert rw.shape == (x.shape[0],)
+        check(self.lib.v21_trainer_set_data(self.h, which, _fptr(x), _fptr(y) if y is not None else None,
+                                            _fptr(rw), x.shape[0]))
+
+    def run_epoch(self, perm, batch):
+        loss = C.c_double(0)
+        pp = None
+        if perm is not None:
+            perm = np.ascontiguousarray(perm, dtype=np.int32)
+            pp = perm.ctypes.data_as(C.POINTER(C.c_int32))
+        with self.ctx.lock:
+            check(self.lib.v21_trainer_run_epoch(self.h, pp, int(batch), C.byref(loss)))
+        return loss.value
+
+    def evaluate(self, which, batch):
+        loss = C.c_double(0)
+        with self.ctx.lock:
+            check(self.lib.v21_trainer_eval(self.h, which, int(batch), C.byref(loss)))
+        return loss.value
+
+    def step_dev(self, d_x, d_y, d_rw, n_rows, global_rows=None):
+        check(self.lib.v21_trainer_step_dev(self.h, _P(d_x), _P(d_y) if d_y else None, _P(d_rw), int(n_rows),
+                                            int(global_rows if global_rows is not None else n_rows)))
+
+    def last_step_loss(self):
+        v = C.c_double(0)
+        check(self.lib.v21_trainer_last_step_loss(self.h, C.byref(v)))
+        return v.value
+
+    def get_state(self):
+        n = self.stack.num_params
+        m, v, it = np.empty(n, np.float32), np.empty(n, np.float32), C.c_int64(0)
+        check(self.lib.v21_trainer_get_state(self.h, C.byref(it), _fptr(m), _fptr(v), n))
+        return it.value, m, v
+
+    def set_state(self, it, m=None, v=None):
+        n = self.stack.num_params
+        m = None if m is None else np.ascontiguousarray(m, np.float32)
+        v = None if v is None else np.ascontiguousarray(v, np.float32)
+        check(self.lib.v21_trainer_set_state(self.h, int(it), _fptr(m) if m is not None else None,
+                                             _fptr(v) if v is not None else None, n))
+
+    def get_grad(self):
+        g = np.empty(self.stack.num_params, np.float32)
+        check(self.lib.v21_trainer_get_grad(self.h, _fptr(g), g.size))
+        return g

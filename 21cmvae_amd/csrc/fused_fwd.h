@@ -1,0 +1,471 @@
+// fused_fwd.h -- K1: the whole dense stack of one emulator in ONE launch (gfx950).
+//
+// Replaces the Keras predict loop behind emulator.py:402 / :789-790 of the reference
+// (batch-of-32 MatMul+BiasAdd+Relu per layer) with a register-resident chain:
+//
+//   * a wave owns CT column tiles of 32 signals and keeps the TRANSPOSED activation
+//     H^T (features x signals) in registers across all layers: the f32 accumulator
+//     tile of layer l is, after ReLU (+ pack to f16/bf16), directly the B operand of
+//     layer l+1 ("accumulator tile as the next MFMA's operand").  Hidden layers compute
+//     H_{l+1}^T = W^T H_l^T (W^T fragment = A operand); the LAST layer flips to
+//     Y = H W (activation = A operand) so the 32 lanes of a half-wave hold 32
+//     consecutive output bins and rows are stored as 128-byte segments.
+//   * activations never touch LDS or HBM; the only streamed operand is the weight
+//     set, pre-packed on the host into 1-KiB MFMA fragments in consumption order
+//     ("the stream", pack_stream() in v21_api.hip).  The 4 waves of a workgroup share
+//     it through a 4-slot LDS ring filled by LDS-DMA (global_load_lds_dwordx4) two
+//     blocks ahead, with one counted vmcnt + s_barrier per 24-fragment block.
+//   * bias enters as the accumulator's initial value (hidden layers) or in the
+//     epilogue together with preprocess.unpreproc (last layer); the optional
+//     prologue is preprocess.par_transform with cached training-set statistics.
+//
+// Everything (layer, tile, k-step, fragment and ring-slot indices, wait counts) is a
+// compile-time constant: the kernel is straight-line code per architecture.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "../../include/v21.h"
+
+namespace v21 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kFragBytes = 1024;  // one MFMA operand fragment: 64 lanes x 16 B
+constexpr int kBlkFrags = 24;     // fragments per ring block
+constexpr int kRing = 4;          // LDS ring slots
+constexpr int kWaves = 4;         // one wave per SIMD
+constexpr int kFusedLds = kRing * kBlkFrags * kFragBytes;  // 96 KiB
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>),
+// expanded in chunks of 256 so that fold expressions stay below clang's nesting limit
+template <int Base, int N, class F>
+__device__ __forceinline__ void static_for_chunk(F& f) {
+  [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+    (f(std::integral_constant<int, Base + I>{}), ...);
+  }(std::make_integer_sequence<int, N>{});
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  constexpr int CH = 256;
+  if constexpr (N <= CH) {
+    static_for_chunk<0, N>(f);
+  } else {
+    [&]<int... C>(std::integer_sequence<int, C...>) __attribute__((always_inline)) {
+      (static_for_chunk<C * CH, (N - C * CH < CH ? N - C * CH : CH)>(f), ...);
+    }(std::make_integer_sequence<int, (N + CH - 1) / CH>{});
+  }
+}
+
+struct FusedArgs {
+  const float* x;
+  long long ldx;
+  float* y;
+  long long ldy;
+  long long n_rows;
+  const unsigned char* stream;  // packed fragments, padded to 4 KiB
+  float out_std;                // 1.0 when no output transform
+  float out_mean_scale;         // 1.0 / 0.0: output transform on / off
+  int in_transform;
+  v21_affine_in tin;
+};
+
+// ---- precision traits ------------------------------------------------------------
+// FPI = features per stream item (one 1-KiB fragment = one k-step); EPI = operand
+// elements per lane per item.  Accumulator register i of tile nt becomes element
+// i % EPI of item (16/EPI)*nt + i / EPI of the next layer's operand, and element e of
+// item ku held by lane half h is feature  FPI*ku + 8*(e>>2) + 4*h + (e&3).
+struct PrecF16 {
+  using frag = f16x8;
+  using elem = _Float16;
+  static constexpr int FPI = 16, EPI = 8, CT = 2;
+  template <bool SWAP> static __device__ __forceinline__ f32x16 mfma(frag w, frag x, f32x16 c) {
+    if constexpr (!SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0);
+  }
+};
+struct PrecBF16 {
+  using frag = bf16x8;
+  using elem = __bf16;
+  static constexpr int FPI = 16, EPI = 8, CT = 2;
+  template <bool SWAP> static __device__ __forceinline__ f32x16 mfma(frag w, frag x, f32x16 c) {
+    if constexpr (!SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, w, c, 0, 0, 0);
+  }
+};
+// exact f32: v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain (no reduced precision)
+struct PrecF32 {
+  using frag = f32x4;
+  using elem = float;
+  static constexpr int FPI = 8, EPI = 4, CT = 1;
+  template <bool SWAP> static __device__ __forceinline__ f32x16 mfma(frag w, frag x, f32x16 c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (!SWAP) c = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], c, 0, 0, 0);
+      else c = __builtin_amdgcn_mfma_f32_32x32x2f32(x[e], w[e], c, 0, 0, 0);
+    }
+    return c;
+  }
+};
+
+// ---- compile-time geometry of (architecture, precision) ---------------------------
+// Arch::L layers, Arch::dims[L+1], Arch::act[L] (1 = ReLU).  The last layer is the
+// "output orientation" layer and must be linear.
+template <class Arch, class P> struct Geo {
+  static constexpr int L = Arch::L;
+  static constexpr int FPI = P::FPI;
+  static constexpr int IPT = 16 / P::EPI;  // operand items produced per 32-wide tile
+  static constexpr int dim(int i) { return Arch::dims[i]; }
+  static constexpr int act(int l) { return Arch::act[l]; }
+  static constexpr int ks_of(int l) { return (dim(l) + FPI - 1) / FPI; }
+  static constexpr int nt_of(int l) { return (dim(l + 1) + 31) / 32; }
+  // stream index of the aux fragment of tile (l, nt); its k-steps follow it
+  static constexpr int tile_base(int l, int nt) {
+    int f = 0;
+    for (int i = 0; i < l; ++i) f += nt_of(i) * (ks_of(i) + 1);
+    return f + nt * (ks_of(l) + 1);
+  }
+  static constexpr int total() { return tile_base(L, 0); }
+  static constexpr int padded() { return (total() + 3) / 4 * 4; }
+  static constexpr int n_blocks() { return (padded() + kBlkFrags - 1) / kBlkFrags; }
+  static constexpr int blk_glds(int b) {  // LDS-DMA instructions per wave in block b
+    if (b < 0 || b >= n_blocks()) return 0;
+    const int rem = padded() - b * kBlkFrags;
+    return (rem < kBlkFrags ? rem : kBlkFrags) / kWaves;
+  }
+  static constexpr int ks_max() {
+    int m = 0;
+    for (int l = 0; l < L; ++l) m = ks_of(l) > m ? ks_of(l) : m;
+    return m;
+  }
+  struct Item { int l, nt, ks; };  // ks == -1: the tile's aux fragment
+  static constexpr Item item_at(int F) {
+    for (int l = 0; l < L; ++l) {
+      const int tl = ks_of(l) + 1, cnt = nt_of(l) * tl;
+      if (F < cnt) return Item{l, F / tl, F % tl - 1};
+      F -= cnt;
+    }
+    return Item{-1, -1, -1};
+  }
+  static constexpr int gtile(int l, int nt) {  // global tile counter
+    int g = 0;
+    for (int i = 0; i < l; ++i) g += nt_of(i);
+    return g + nt;
+  }
+  static constexpr Item tile_at(int g) {
+    for (int l = 0; l < L; ++l) {
+      if (g < nt_of(l)) return Item{l, g, -1};
+      g -= nt_of(l);
+    }
+    return Item{-1, -1, -1};
+  }
+  static constexpr int n_tiles() { return gtile(L, 0); }
+
+  // Program order is a sequence of steps S = 0 .. total+D-1.  Step S does, in order:
+  // [ring rendezvous if S is the first item of a block] -> LDS read of item S ->
+  // MFMAs of item S-D -> a slice ("chunks") of the PREVIOUS tile's epilogue.
+  // A tile's epilogue is cut into chunks of one (column tile, register pair) each and
+  // spread over the first k-steps of the next tile, so that its VALU work (hidden
+  // layers: ReLU + pack) or its stores (output layer) issue in the gaps between that
+  // tile's MFMAs instead of stalling the matrix pipe at the tile seam.
+  //
+  // k-steps of tile G+1 over which tile G's epilogue may be spread (0 = it must run
+  // whole before the first k-step of G+1, which already consumes it)
+  static constexpr int spread_limit(int G) {
+    const Item t = tile_at(G), n = tile_at(G + 1);
+    if (n.l < 0) return 0;
+    if (n.l == t.l) return ks_of(n.l);
+    const int first_use = IPT * (nt_of(t.l) - 1);
+    return first_use < ks_of(n.l) ? first_use : ks_of(n.l);
+  }
+  static constexpr int chunks_per_kstep(int G, int nchunks) {
+    const int lim = spread_limit(G);
+    return lim <= 0 ? nchunks : (nchunks + lim - 1) / lim;
+  }
+  // output-layer store instructions issued by one wave in steps < S
+  static constexpr int stores_before_step(int S, int CT, int D) {
+    int s = 0;
+    const int l = L - 1, nch = CT * 8;
+    for (int nt = 0; nt + 1 < nt_of(l); ++nt) {
+      const int cpk = chunks_per_kstep(gtile(l, nt), nch);
+      const int nb = tile_base(l, nt + 1);  // aux item of the next tile
+      for (int c = 0; c < nch; ++c)
+        if (nb + 1 + c / cpk + D < S) s += 2;
+    }
+    return s;
+  }
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is 6 bits");
+  // one statement: nothing that touches memory may move across the rendezvous
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst+1 KiB).
+// Issued through inline asm ON PURPOSE: with the builtin form hipcc (ROCm 7.2) treats
+// the DMA as a pending LDS event and degrades every later LDS-read wait in the kernel
+// from a counted lgkmcnt(N) to lgkmcnt(0).  The statement has no VGPR destination, so
+// it is register-safe; completion is tracked by hand (wait_vmcnt_barrier).  M0 is
+// saved/restored inside the statement because the compiler owns it.
+__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+
+// LDS-DMA of block B of the stream into ring slot B % kRing: wave w moves
+// fragments w, w+4, ... (1 KiB each, lane-linear both sides).
+template <class G, int B>
+__device__ __forceinline__ void issue_block(const unsigned char* gstream, unsigned char* smem,
+                                            int wave, int lane) {
+  if constexpr (B >= 0 && B < G::n_blocks()) {
+    constexpr int NG = G::blk_glds(B);
+    const unsigned char* g = gstream + (size_t)B * kBlkFrags * kFragBytes + wave * kFragBytes + lane * 16;
+    const unsigned s = lds_addr(smem) + (B % kRing) * kBlkFrags * kFragBytes + wave * kFragBytes;
+    static_for<NG>([&](auto i) __attribute__((always_inline)) {
+      constexpr int I = decltype(i)::value;
+      glds16(g + I * kWaves * kFragBytes, s + I * kWaves * kFragBytes);
+    });
+  }
+}
+
+// Before the LDS read of item S (S = first item of block B): wait until this wave's
+// share of block B has landed, rendezvous (now every wave's share has), then refill
+// the slot of block B-2, which every wave has finished consuming (D <= kBlkFrags).
+// The prologue issued blocks 0..kRing-1; boundary B' >= 2 issues block B'+kRing-2.
+template <class G, int CT, int D, int S>
+__device__ __forceinline__ void ring_boundary(const unsigned char* gstream, unsigned char* smem,
+                                              int wave, int lane) {
+  if constexpr (S % kBlkFrags == 0 && S < G::padded()) {
+    constexpr int B = S / kBlkFrags;
+    constexpr int last_issued = (B + kRing - 3 > kRing - 1) ? B + kRing - 3 : kRing - 1;
+    constexpr int GA = [] {
+      int s = 0;
+      for (int i = B + 1; i <= last_issued; ++i) s += G::blk_glds(i);
+      return s;
+    }();
+    // stores younger than block B's DMA: issued in steps [S_issue, S)
+    constexpr int S_issue = (B < kRing) ? 0 : (B - kRing + 2) * kBlkFrags;
+    constexpr int SA = G::stores_before_step(S, CT, D) - G::stores_before_step(S_issue, CT, D);
+    constexpr int N = (GA + SA) > 63 ? 63 : (GA + SA);
+    wait_vmcnt_barrier<N>();
+    if constexpr (B >= 2) issue_block<G, B + kRing - 2>(gstream, smem, wave, lane);
+  }
+}
+
+template <int F> __device__ __forceinline__ const unsigned char* frag_ptr(const unsigned char* smem, int lane) {
+  constexpr int B = F / kBlkFrags;
+  return smem + ((B % kRing) * kBlkFrags + (F % kBlkFrags)) * kFragBytes + lane * 16;
+}
+
+// ---- the kernel -------------------------------------------------------------------
+// grid.x = ceil(n_rows / (kWaves*CT*32)); block = 256 threads; dynamic LDS kFusedLds.
+template <class Arch, class P, bool PIN>
+__global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = Geo<Arch, P>;
+  using frag = typename P::frag;
+  using elem = typename P::elem;
+  using Item = typename G::Item;
+  constexpr int L = G::L, CT = P::CT, EPI = P::EPI, FPI = P::FPI, IPT = G::IPT;
+  constexpr int KSM = G::ks_max();
+  constexpr int D = 2;  // LDS read-ahead, in fragments
+  constexpr int TOTAL = G::total();
+  constexpr int NOUT = G::dim(L);
+  constexpr int NCH = CT * 8;  // epilogue chunks per tile
+  static_assert(G::act(L - 1) == 0, "output layer must be linear");
+  static_assert(D <= kBlkFrags, "read-ahead must stay within one block");
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const long long wg_row0 = (long long)blockIdx.x * (kWaves * CT * 32);
+  const long long row0 = wg_row0 + wave * (CT * 32);
+
+  frag bufA[CT][KSM], bufB[CT][KSM];
+
+  // ---- layer-0 operand: x rows -> operand registers; optional fused par_transform
+  {
+    constexpr int K0 = G::dim(0);
+    static_for<CT>([&](auto ct_) __attribute__((always_inline)) {
+      constexpr int ct = decltype(ct_)::value;
+      const long long row = row0 + ct * 32 + r;
+      const bool ok = row < a.n_rows;
+      const float* xr = a.x + (ok ? row : 0) * a.ldx;
+      static_for<G::ks_of(0)>([&](auto ks_) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_)::value;
+        frag v;
+        static_for<EPI>([&](auto e_) __attribute__((always_inline)) {
+          constexpr int e = decltype(e_)::value;
+          constexpr int f0 = FPI * ks + 8 * (e >> 2) + (e & 3);  // lanes h = 0
+          constexpr int f1 = f0 + 4;                             // lanes h = 1
+          float t = 0.f;
+          if constexpr (f0 < K0) {
+            const bool valid = ok && (h == 0 || f1 < K0);
+            if (valid) {
+              t = xr[f0 + 4 * h];
+              if (a.in_transform) {
+                constexpr int g1 = f1 < 8 ? f1 : 7;
+                constexpr int g0 = f0 < 8 ? f0 : 7;
+                const float zf = h ? a.tin.zero_floor[g1] : a.tin.zero_floor[g0];
+                const int lm = h ? a.tin.log_mask[g1] : a.tin.log_mask[g0];
+                const float lo = h ? a.tin.lo[g1] : a.tin.lo[g0];
+                const float sc = h ? a.tin.scale[g1] : a.tin.scale[g0];
+                if (zf > 0.f && t == 0.f) t = zf;
+                if (lm) t = __log10f(t);
+                t = (t - lo) * sc - 1.0f;
+              }
+            }
+          }
+          v[e] = (elem)t;
+        });
+        bufA[ct][ks] = v;
+      });
+    });
+  }
+
+  // ---- ring prologue: blocks 0..kRing-1 in flight
+  static_for<kRing>([&](auto b) __attribute__((always_inline)) {
+    issue_block<G, decltype(b)::value>(a.stream, smem, wave, lane);
+  });
+
+  // output addressing (last layer): per-workgroup buffer resource so that rows past
+  // n_rows and columns past out_dim are dropped by the hardware range check while the
+  // store instruction still issues (keeps the vmcnt arithmetic of ring_boundary exact).
+  long long wg_rows = a.n_rows - wg_row0;
+  if (wg_rows > kWaves * CT * 32) wg_rows = kWaves * CT * 32;
+  if (wg_rows < 0) wg_rows = 0;
+  const unsigned out_bytes = (unsigned)(wg_rows * a.ldy * 4);
+  __amdgpu_buffer_rsrc_t orsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + wg_row0 * a.ldy), 0, out_bytes, 0x00020000);
+  const unsigned ldy_b = (unsigned)a.ldy * 4u;
+
+  frag q[D + 1];      // fragments in flight LDS -> registers
+  f32x16 auxb[2];     // aux fragment of the tile being started (by tile parity)
+  f32x16 acc[2][CT];  // accumulators, double-buffered by tile parity
+
+  // chunk c = (ct, register pair) of the epilogue of global tile GT (compile-time):
+  // hidden layer -> ReLU (+ pack) two values into the next layer's operand registers;
+  // output layer -> Dense bias + preprocess.unpreproc + two row-segment stores.
+  auto epilogue_chunk = [&](auto g_, auto c_) __attribute__((always_inline)) {
+    constexpr int GT = decltype(g_)::value;
+    constexpr int c = decltype(c_)::value;
+    constexpr Item t = G::tile_at(GT);
+    constexpr int l = t.l, nt = t.nt;
+    constexpr int ct = c / 8, pr = c % 8;  // accumulator registers 2pr, 2pr+1
+    if constexpr (l < L - 1) {
+      constexpr int item = IPT * nt + (2 * pr) / EPI, e0 = (2 * pr) % EPI;
+      if constexpr (item < G::ks_of(l + 1)) {
+        auto& out = (l & 1) ? bufA : bufB;
+        float x0 = acc[GT & 1][ct][2 * pr], x1 = acc[GT & 1][ct][2 * pr + 1];
+        if constexpr (G::act(l) != 0) {
+          // ReLU as a signed-integer max on the bit pattern: one VALU op, no
+          // canonicalising pre-pass (negative floats are negative integers)
+          x0 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x0), 0));
+          x1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x1), 0));
+        }
+        out[ct][item][e0] = (elem)x0;
+        out[ct][item][e0 + 1] = (elem)x1;
+      }
+    } else {
+      const float obias = auxb[GT & 1][0], omean = auxb[GT & 1][1] * a.out_mean_scale;
+      const int col = 32 * nt + r;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = 2 * pr + u;
+        const unsigned row_in_wg = wave * (CT * 32) + ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        // (acc + bias) * std + mean, each rounded to f32 as numpy does (unpreproc)
+        const float y = (acc[GT & 1][ct][i] + obias) * a.out_std + omean;
+        unsigned off = row_in_wg * ldy_b + (unsigned)col * 4u;
+        if (col >= NOUT) off = 0xFFFFFFF0u;  // out of range -> dropped by the range check
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), orsrc, off, 0, 0);
+      }
+    }
+  };
+  auto epilogue_range = [&](auto g_, auto lo_, auto hi_) __attribute__((always_inline)) {
+    constexpr int LO = decltype(lo_)::value, HI = decltype(hi_)::value;
+    static_for<(HI > LO ? HI - LO : 0)>([&](auto k) __attribute__((always_inline)) {
+      epilogue_chunk(g_, std::integral_constant<int, LO + decltype(k)::value>{});
+    });
+  };
+
+  static_for<TOTAL + D>([&](auto s_) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_)::value;
+    // ---- load side: item S
+    if constexpr (S < TOTAL) {
+      ring_boundary<G, CT, D, S>(a.stream, smem, wave, lane);
+      constexpr Item it = G::item_at(S);
+      if constexpr (it.ks >= 0) {
+        q[S % (D + 1)] = *(const frag*)frag_ptr<S>(smem, lane);
+      } else {
+        constexpr int GT = G::gtile(it.l, it.nt);
+        const unsigned char* aux = frag_ptr<S>(smem, 0);
+        if constexpr (it.l < L - 1) {
+          // bias[32nt + rho(reg) + 4h]: the accumulator's initial value
+          const f32x4* bp = (const f32x4*)(aux + h * 64);
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 t = bp[qd];
+            auxb[GT & 1][4 * qd + 0] = t[0]; auxb[GT & 1][4 * qd + 1] = t[1];
+            auxb[GT & 1][4 * qd + 2] = t[2]; auxb[GT & 1][4 * qd + 3] = t[3];
+          }
+        } else {
+          auxb[GT & 1][0] = ((const float*)aux)[r];       // bias[32nt + c]
+          auxb[GT & 1][1] = ((const float*)aux)[32 + r];  // mean[32nt + c]
+        }
+      }
+    }
+    // ---- compute side: item S - D
+    if constexpr (S >= D) {
+      constexpr int C = S - D;
+      constexpr Item it = G::item_at(C);
+      if constexpr (it.ks >= 0) {
+        constexpr int GT = G::gtile(it.l, it.nt);
+        constexpr int GP = GT > 0 ? GT - 1 : 0;  // previous tile: its epilogue is pending
+        constexpr int CPK = G::chunks_per_kstep(GP, NCH);
+        constexpr bool whole_first = (GT > 0) && (G::spread_limit(GP) == 0);
+        if constexpr (whole_first && it.ks == 0)
+          epilogue_range(std::integral_constant<int, GP>{}, std::integral_constant<int, 0>{},
+                         std::integral_constant<int, NCH>{});
+        auto& in = (it.l & 1) ? bufB : bufA;
+        const frag w = q[C % (D + 1)];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          f32x16 c0;
+          if constexpr (it.ks == 0) {
+            if constexpr (it.l < L - 1) c0 = auxb[GT & 1];
+            else
+#pragma unroll
+              for (int i = 0; i < 16; ++i) c0[i] = 0.f;
+          } else {
+            c0 = acc[GT & 1][ct];
+          }
+          acc[GT & 1][ct] = P::template mfma<(it.l == L - 1)>(w, in[ct][it.ks], c0);
+        }
+        if constexpr (GT > 0 && !whole_first) {
+          constexpr int lo = it.ks * CPK < NCH ? it.ks * CPK : NCH;
+          constexpr int hi = (it.ks + 1) * CPK < NCH ? (it.ks + 1) * CPK : NCH;
+          epilogue_range(std::integral_constant<int, GP>{}, std::integral_constant<int, lo>{},
+                         std::integral_constant<int, hi>{});
+        }
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  });
+  epilogue_range(std::integral_constant<int, G::n_tiles() - 1>{}, std::integral_constant<int, 0>{},
+                 std::integral_constant<int, NCH>{});
+}
+
+}  // namespace v21

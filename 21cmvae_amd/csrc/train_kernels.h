@@ -1,0 +1,183 @@
+// train_kernels.h -- the non-GEMM kernels of a training step and of the generic
+// forward path (gfx950).  All are HBM/L2 streaming kernels: coalesced 4-byte or 16-byte
+// accesses, one wave per row where a row reduction is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/v21.h"
+
+namespace v21 {
+
+// K5: dst[i, :] = src[idx[i], :]  -- the Keras data adapter's shuffled batch
+// (emulator.py:369-378 [K]).  idx == nullptr -> rows first..first+n-1.
+__global__ void gather_rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                   const int* __restrict__ idx, long long first, int n, int d,
+                                   long long lds_, long long ldd) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const long long s = idx ? (long long)idx[first + row] : first + row;
+  const float* sp = src + s * lds_;
+  float* dp = dst + (long long)row * ldd;
+  for (int j = lane; j < d; j += 64) dp[j] = sp[j];
+}
+__global__ void gather_vec_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                  const int* __restrict__ idx, long long first, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx ? (long long)idx[first + i] : first + i];
+}
+
+// K2: loss_i = w_i sum_j (p - y)^2 (relative_mse_loss, emulator.py:68-81, with
+// w_i = 1/(D amp_i^2); plain MSE w_i = 1/D) and dL/dp = scale * w_i * (p - y),
+// scale = 2 / B_global ([K]: batch loss = mean of per-sample losses).
+// One wave per row; WRITE_GRAD = false is the validation pass.
+template <bool WRITE_GRAD>
+__global__ void loss_grad_kernel(const float* __restrict__ p, long long ldp,
+                                 const float* __restrict__ y, long long ldy,
+                                 const float* __restrict__ w, float* __restrict__ dz,
+                                 long long lddz, float* __restrict__ rowloss, int n, int d,
+                                 float scale) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float wi = w[row];
+  const float gs = scale * wi;
+  const float* pr = p + (long long)row * ldp;
+  const float* yr = y + (long long)row * ldy;
+  float s = 0.f;
+  for (int j = lane; j < d; j += 64) {
+    const float df = pr[j] - yr[j];
+    s += df * df;
+    if (WRITE_GRAD) dz[(long long)row * lddz + j] = gs * df;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) rowloss[row] = wi * s;
+}
+
+// deterministic sum of n floats by ONE workgroup -> out[0] (n <= a few 10^5)
+__global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out, int accumulate) {
+  __shared__ double part[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)v[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
+    out[0] = accumulate ? out[0] + (float)t : (float)t;
+  }
+}
+
+// K4: Keras-2.7 Adam (tf.raw_ops.ResourceApplyAdam [K]):
+//   m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);  w -= alpha m / (sqrt(v) + eps)
+// alpha = lr sqrt(1-b2^t)/(1-b1^t) is computed by the host in f32.  One flat arena,
+// float4 per lane; gscale folds 1/nranks-style factors (1.0 here: the loss gradient
+// already carries 1/B_global).
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, long long n,
+                            float alpha, float omb1, float omb2, float eps) {
+  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    float4 W = *(float4*)(w + i4), G = *(const float4*)(g + i4), M = *(float4*)(m + i4),
+           V = *(float4*)(v + i4);
+    float* wp = &W.x; const float* gp = &G.x; float* mp = &M.x; float* vp = &V.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mp[k] = mp[k] + (gp[k] - mp[k]) * omb1;
+      vp[k] = vp[k] + (gp[k] * gp[k] - vp[k]) * omb2;
+      wp[k] = wp[k] - (mp[k] * alpha) / (sqrtf(vp[k]) + eps);
+    }
+    *(float4*)(w + i4) = W; *(float4*)(m + i4) = M; *(float4*)(v + i4) = V;
+  } else {
+    for (long long i = i4; i < n; ++i) {
+      const float gi = g[i];
+      const float mi = m[i] + (gi - m[i]) * omb1;
+      const float vi = v[i] + (gi * gi - v[i]) * omb2;
+      m[i] = mi; v[i] = vi;
+      w[i] = w[i] - (mi * alpha) / (sqrtf(vi) + eps);
+    }
+  }
+}
+
+// generic-path prologue / epilogue (the fused kernel does these in registers)
+__global__ void affine_in_kernel(float* __restrict__ dst, long long ldd, const float* __restrict__ src,
+                                 long long lds_, long long n, const v21_affine_in t) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * t.n) return;
+  const long long row = i / t.n;
+  const int j = (int)(i % t.n);
+  float x = src[row * lds_ + j];
+  if (t.zero_floor[j] > 0.f && x == 0.f) x = t.zero_floor[j];
+  if (t.log_mask[j]) x = __log10f(x);
+  dst[row * ldd + j] = (x - t.lo[j]) * t.scale[j] - 1.0f;
+}
+__global__ void affine_out_kernel(float* __restrict__ y, long long ldy, long long n, int d,
+                                  float stdv, const float* __restrict__ mean) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * d) return;
+  const long long row = i / d;
+  const int j = (int)(i % d);
+  y[row * ldy + j] = y[row * ldy + j] * stdv + mean[j];
+}
+
+// Weight stream of the fused forward kernel (fused_fwd.h): one thread per (fragment,
+// lane).  Layer table in `lt`: per layer {K, N, ks, nt, w_off, b_off, first_frag}.
+struct PackLayer { int K, N, ks, nt; long long w_off, b_off; int first; int pad; };
+struct PackArgs {
+  const float* w;        // flat arena
+  const float* mean;     // out_dim floats or nullptr
+  unsigned char* stream;
+  int L, total, padded, fpi, epi, esize;  // esize: 2 (f16/bf16) or 4 (f32)
+  int is_bf16;
+  PackLayer lt[16];
+};
+__global__ void pack_stream_kernel(const PackArgs a) {
+  const int F = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (F >= a.padded) return;
+  unsigned char* dst = a.stream + (size_t)F * 1024;
+  if (F >= a.total) {  // tail padding
+    ((float4*)dst)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  int l = 0;
+  while (l + 1 < a.L && F >= a.lt[l + 1].first) ++l;
+  const PackLayer L = a.lt[l];
+  const int rel = F - L.first, tl = L.ks + 1;
+  const int nt = rel / tl, ks = rel % tl - 1;
+  const int r = lane & 31, h = lane >> 5;
+  if (ks < 0) {  // aux fragment: 256 floats, 4 per lane
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) {
+      const int idx = lane * 4 + q;
+      float v = 0.f;
+      if (l < a.L - 1) {
+        if (idx < 32) {  // [h][reg]: bias[32nt + rho(reg) + 4h]
+          const int hh = idx >> 4, reg = idx & 15;
+          const int n = 32 * nt + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+          if (n < L.N) v = a.w[L.b_off + n];
+        }
+      } else {
+        if (idx < 32) { const int n = 32 * nt + idx; if (n < L.N) v = a.w[L.b_off + n]; }
+        else if (idx < 64) { const int n = 32 * nt + idx - 32; if (n < L.N && a.mean) v = a.mean[n]; }
+      }
+      out[q] = v;
+    }
+    ((float4*)dst)[lane] = make_float4(out[0], out[1], out[2], out[3]);
+    return;
+  }
+  const int n = 32 * nt + r;
+  for (int e = 0; e < a.epi; ++e) {
+    const int f = a.fpi * ks + 8 * (e >> 2) + 4 * h + (e & 3);
+    float v = 0.f;
+    if (f < L.K && n < L.N) v = a.w[L.w_off + (long long)f * L.N + n];
+    if (a.esize == 4) ((float*)dst)[lane * 4 + e] = v;
+    else if (a.is_bf16) ((__bf16*)dst)[lane * 8 + e] = (__bf16)v;
+    else ((_Float16*)dst)[lane * 8 + e] = (_Float16)v;
+  }
+}
+
+}  // namespace v21

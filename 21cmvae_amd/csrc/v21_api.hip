@@ -1,0 +1,870 @@
+// v21_api.hip -- implementation of the C ABI declared in include/v21.h.
+//
+// Host-side orchestration of the HIP kernels in fused_fwd.h (K1), gemm.h (K3) and
+// train_kernels.h (K2, K4, K5): contexts and streams, the flat fp32 parameter arena
+// (Keras get_weights() order), the packed weight stream of the fused forward kernel,
+// the per-layer fallback, the Keras-fit()-shaped epoch driver and the RCCL gradient
+// all-reduce (K6; RCCL is dlopen'ed so single-GPU users never need it).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/v21.h"
+#include "archs.h"
+#include "fused_fwd.h"
+#include "gemm.h"
+#include "train_kernels.h"
+
+using namespace v21;
+
+// ---------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(V21_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+#define CHK(expr)            \
+  do {                       \
+    int r_ = (expr);         \
+    if (r_ != V21_OK) return r_; \
+  } while (0)
+
+extern "C" const char* v21_last_error(void) { return g_err.c_str(); }
+extern "C" int v21_version(void) { return 100; }
+extern "C" int v21_device_count(int* n) {
+  if (!n) return fail(V21_ERR_ARG, "null n");
+  HIPCHK(hipGetDeviceCount(n));
+  return V21_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// RCCL, loaded at run time
+// ---------------------------------------------------------------------------------
+struct nccl_uid { char internal[128]; };
+typedef void* nccl_comm;
+typedef int (*fn_GetUniqueId)(nccl_uid*);
+typedef int (*fn_CommInitRank)(nccl_comm*, int, nccl_uid, int);
+typedef int (*fn_AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
+typedef int (*fn_CommDestroy)(nccl_comm);
+typedef const char* (*fn_GetErrorString)(int);
+struct RcclApi {
+  void* lib = nullptr;
+  fn_GetUniqueId GetUniqueId = nullptr;
+  fn_CommInitRank CommInitRank = nullptr;
+  fn_AllReduce AllReduce = nullptr;
+  fn_CommDestroy CommDestroy = nullptr;
+  fn_GetErrorString GetErrorString = nullptr;
+};
+static RcclApi g_rccl;
+static int load_rccl() {
+  if (g_rccl.lib) return V21_OK;
+  const char* cands[] = {getenv("V21_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* c : cands) {
+    if (!c || !*c) continue;
+    lib = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(V21_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
+  g_rccl.GetUniqueId = (fn_GetUniqueId)dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (fn_CommInitRank)dlsym(lib, "ncclCommInitRank");
+  g_rccl.AllReduce = (fn_AllReduce)dlsym(lib, "ncclAllReduce");
+  g_rccl.CommDestroy = (fn_CommDestroy)dlsym(lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (fn_GetErrorString)dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    return fail(V21_ERR_COMM, "librccl lacks a required symbol");
+  g_rccl.lib = lib;
+  return V21_OK;
+}
+static const char* rccl_err(int r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"; }
+
+// ---------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------
+struct v21_ctx {
+  int device = 0;
+  hipStream_t own = nullptr, stream = nullptr;
+  nccl_comm comm = nullptr;
+  int nranks = 1, rank = 0;
+};
+static int use(v21_ctx* c) {
+  if (!c) return fail(V21_ERR_ARG, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  return V21_OK;
+}
+
+extern "C" int v21_ctx_create(int device, v21_ctx** out) {
+  if (!out) return fail(V21_ERR_ARG, "null out");
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(V21_ERR_ARG, "device %d out of range (%d visible)", device, n);
+  HIPCHK(hipSetDevice(device));
+  v21_ctx* c = new v21_ctx();
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail(V21_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  c->stream = c->own;
+  *out = c;
+  return V21_OK;
+}
+extern "C" int v21_ctx_destroy(v21_ctx* c) {
+  if (!c) return V21_OK;
+  hipSetDevice(c->device);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  if (c->own) { hipStreamSynchronize(c->own); hipStreamDestroy(c->own); }
+  delete c;
+  return V21_OK;
+}
+extern "C" int v21_ctx_sync(v21_ctx* c) { CHK(use(c)); HIPCHK(hipStreamSynchronize(c->stream)); return V21_OK; }
+extern "C" int v21_ctx_set_stream(v21_ctx* c, void* s) { CHK(use(c)); c->stream = s ? (hipStream_t)s : c->own; return V21_OK; }
+extern "C" int v21_ctx_get_stream(v21_ctx* c, void** s) { if (!c || !s) return fail(V21_ERR_ARG, "null"); *s = (void*)c->stream; return V21_OK; }
+
+extern "C" int v21_malloc(v21_ctx* c, size_t bytes, void** p) {
+  CHK(use(c));
+  if (!p) return fail(V21_ERR_ARG, "null dptr");
+  HIPCHK(hipMalloc(p, bytes ? bytes : 4));
+  return V21_OK;
+}
+extern "C" int v21_free(v21_ctx* c, void* p) { CHK(use(c)); if (p) HIPCHK(hipFree(p)); return V21_OK; }
+extern "C" int v21_memcpy_h2d(v21_ctx* c, void* d, const void* s, size_t b) {
+  CHK(use(c));
+  HIPCHK(hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return V21_OK;
+}
+extern "C" int v21_memcpy_d2h(v21_ctx* c, void* d, const void* s, size_t b) {
+  CHK(use(c));
+  HIPCHK(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return V21_OK;
+}
+extern "C" int v21_memset(v21_ctx* c, void* d, int v, size_t b) { CHK(use(c)); HIPCHK(hipMemsetAsync(d, v, b, c->stream)); return V21_OK; }
+extern "C" int v21_event_create(v21_ctx* c, void** ev) {
+  CHK(use(c));
+  hipEvent_t e;
+  HIPCHK(hipEventCreate(&e));
+  *ev = (void*)e;
+  return V21_OK;
+}
+extern "C" int v21_event_destroy(v21_ctx* c, void* ev) { CHK(use(c)); HIPCHK(hipEventDestroy((hipEvent_t)ev)); return V21_OK; }
+extern "C" int v21_event_record(v21_ctx* c, void* ev) { CHK(use(c)); HIPCHK(hipEventRecord((hipEvent_t)ev, c->stream)); return V21_OK; }
+extern "C" int v21_event_elapsed_ms(v21_ctx* c, void* a, void* b, float* ms) {
+  CHK(use(c));
+  HIPCHK(hipEventSynchronize((hipEvent_t)b));
+  HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return V21_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// fused-kernel registry
+// ---------------------------------------------------------------------------------
+namespace v21 {
+#define V21_DECL(a)                                                          \
+  hipError_t launch_fused_##a##_F32(const FusedArgs&, int, hipStream_t);     \
+  hipError_t launch_fused_##a##_F16(const FusedArgs&, int, hipStream_t);     \
+  hipError_t launch_fused_##a##_BF16(const FusedArgs&, int, hipStream_t);
+V21_ARCH_LIST(V21_DECL)
+#undef V21_DECL
+}  // namespace v21
+
+typedef hipError_t (*fused_launcher)(const FusedArgs&, int, hipStream_t);
+struct FusedEntry {
+  int L;
+  const int* dims;
+  const int* act;
+  fused_launcher fn[3];
+};
+#define V21_ENTRY(a) \
+  {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_##a##_F32, launch_fused_##a##_F16, launch_fused_##a##_BF16}},
+static const FusedEntry g_fused[] = {V21_ARCH_LIST(V21_ENTRY)};
+#undef V21_ENTRY
+
+// ---------------------------------------------------------------------------------
+// dense stack
+// ---------------------------------------------------------------------------------
+struct v21_mlp {
+  v21_ctx* ctx = nullptr;
+  int L = 0;
+  std::vector<int> dims, act;
+  std::vector<long long> w_off, b_off;
+  size_t nparams = 0;
+  float* d_w = nullptr;  // nparams (+4 pad) floats
+  int fused_id = -1;
+  unsigned char* d_stream[3] = {nullptr, nullptr, nullptr};
+  bool stream_ok[3] = {false, false, false};
+  bool has_tin = false, has_tout = false;
+  v21_affine_in tin{};
+  float out_std = 1.f;
+  float* d_mean = nullptr;
+  // generic path scratch
+  float* d_act[2] = {nullptr, nullptr};
+  long long act_rows = 0;
+  // host-API staging
+  float *d_xs = nullptr, *d_ys = nullptr;
+  long long stage_rows = 0;
+  int maxdim = 0;
+};
+
+static int fpi_of(int prec) { return prec == V21_PREC_F32 ? 8 : 16; }
+static void stream_geometry(const v21_mlp* m, int prec, int* total, int* padded) {
+  int f = 0;
+  for (int l = 0; l < m->L; ++l) f += ((m->dims[l + 1] + 31) / 32) * ((m->dims[l] + fpi_of(prec) - 1) / fpi_of(prec) + 1);
+  *total = f;
+  *padded = (f + 3) / 4 * 4;
+}
+
+extern "C" int v21_mlp_create(v21_ctx* ctx, int n_layers, const int* dims, const int* act, v21_mlp** out) {
+  CHK(use(ctx));
+  if (!dims || !act || !out) return fail(V21_ERR_ARG, "null argument");
+  if (n_layers < 1 || n_layers > 16) return fail(V21_ERR_ARG, "n_layers %d not in [1,16]", n_layers);
+  for (int i = 0; i <= n_layers; ++i)
+    if (dims[i] < 1 || dims[i] > 65536) return fail(V21_ERR_ARG, "dims[%d] = %d out of range", i, dims[i]);
+  for (int i = 0; i < n_layers; ++i)
+    if (act[i] != V21_ACT_LINEAR && act[i] != V21_ACT_RELU) return fail(V21_ERR_ARG, "act[%d] = %d unknown", i, act[i]);
+  v21_mlp* m = new v21_mlp();
+  m->ctx = ctx;
+  m->L = n_layers;
+  m->dims.assign(dims, dims + n_layers + 1);
+  m->act.assign(act, act + n_layers);
+  long long o = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    m->w_off.push_back(o); o += (long long)dims[l] * dims[l + 1];
+    m->b_off.push_back(o); o += dims[l + 1];
+  }
+  m->nparams = (size_t)o;
+  m->maxdim = *std::max_element(m->dims.begin(), m->dims.end());
+  hipError_t e = hipMalloc((void**)&m->d_w, (m->nparams + 4) * sizeof(float));
+  if (e != hipSuccess) { delete m; return fail(V21_ERR_HIP, "hipMalloc weights: %s", hipGetErrorString(e)); }
+  hipMemsetAsync(m->d_w, 0, (m->nparams + 4) * sizeof(float), ctx->stream);
+  for (size_t i = 0; i < sizeof(g_fused) / sizeof(g_fused[0]); ++i) {
+    const FusedEntry& fe = g_fused[i];
+    if (fe.L != n_layers) continue;
+    bool same = true;
+    for (int k = 0; k <= n_layers && same; ++k) same = fe.dims[k] == dims[k];
+    for (int k = 0; k < n_layers && same; ++k) same = fe.act[k] == act[k];
+    if (same) { m->fused_id = (int)i; break; }
+  }
+  *out = m;
+  return V21_OK;
+}
+extern "C" int v21_mlp_destroy(v21_mlp* m) {
+  if (!m) return V21_OK;
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  hipFree(m->d_w);
+  for (int i = 0; i < 3; ++i) if (m->d_stream[i]) hipFree(m->d_stream[i]);
+  if (m->d_mean) hipFree(m->d_mean);
+  for (int i = 0; i < 2; ++i) if (m->d_act[i]) hipFree(m->d_act[i]);
+  if (m->d_xs) hipFree(m->d_xs);
+  if (m->d_ys) hipFree(m->d_ys);
+  delete m;
+  return V21_OK;
+}
+extern "C" int v21_mlp_num_params(const v21_mlp* m, size_t* n) {
+  if (!m || !n) return fail(V21_ERR_ARG, "null argument");
+  *n = m->nparams;
+  return V21_OK;
+}
+static void invalidate_streams(v21_mlp* m) { m->stream_ok[0] = m->stream_ok[1] = m->stream_ok[2] = false; }
+
+extern "C" int v21_mlp_set_weights(v21_mlp* m, const float* flat, size_t n) {
+  if (!m || !flat) return fail(V21_ERR_ARG, "null argument");
+  if (n != m->nparams) return fail(V21_ERR_ARG, "set_weights: got %zu floats, stack has %zu", n, m->nparams);
+  CHK(use(m->ctx));
+  HIPCHK(hipMemcpyAsync(m->d_w, flat, n * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));
+  invalidate_streams(m);
+  return V21_OK;
+}
+extern "C" int v21_mlp_get_weights(v21_mlp* m, float* flat, size_t n) {
+  if (!m || !flat) return fail(V21_ERR_ARG, "null argument");
+  if (n != m->nparams) return fail(V21_ERR_ARG, "get_weights: got room for %zu floats, stack has %zu", n, m->nparams);
+  CHK(use(m->ctx));
+  HIPCHK(hipMemcpyAsync(flat, m->d_w, n * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));
+  return V21_OK;
+}
+extern "C" int v21_mlp_set_input_transform(v21_mlp* m, const v21_affine_in* t) {
+  if (!m) return fail(V21_ERR_ARG, "null mlp");
+  if (!t) { m->has_tin = false; return V21_OK; }
+  if (t->n != m->dims[0] || t->n > 8) return fail(V21_ERR_ARG, "input transform: n = %d, stack input = %d (max 8)", t->n, m->dims[0]);
+  m->tin = *t;
+  m->has_tin = true;
+  return V21_OK;
+}
+extern "C" int v21_mlp_set_output_transform(v21_mlp* m, const v21_affine_out* t) {
+  if (!m) return fail(V21_ERR_ARG, "null mlp");
+  CHK(use(m->ctx));
+  invalidate_streams(m);
+  if (!t) { m->has_tout = false; return V21_OK; }
+  if (t->n != m->dims[m->L] || !t->mean) return fail(V21_ERR_ARG, "output transform: n = %d, stack output = %d", t->n, m->dims[m->L]);
+  if (!m->d_mean) HIPCHK(hipMalloc((void**)&m->d_mean, (size_t)t->n * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(m->d_mean, t->mean, (size_t)t->n * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));
+  m->out_std = t->std;
+  m->has_tout = true;
+  return V21_OK;
+}
+extern "C" int v21_mlp_has_fused(const v21_mlp* m, int precision, int* yes) {
+  if (!m || !yes) return fail(V21_ERR_ARG, "null argument");
+  if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
+  *yes = m->fused_id >= 0 ? 1 : 0;
+  return V21_OK;
+}
+
+static int ensure_stream(v21_mlp* m, int prec) {
+  if (m->stream_ok[prec]) return V21_OK;
+  int total, padded;
+  stream_geometry(m, prec, &total, &padded);
+  if (!m->d_stream[prec]) HIPCHK(hipMalloc((void**)&m->d_stream[prec], (size_t)padded * 1024));
+  PackArgs pa{};
+  pa.w = m->d_w;
+  pa.mean = m->has_tout ? m->d_mean : nullptr;
+  pa.stream = m->d_stream[prec];
+  pa.L = m->L;
+  pa.total = total;
+  pa.padded = padded;
+  pa.fpi = fpi_of(prec);
+  pa.epi = prec == V21_PREC_F32 ? 4 : 8;
+  pa.esize = prec == V21_PREC_F32 ? 4 : 2;
+  pa.is_bf16 = prec == V21_PREC_BF16;
+  int f = 0;
+  for (int l = 0; l < m->L; ++l) {
+    PackLayer& pl = pa.lt[l];
+    pl.K = m->dims[l]; pl.N = m->dims[l + 1];
+    pl.ks = (pl.K + pa.fpi - 1) / pa.fpi; pl.nt = (pl.N + 31) / 32;
+    pl.w_off = m->w_off[l]; pl.b_off = m->b_off[l];
+    pl.first = f;
+    f += pl.nt * (pl.ks + 1);
+  }
+  hipLaunchKernelGGL(pack_stream_kernel, dim3((padded + 3) / 4), dim3(256), 0, m->ctx->stream, pa);
+  HIPCHK(hipGetLastError());
+  m->stream_ok[prec] = true;
+  return V21_OK;
+}
+
+template <class P, int EP>
+static int launch_gemm(const GemmArgs& g, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0) return V21_OK;
+  dim3 grid((g.N + kBN - 1) / kBN, (g.M + kBM - 1) / kBM);
+  hipLaunchKernelGGL((gemm_kernel<P, EP>), grid, dim3(256), 0, st, g);
+  HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+template <int EP>
+static int launch_gemm_prec(int prec, const GemmArgs& g, hipStream_t st) {
+  switch (prec) {
+    case V21_PREC_F32: return launch_gemm<PrecF32, EP>(g, st);
+    case V21_PREC_F16: return launch_gemm<PrecF16, EP>(g, st);
+    case V21_PREC_BF16: return launch_gemm<PrecBF16, EP>(g, st);
+  }
+  return fail(V21_ERR_ARG, "precision %d unknown", prec);
+}
+
+// one dense layer: out = act(in W + b)
+static int dense_forward(v21_mlp* m, int l, const float* in, long long ldin, float* out, long long ldout,
+                         int rows, int prec, hipStream_t st) {
+  GemmArgs g{};
+  g.A = in; g.sa_m = ldin; g.sa_k = 1;
+  g.B = m->d_w + m->w_off[l]; g.sb_k = m->dims[l + 1]; g.sb_n = 1;
+  g.C = out; g.ldc = ldout;
+  g.M = rows; g.N = m->dims[l + 1]; g.K = m->dims[l];
+  g.bias = m->d_w + m->b_off[l];
+  g.ones_row = -1; g.alpha = 1.f;
+  return m->act[l] == V21_ACT_RELU ? launch_gemm_prec<EP_BIAS_RELU>(prec, g, st) : launch_gemm_prec<EP_BIAS>(prec, g, st);
+}
+
+static int forward_generic(v21_mlp* m, const float* d_x, long long ldx, long long n, float* d_y, long long ldy,
+                           int prec, int flags) {
+  hipStream_t st = m->ctx->stream;
+  const long long chunk = 8192;
+  if (m->act_rows < chunk) {
+    for (int i = 0; i < 2; ++i) {
+      if (m->d_act[i]) HIPCHK(hipFree(m->d_act[i]));
+      HIPCHK(hipMalloc((void**)&m->d_act[i], (size_t)chunk * m->maxdim * sizeof(float)));
+    }
+    m->act_rows = chunk;
+  }
+  for (long long r0 = 0; r0 < n; r0 += chunk) {
+    const int rows = (int)std::min(chunk, n - r0);
+    const float* in = d_x + r0 * ldx;
+    long long ldin = ldx;
+    int cur = 0;
+    if ((flags & V21_FWD_IN_TRANSFORM) && m->has_tin) {
+      const long long tot = (long long)rows * m->dims[0];
+      hipLaunchKernelGGL(affine_in_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->d_act[0],
+                         (long long)m->dims[0], in, ldx, (long long)rows, m->tin);
+      HIPCHK(hipGetLastError());
+      in = m->d_act[0]; ldin = m->dims[0]; cur = 1;
+    }
+    for (int l = 0; l < m->L; ++l) {
+      const bool last = l == m->L - 1;
+      float* out = last ? d_y + r0 * ldy : m->d_act[cur];
+      const long long ldo = last ? ldy : m->dims[l + 1];
+      CHK(dense_forward(m, l, in, ldin, out, ldo, rows, prec, st));
+      in = out; ldin = ldo; cur ^= 1;
+    }
+    if ((flags & V21_FWD_OUT_TRANSFORM) && m->has_tout) {
+      const long long tot = (long long)rows * m->dims[m->L];
+      hipLaunchKernelGGL(affine_out_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_y + r0 * ldy,
+                         ldy, (long long)rows, m->dims[m->L], m->out_std, m->d_mean);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  return V21_OK;
+}
+
+extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, int64_t n, float* d_y, int64_t ldy,
+                                   int precision, int flags) {
+  if (!m || !d_x || !d_y) return fail(V21_ERR_ARG, "null argument");
+  if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
+  if (n < 0 || ldx < m->dims[0] || ldy < m->dims[m->L]) return fail(V21_ERR_ARG, "bad shape: n=%lld ldx=%lld ldy=%lld", (long long)n, (long long)ldx, (long long)ldy);
+  if (n == 0) return V21_OK;
+  CHK(use(m->ctx));
+  if ((flags & V21_FWD_IN_TRANSFORM) && !m->has_tin) return fail(V21_ERR_STATE, "input transform requested but not set");
+  if ((flags & V21_FWD_OUT_TRANSFORM) && !m->has_tout) return fail(V21_ERR_STATE, "output transform requested but not set");
+  const bool fused = m->fused_id >= 0 && !(flags & V21_FWD_FORCE_GENERIC) &&
+                     (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) && ldy < (1ll << 21);
+  if (!fused) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
+  CHK(ensure_stream(m, precision));
+  FusedArgs a{};
+  a.x = d_x; a.ldx = ldx; a.y = d_y; a.ldy = ldy; a.n_rows = n;
+  a.stream = m->d_stream[precision];
+  const bool tout = (flags & V21_FWD_OUT_TRANSFORM) != 0;
+  a.out_std = tout ? m->out_std : 1.0f;
+  a.out_mean_scale = tout ? 1.0f : 0.0f;
+  a.in_transform = (flags & V21_FWD_IN_TRANSFORM) ? 1 : 0;
+  if (a.in_transform) a.tin = m->tin;
+  static const int pin = getenv("V21_FUSED_PIN") ? atoi(getenv("V21_FUSED_PIN")) : 0;
+  HIPCHK(g_fused[m->fused_id].fn[precision](a, pin, m->ctx->stream));
+  return V21_OK;
+}
+
+extern "C" int v21_mlp_forward(v21_mlp* m, const void* x, int x_dtype, int64_t n, float* y, int precision, int flags) {
+  if (!m || !x || !y) return fail(V21_ERR_ARG, "null argument");
+  if (n < 0) return fail(V21_ERR_ARG, "negative row count");
+  if (x_dtype != V21_DTYPE_F32 && x_dtype != V21_DTYPE_F64) return fail(V21_ERR_ARG, "x_dtype %d unknown", x_dtype);
+  if (n == 0) return V21_OK;
+  CHK(use(m->ctx));
+  hipStream_t st = m->ctx->stream;
+  const int din = m->dims[0], dout = m->dims[m->L];
+  const long long chunk = 1 << 18;  // rows per host round trip
+  const long long need = std::min<long long>(n, chunk);
+  if (m->stage_rows < need) {
+    if (m->d_xs) HIPCHK(hipFree(m->d_xs));
+    if (m->d_ys) HIPCHK(hipFree(m->d_ys));
+    HIPCHK(hipMalloc((void**)&m->d_xs, (size_t)need * din * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&m->d_ys, (size_t)need * dout * sizeof(float)));
+    m->stage_rows = need;
+  }
+  std::vector<float> tmp;
+  for (long long r0 = 0; r0 < n; r0 += chunk) {
+    const long long rows = std::min(chunk, n - r0);
+    const float* src;
+    if (x_dtype == V21_DTYPE_F64) {  // Keras casts float64 inputs to float32 [K]
+      tmp.resize((size_t)rows * din);
+      const double* xd = (const double*)x + r0 * din;
+      for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (float)xd[i];
+      src = tmp.data();
+    } else {
+      src = (const float*)x + r0 * din;
+    }
+    HIPCHK(hipMemcpyAsync(m->d_xs, src, (size_t)rows * din * sizeof(float), hipMemcpyHostToDevice, st));
+    CHK(v21_mlp_forward_dev(m, m->d_xs, din, rows, m->d_ys, dout, precision, flags));
+    HIPCHK(hipMemcpyAsync(y + r0 * dout, m->d_ys, (size_t)rows * dout * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return V21_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// communicator
+// ---------------------------------------------------------------------------------
+extern "C" int v21_comm_get_unique_id(v21_ctx* c, void* id) {
+  CHK(use(c));
+  if (!id) return fail(V21_ERR_ARG, "null id");
+  CHK(load_rccl());
+  nccl_uid u;
+  int r = g_rccl.GetUniqueId(&u);
+  if (r != 0) return fail(V21_ERR_COMM, "ncclGetUniqueId: %s", rccl_err(r));
+  memcpy(id, &u, sizeof u);
+  return V21_OK;
+}
+extern "C" int v21_comm_init(v21_ctx* c, int nranks, int rank, const void* id) {
+  CHK(use(c));
+  if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(V21_ERR_ARG, "bad communicator arguments");
+  if (c->comm) return fail(V21_ERR_STATE, "communicator already initialised");
+  CHK(load_rccl());
+  nccl_uid u;
+  memcpy(&u, id, sizeof u);
+  int r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+  if (r != 0) { c->comm = nullptr; return fail(V21_ERR_COMM, "ncclCommInitRank: %s", rccl_err(r)); }
+  c->nranks = nranks;
+  c->rank = rank;
+  return V21_OK;
+}
+extern "C" int v21_comm_destroy(v21_ctx* c) {
+  CHK(use(c));
+  if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+  c->nranks = 1; c->rank = 0;
+  return V21_OK;
+}
+extern "C" int v21_comm_allreduce_f32(v21_ctx* c, float* d_buf, size_t n) {
+  CHK(use(c));
+  if (!c->comm) return V21_OK;  // single rank: identity
+  int r = g_rccl.AllReduce(d_buf, d_buf, n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->stream);
+  if (r != 0) return fail(V21_ERR_COMM, "ncclAllReduce: %s", rccl_err(r));
+  return V21_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// trainer
+// ---------------------------------------------------------------------------------
+struct v21_trainer {
+  v21_mlp* mlp = nullptr;
+  v21_ctx* ctx = nullptr;
+  int prec = 0, max_batch = 0;
+  v21_adam adam{1e-3f, 0.9f, 0.999f, 1e-7f};
+  long long iter = 0;
+  size_t P = 0;
+  float *d_g = nullptr, *d_m = nullptr, *d_v = nullptr;  // P + 4 floats; d_g[P] = loss slot
+  float* d_x[2] = {nullptr, nullptr};
+  float* d_y[2] = {nullptr, nullptr};
+  float* d_rw[2] = {nullptr, nullptr};
+  long long n[2] = {0, 0};
+  bool y_is_x[2] = {false, false};
+  int* d_perm = nullptr;
+  long long perm_cap = 0;
+  std::vector<float*> d_h;  // L+1 activation buffers (h[0] = batch input)
+  float* d_yb = nullptr;
+  float* d_wb = nullptr;
+  float* d_dz[2] = {nullptr, nullptr};
+  float* d_rowloss = nullptr;
+  float* d_steploss = nullptr;
+  long long steploss_cap = 0;
+  float* d_evalsum = nullptr;
+};
+
+extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_trainer** out) {
+  if (!m || !out) return fail(V21_ERR_ARG, "null argument");
+  if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
+  if (max_batch < 1 || max_batch > (1 << 20)) return fail(V21_ERR_ARG, "max_batch %d out of range", max_batch);
+  CHK(use(m->ctx));
+  v21_trainer* t = new v21_trainer();
+  t->mlp = m; t->ctx = m->ctx; t->prec = precision; t->max_batch = max_batch; t->P = m->nparams;
+  const size_t ab = (t->P + 4) * sizeof(float);
+  HIPCHK(hipMalloc((void**)&t->d_g, ab));
+  HIPCHK(hipMalloc((void**)&t->d_m, ab));
+  HIPCHK(hipMalloc((void**)&t->d_v, ab));
+  HIPCHK(hipMemsetAsync(t->d_g, 0, ab, t->ctx->stream));
+  HIPCHK(hipMemsetAsync(t->d_m, 0, ab, t->ctx->stream));
+  HIPCHK(hipMemsetAsync(t->d_v, 0, ab, t->ctx->stream));
+  t->d_h.resize(m->L + 1, nullptr);
+  for (int l = 0; l <= m->L; ++l) HIPCHK(hipMalloc((void**)&t->d_h[l], (size_t)max_batch * m->dims[l] * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&t->d_yb, (size_t)max_batch * m->dims[m->L] * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&t->d_wb, (size_t)max_batch * sizeof(float)));
+  for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc((void**)&t->d_dz[i], (size_t)max_batch * m->maxdim * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&t->d_rowloss, (size_t)max_batch * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&t->d_evalsum, 16));
+  *out = t;
+  return V21_OK;
+}
+extern "C" int v21_trainer_destroy(v21_trainer* t) {
+  if (!t) return V21_OK;
+  hipSetDevice(t->ctx->device);
+  hipStreamSynchronize(t->ctx->stream);
+  hipFree(t->d_g); hipFree(t->d_m); hipFree(t->d_v);
+  for (int i = 0; i < 2; ++i) {
+    if (t->d_x[i]) hipFree(t->d_x[i]);
+    if (t->d_y[i] && !t->y_is_x[i]) hipFree(t->d_y[i]);
+    if (t->d_rw[i]) hipFree(t->d_rw[i]);
+    hipFree(t->d_dz[i]);
+  }
+  if (t->d_perm) hipFree(t->d_perm);
+  for (float* p : t->d_h) hipFree(p);
+  hipFree(t->d_yb); hipFree(t->d_wb); hipFree(t->d_rowloss); hipFree(t->d_evalsum);
+  if (t->d_steploss) hipFree(t->d_steploss);
+  delete t;
+  return V21_OK;
+}
+extern "C" int v21_trainer_set_adam(v21_trainer* t, const v21_adam* cfg) {
+  if (!t || !cfg) return fail(V21_ERR_ARG, "null argument");
+  if (!(cfg->lr >= 0.f) || !(cfg->beta1 >= 0.f && cfg->beta1 < 1.f) || !(cfg->beta2 >= 0.f && cfg->beta2 < 1.f) || !(cfg->eps >= 0.f))
+    return fail(V21_ERR_ARG, "bad Adam hyper-parameters");
+  t->adam = *cfg;
+  return V21_OK;
+}
+extern "C" int v21_trainer_set_lr(v21_trainer* t, float lr) { if (!t) return fail(V21_ERR_ARG, "null"); t->adam.lr = lr; return V21_OK; }
+extern "C" int v21_trainer_get_lr(v21_trainer* t, float* lr) { if (!t || !lr) return fail(V21_ERR_ARG, "null"); *lr = t->adam.lr; return V21_OK; }
+
+extern "C" int v21_trainer_set_data(v21_trainer* t, int which, const float* x, const float* y, const float* rw, int64_t n) {
+  if (!t || !x || !rw) return fail(V21_ERR_ARG, "null argument");
+  if (which < 0 || which > 1) return fail(V21_ERR_ARG, "which must be 0 (train) or 1 (val)");
+  if (n < 1) return fail(V21_ERR_ARG, "need at least one row");
+  CHK(use(t->ctx));
+  v21_mlp* m = t->mlp;
+  const int din = m->dims[0], dout = m->dims[m->L];
+  if (!y && din != dout) return fail(V21_ERR_ARG, "y == NULL (y = x) needs in_dim == out_dim");
+  hipStream_t st = t->ctx->stream;
+  if (t->d_x[which]) { HIPCHK(hipFree(t->d_x[which])); t->d_x[which] = nullptr; }
+  if (t->d_y[which] && !t->y_is_x[which]) HIPCHK(hipFree(t->d_y[which]));
+  t->d_y[which] = nullptr;
+  if (t->d_rw[which]) { HIPCHK(hipFree(t->d_rw[which])); t->d_rw[which] = nullptr; }
+  HIPCHK(hipMalloc((void**)&t->d_x[which], (size_t)n * din * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(t->d_x[which], x, (size_t)n * din * sizeof(float), hipMemcpyHostToDevice, st));
+  if (y) {
+    HIPCHK(hipMalloc((void**)&t->d_y[which], (size_t)n * dout * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(t->d_y[which], y, (size_t)n * dout * sizeof(float), hipMemcpyHostToDevice, st));
+    t->y_is_x[which] = false;
+  } else {
+    t->d_y[which] = t->d_x[which];
+    t->y_is_x[which] = true;
+  }
+  HIPCHK(hipMalloc((void**)&t->d_rw[which], (size_t)n * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(t->d_rw[which], rw, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  t->n[which] = n;
+  return V21_OK;
+}
+
+static float adam_alpha(const v21_adam& a, long long t) {
+  // [K] alpha_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in float32
+  const float b1p = powf(a.beta1, (float)t), b2p = powf(a.beta2, (float)t);
+  return a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+}
+
+// forward through the stack on a device batch; h0 = input rows (ld = dims[0])
+static int trainer_forward(v21_trainer* t, const float* h0, int rows) {
+  v21_mlp* m = t->mlp;
+  const float* in = h0;
+  for (int l = 0; l < m->L; ++l) {
+    CHK(dense_forward(m, l, in, m->dims[l], t->d_h[l + 1], m->dims[l + 1], rows, t->prec, t->ctx->stream));
+    in = t->d_h[l + 1];
+  }
+  return V21_OK;
+}
+
+// one optimizer step on a device-resident batch of `rows` local rows out of a
+// global batch of `brows`; the batch loss numerator lands in loss_out[0] (device).
+static int trainer_step(v21_trainer* t, const float* h0, const float* yb, const float* wb, int rows, int brows,
+                        float* loss_out) {
+  v21_mlp* m = t->mlp;
+  hipStream_t st = t->ctx->stream;
+  const int L = m->L, dout = m->dims[L];
+  if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
+  if (rows > 0) {
+    CHK(trainer_forward(t, h0, rows));
+    const int wpb = 4;  // waves (rows) per block
+    hipLaunchKernelGGL(loss_grad_kernel<true>, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, st, t->d_h[L],
+                       (long long)dout, yb, (long long)dout, wb, t->d_dz[0], (long long)dout, t->d_rowloss, rows, dout,
+                       2.0f / (float)brows);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_g + t->P, 0);
+    HIPCHK(hipGetLastError());
+    int cur = 0;
+    for (int l = L - 1; l >= 0; --l) {
+      const float* hin = l == 0 ? h0 : t->d_h[l];
+      const int K = m->dims[l], N = m->dims[l + 1];
+      GemmArgs g{};  // [dW; db] = [H^T; 1^T] dZ
+      g.A = hin; g.sa_m = 1; g.sa_k = K;
+      g.B = t->d_dz[cur]; g.sb_k = N; g.sb_n = 1;
+      g.C = t->d_g + m->w_off[l]; g.ldc = N;
+      g.M = K + 1; g.N = N; g.K = rows;
+      g.ones_row = K; g.alpha = 1.f;
+      CHK(launch_gemm_prec<EP_PLAIN>(t->prec, g, st));
+      if (l > 0) {  // dH = dZ W^T, masked by the ReLU of the layer below
+        GemmArgs d{};
+        d.A = t->d_dz[cur]; d.sa_m = N; d.sa_k = 1;
+        d.B = m->d_w + m->w_off[l]; d.sb_k = 1; d.sb_n = N;
+        d.C = t->d_dz[cur ^ 1]; d.ldc = K;
+        d.M = rows; d.N = K; d.K = N;
+        d.ones_row = -1; d.alpha = 1.f;
+        if (m->act[l - 1] == V21_ACT_RELU) {
+          d.mask = t->d_h[l]; d.ldmask = K;
+          CHK(launch_gemm_prec<EP_MASK>(t->prec, d, st));
+        } else {
+          CHK(launch_gemm_prec<EP_PLAIN>(t->prec, d, st));
+        }
+        cur ^= 1;
+      }
+    }
+  } else {
+    HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
+  }
+  CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
+  t->iter += 1;
+  const float alpha = adam_alpha(t->adam, t->iter);
+  const long long n4 = ((long long)t->P + 3) / 4;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, m->d_w, t->d_g, t->d_m, t->d_v,
+                     (long long)t->P, alpha, 1.0f - t->adam.beta1, 1.0f - t->adam.beta2, t->adam.eps);
+  HIPCHK(hipGetLastError());
+  if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+  invalidate_streams(m);
+  return V21_OK;
+}
+
+static int gather_batch(v21_trainer* t, int which, const int* d_idx, long long first, int rows, bool want_y) {
+  v21_mlp* m = t->mlp;
+  hipStream_t st = t->ctx->stream;
+  const int din = m->dims[0], dout = m->dims[m->L];
+  const int wpb = 4;
+  dim3 grid((rows + wpb - 1) / wpb), block(64 * wpb);
+  hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, st, t->d_h[0], (const float*)t->d_x[which], d_idx, first, rows,
+                     din, (long long)din, (long long)din);
+  HIPCHK(hipGetLastError());
+  if (want_y && !t->y_is_x[which]) {
+    hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, st, t->d_yb, (const float*)t->d_y[which], d_idx, first, rows,
+                       dout, (long long)dout, (long long)dout);
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(gather_vec_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, t->d_wb, (const float*)t->d_rw[which],
+                     d_idx, first, rows);
+  HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+
+extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int batch, double* loss) {
+  if (!t || !loss) return fail(V21_ERR_ARG, "null argument");
+  if (t->n[0] < 1) return fail(V21_ERR_STATE, "no training data set");
+  CHK(use(t->ctx));
+  hipStream_t st = t->ctx->stream;
+  const long long n = t->n[0];
+  const int R = t->ctx->nranks, rk = t->ctx->rank;
+  if (batch < 1) return fail(V21_ERR_ARG, "batch must be >= 1");
+  if ((batch + R - 1) / R > t->max_batch) return fail(V21_ERR_ARG, "per-rank batch %d exceeds max_batch %d", (batch + R - 1) / R, t->max_batch);
+  const int* d_idx = nullptr;
+  if (perm) {
+    if (t->perm_cap < n) {
+      if (t->d_perm) HIPCHK(hipFree(t->d_perm));
+      HIPCHK(hipMalloc((void**)&t->d_perm, (size_t)n * sizeof(int)));
+      t->perm_cap = n;
+    }
+    HIPCHK(hipMemcpyAsync(t->d_perm, perm, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    d_idx = t->d_perm;
+  }
+  const long long steps = (n + batch - 1) / batch;
+  if (t->steploss_cap < steps) {
+    if (t->d_steploss) HIPCHK(hipFree(t->d_steploss));
+    HIPCHK(hipMalloc((void**)&t->d_steploss, (size_t)steps * sizeof(float)));
+    t->steploss_cap = steps;
+  }
+  for (long long s = 0; s < steps; ++s) {
+    const long long first = s * batch;
+    const int brows = (int)std::min<long long>(batch, n - first);  // rows of the global batch
+    const long long lo = first + (long long)brows * rk / R, hi = first + (long long)brows * (rk + 1) / R;
+    const int rows = (int)(hi - lo);
+    if (rows > 0) CHK(gather_batch(t, 0, d_idx, lo, rows, true));
+    const float* yb = t->y_is_x[0] ? t->d_h[0] : t->d_yb;
+    CHK(trainer_step(t, t->d_h[0], yb, t->d_wb, rows, brows, t->d_steploss + s));
+  }
+  std::vector<float> h(steps);
+  HIPCHK(hipMemcpyAsync(h.data(), t->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  double tot = 0.0;
+  for (float v : h) tot += (double)v;  // each entry = batch_loss * n_b  ([K] epoch loss)
+  *loss = tot / (double)n;
+  return V21_OK;
+}
+
+extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* loss) {
+  if (!t || !loss) return fail(V21_ERR_ARG, "null argument");
+  if (which < 0 || which > 1 || t->n[which] < 1) return fail(V21_ERR_STATE, "no data set for split %d", which);
+  CHK(use(t->ctx));
+  hipStream_t st = t->ctx->stream;
+  v21_mlp* m = t->mlp;
+  const long long n = t->n[which];
+  const int dout = m->dims[m->L];
+  if (batch < 1) return fail(V21_ERR_ARG, "batch must be >= 1");
+  const int b = std::min(batch, t->max_batch);
+  HIPCHK(hipMemsetAsync(t->d_evalsum, 0, 16, st));
+  for (long long first = 0; first < n; first += b) {
+    const int rows = (int)std::min<long long>(b, n - first);
+    CHK(gather_batch(t, which, nullptr, first, rows, true));
+    CHK(trainer_forward(t, t->d_h[0], rows));
+    const float* yb = t->y_is_x[which] ? t->d_h[0] : t->d_yb;
+    const int wpb = 4;
+    hipLaunchKernelGGL(loss_grad_kernel<false>, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, st, t->d_h[m->L],
+                       (long long)dout, yb, (long long)dout, t->d_wb, (float*)nullptr, 0ll, t->d_rowloss, rows, dout, 0.f);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_evalsum, 1);
+    HIPCHK(hipGetLastError());
+  }
+  float s = 0.f;
+  HIPCHK(hipMemcpyAsync(&s, t->d_evalsum, sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *loss = (double)s / (double)n;
+  return V21_OK;
+}
+
+extern "C" int v21_trainer_step_dev(v21_trainer* t, const float* d_x, const float* d_y, const float* d_rw, int n_rows,
+                                    int global_rows) {
+  if (!t || !d_x || !d_rw) return fail(V21_ERR_ARG, "null argument");
+  if (n_rows < 0 || global_rows < std::max(n_rows, 1)) return fail(V21_ERR_ARG, "bad row counts");
+  CHK(use(t->ctx));
+  return trainer_step(t, d_x, d_y ? d_y : d_x, d_rw, n_rows, global_rows, nullptr);
+}
+extern "C" int v21_trainer_last_step_loss(v21_trainer* t, double* loss) {
+  if (!t || !loss) return fail(V21_ERR_ARG, "null argument");
+  CHK(use(t->ctx));
+  float s = 0.f;
+  HIPCHK(hipMemcpyAsync(&s, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  *loss = (double)s;  // sum_i w_i sum_j (p-y)^2 over the global batch
+  return V21_OK;
+}
+extern "C" int v21_trainer_get_state(v21_trainer* t, int64_t* iter, float* mm, float* vv, size_t n) {
+  if (!t) return fail(V21_ERR_ARG, "null trainer");
+  CHK(use(t->ctx));
+  if (iter) *iter = t->iter;
+  if ((mm || vv) && n != t->P) return fail(V21_ERR_ARG, "state size %zu != %zu", n, t->P);
+  if (mm) HIPCHK(hipMemcpyAsync(mm, t->d_m, n * sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
+  if (vv) HIPCHK(hipMemcpyAsync(vv, t->d_v, n * sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  return V21_OK;
+}
+extern "C" int v21_trainer_set_state(v21_trainer* t, int64_t iter, const float* mm, const float* vv, size_t n) {
+  if (!t) return fail(V21_ERR_ARG, "null trainer");
+  CHK(use(t->ctx));
+  if (iter < 0) return fail(V21_ERR_ARG, "negative iteration count");
+  if ((mm || vv) && n != t->P) return fail(V21_ERR_ARG, "state size %zu != %zu", n, t->P);
+  t->iter = iter;
+  if (mm) HIPCHK(hipMemcpyAsync(t->d_m, mm, n * sizeof(float), hipMemcpyHostToDevice, t->ctx->stream));
+  if (vv) HIPCHK(hipMemcpyAsync(t->d_v, vv, n * sizeof(float), hipMemcpyHostToDevice, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  return V21_OK;
+}
+extern "C" int v21_trainer_get_grad(v21_trainer* t, float* g, size_t n) {
+  if (!t || !g) return fail(V21_ERR_ARG, "null argument");
+  if (n != t->P) return fail(V21_ERR_ARG, "grad size %zu != %zu", n, t->P);
+  CHK(use(t->ctx));
+  HIPCHK(hipMemcpyAsync(g, t->d_g, n * sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  return V21_OK;
+}
+extern "C" int v21_trainer_use_graph(v21_trainer* t, int enable) {
+  if (!t) return fail(V21_ERR_ARG, "null trainer");
+  (void)enable;  // hipGraph capture of the step: not in this build
+  return V21_OK;
+}

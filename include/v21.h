@@ -1,0 +1,168 @@
+/* v21.h -- C ABI of libv21.so: the MI355X (gfx950) engine behind the 21cmVAE
+ * predict()/train() hot path.
+ *
+ * The reference (christianhbye/21cmVAE) has no FFI of its own: its numeric engine is
+ * TensorFlow/Keras, reached through eight call sites in
+ * VeryAccurateEmulator/emulator.py (:369, :402, :739, :753-754, :756, :789, :790, :827).
+ * Every entry point below names the reference call site it replaces.  The Python
+ * shim (21cmvae_amd/engine.py) binds these with ctypes; INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, opaque handles, no exceptions cross the boundary;
+ *   - every function returns 0 on success or a negative V21_ERR_* code;
+ *     v21_last_error() returns a thread-local human-readable message;
+ *   - host buffers are caller-owned, C-contiguous, alive for the call only;
+ *     device memory is owned by the library (or, for *_dev entry points, by the
+ *     caller, who passes raw device pointers on the context's stream);
+ *   - weights travel in Keras get_weights() order: W0 (in,out) row-major, b0, W1, ...
+ *     (layout confirmed by the reference's shipped .h5 files);
+ *   - one context per device; calls on one context must be serialised by the caller.
+ */
+#ifndef V21_H
+#define V21_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct v21_ctx v21_ctx;
+typedef struct v21_mlp v21_mlp;
+typedef struct v21_trainer v21_trainer;
+
+enum {
+  V21_OK = 0,
+  V21_ERR_ARG = -1,         /* bad argument (null, shape, range)              */
+  V21_ERR_HIP = -2,         /* a HIP runtime call failed                      */
+  V21_ERR_UNSUPPORTED = -3, /* valid request this build cannot serve          */
+  V21_ERR_STATE = -4,       /* call order violated (e.g. no data set)         */
+  V21_ERR_COMM = -5         /* RCCL failure                                   */
+};
+
+/* arithmetic of the dense contractions (accumulation is always fp32) */
+enum { V21_PREC_F32 = 0, V21_PREC_F16 = 1, V21_PREC_BF16 = 2 };
+enum { V21_ACT_LINEAR = 0, V21_ACT_RELU = 1 };
+enum { V21_DTYPE_F32 = 0, V21_DTYPE_F64 = 1 };
+
+/* Fused prologue = preprocess.par_transform (preprocess.py:49-110) with the
+ * training-set statistics cached: y_j = ((log_mask_j ? log10(x_j) : x_j) - lo_j)
+ * * scale_j - 1, scale_j = 2/(hi_j-lo_j); x_j == 0 -> zero_floor_j first when
+ * zero_floor_j > 0 (the fx == 0 -> 1e-6 rule, preprocess.py:76).  n <= 8. */
+typedef struct {
+  int32_t n;
+  int32_t log_mask[8];
+  float zero_floor[8];
+  float lo[8];
+  float scale[8];
+} v21_affine_in;
+
+/* Fused epilogue = preprocess.unpreproc (preprocess.py:27-46): y*std + mean_j. */
+typedef struct {
+  float std;
+  const float* mean; /* host pointer, out_dim floats */
+  int32_t n;
+} v21_affine_out;
+
+const char* v21_last_error(void);
+int v21_version(void);
+int v21_device_count(int* n);
+
+/* ---- context: one per device; owns a HIP stream ------------------------------ */
+int v21_ctx_create(int device, v21_ctx** out);
+int v21_ctx_destroy(v21_ctx* ctx);
+int v21_ctx_sync(v21_ctx* ctx);
+/* adopt an external hipStream_t (e.g. torch's current stream); NULL restores own */
+int v21_ctx_set_stream(v21_ctx* ctx, void* hip_stream);
+int v21_ctx_get_stream(v21_ctx* ctx, void** hip_stream);
+
+/* device memory + copies + event timing, so a host program needs nothing else */
+int v21_malloc(v21_ctx* ctx, size_t bytes, void** dptr);
+int v21_free(v21_ctx* ctx, void* dptr);
+int v21_memcpy_h2d(v21_ctx* ctx, void* dst, const void* src, size_t bytes);
+int v21_memcpy_d2h(v21_ctx* ctx, void* dst, const void* src, size_t bytes);
+int v21_memset(v21_ctx* ctx, void* dst, int value, size_t bytes);
+int v21_event_create(v21_ctx* ctx, void** ev);
+int v21_event_destroy(v21_ctx* ctx, void* ev);
+int v21_event_record(v21_ctx* ctx, void* ev);               /* on the ctx stream */
+int v21_event_elapsed_ms(v21_ctx* ctx, void* start, void* stop, float* ms); /* syncs stop */
+
+/* ---- dense stack: replaces emulator._gen_model (emulator.py:12-48) + the Keras
+ * Model object it returns.  A chain of models (emulator -> decoder,
+ * emulator.py:789-790; encoder -> decoder, emulator.py:517) is ONE stack whose
+ * `act` array has a linear layer in the middle. ----------------------------------- */
+int v21_mlp_create(v21_ctx* ctx, int n_layers, const int* dims /* n_layers+1 */,
+                   const int* act /* n_layers */, v21_mlp** out);
+int v21_mlp_destroy(v21_mlp* mlp);
+int v21_mlp_num_params(const v21_mlp* mlp, size_t* n);
+/* Keras Model.set_weights / get_weights (flat fp32 arena, Keras order) */
+int v21_mlp_set_weights(v21_mlp* mlp, const float* flat, size_t n);
+int v21_mlp_get_weights(v21_mlp* mlp, float* flat, size_t n);
+/* NULL clears the transform.  Both are copied. */
+int v21_mlp_set_input_transform(v21_mlp* mlp, const v21_affine_in* t);
+int v21_mlp_set_output_transform(v21_mlp* mlp, const v21_affine_out* t);
+/* 1 if (dims, act) has a fully fused register-resident kernel, else 0 */
+int v21_mlp_has_fused(const v21_mlp* mlp, int precision, int* yes);
+
+/* Model.predict (emulator.py:402, :753-754, :789-790) and Model.__call__ (:517, :827):
+ * host (n, in_dim) f32/f64 -> host (n, out_dim) f32.  flags: bit0 = apply input
+ * transform, bit1 = apply output transform, bit2 = force the generic per-layer path. */
+int v21_mlp_forward(v21_mlp* mlp, const void* x, int x_dtype, int64_t n, float* y,
+                    int precision, int flags);
+/* Same, device-resident, asynchronous on the context stream.  ldx/ldy = row pitch
+ * in floats (>= in_dim / out_dim). */
+int v21_mlp_forward_dev(v21_mlp* mlp, const float* d_x, int64_t ldx, int64_t n,
+                        float* d_y, int64_t ldy, int precision, int flags);
+#define V21_FWD_IN_TRANSFORM 1
+#define V21_FWD_OUT_TRANSFORM 2
+#define V21_FWD_FORCE_GENERIC 4
+
+/* ---- trainer: replaces Model.compile + Model.fit (emulator.py:369-378, :739-747,
+ * :756-764; optimizer/loss from notebooks/Training.ipynb cells 4 and 10). ------- */
+typedef struct {
+  float lr, beta1, beta2, eps; /* Keras Adam: 1e-3, 0.9, 0.999, 1e-7 */
+} v21_adam;
+
+int v21_trainer_create(v21_mlp* mlp, int precision, int max_batch, v21_trainer** out);
+int v21_trainer_destroy(v21_trainer* tr);
+int v21_trainer_set_adam(v21_trainer* tr, const v21_adam* cfg);
+int v21_trainer_set_lr(v21_trainer* tr, float lr);
+int v21_trainer_get_lr(v21_trainer* tr, float* lr);
+/* Resident training / validation matrices.  y == NULL means y = x (autoencoder fit,
+ * emulator.py:739-741).  row_weight w_i defines the loss: loss_i = w_i sum_j (y-p)^2
+ * (relative_mse_loss, emulator.py:68-81 -> w_i = 1/(D amp_i^2); plain MSE -> 1/D). */
+int v21_trainer_set_data(v21_trainer* tr, int which /*0 train, 1 val*/, const float* x,
+                         const float* y, const float* row_weight, int64_t n);
+/* One Keras epoch: rows visited in `perm` order (n_train int32; NULL = in order),
+ * batches of `batch` with the partial last batch kept, epoch loss =
+ * sum(batch_loss * n_b) / N.  With a communicator attached each rank takes its
+ * slice of every global batch and gradients are all-reduced (sum) before Adam. */
+int v21_trainer_run_epoch(v21_trainer* tr, const int32_t* perm, int batch, double* loss);
+/* validation pass (which = 1) or loss over the training set (which = 0) */
+int v21_trainer_eval(v21_trainer* tr, int which, int batch, double* loss);
+/* single optimizer step on caller-provided device batch (bench / custom loops) */
+int v21_trainer_step_dev(v21_trainer* tr, const float* d_x, const float* d_y,
+                         const float* d_row_weight, int n_rows, int global_rows);
+int v21_trainer_last_step_loss(v21_trainer* tr, double* loss); /* syncs */
+/* optimizer state: iter + m + v (Keras optimizer_weights order = arena order) */
+int v21_trainer_get_state(v21_trainer* tr, int64_t* iter, float* m, float* v, size_t n);
+int v21_trainer_set_state(v21_trainer* tr, int64_t iter, const float* m, const float* v,
+                          size_t n);
+/* gradient of the last step (after all-reduce), for tests */
+int v21_trainer_get_grad(v21_trainer* tr, float* g, size_t n);
+int v21_trainer_use_graph(v21_trainer* tr, int enable);
+
+/* ---- data-parallel communicator (new: the reference is single-process).  RCCL is
+ * loaded at run time (librccl.so.1) so a single-GPU user needs no RCCL. --------- */
+#define V21_COMM_ID_BYTES 128
+int v21_comm_get_unique_id(v21_ctx* ctx, void* id /* V21_COMM_ID_BYTES */);
+int v21_comm_init(v21_ctx* ctx, int nranks, int rank, const void* id);
+int v21_comm_destroy(v21_ctx* ctx);
+int v21_comm_allreduce_f32(v21_ctx* ctx, float* d_buf, size_t n); /* sum, in place */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V21_H */

@@ -1,0 +1,176 @@
+"""GPU parity of the forward path (K1 fused kernel + generic per-layer path) against
+the CPU oracle, through the C ABI.
+
+Tolerances (pre-processed units unless stated):
+  f32  : atol 2e-5, rtol 1e-5 vs the fp64 oracle -- the "stated fp32 tolerance"
+         (fp32-vs-fp64 forward differences on the shipped weights are
+         max 2.7e-6; the reference's own batched-vs-single check uses atol 5e-5 mK).
+  f16  : added emulation error (reference metric, emulator.py:188-191) mean < 0.05 %,
+         inside the 0.11 % budget that keeps 0.34 % within 1.05x.
+  bf16 : reported, bounded loosely (mean < 0.4 %) -- does not meet the 1.05x bar.
+"""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import ref_numpy as ora
+
+pytestmark = pytest.mark.gpu
+
+F32_ATOL, F32_RTOL = 2e-5, 1e-5
+
+
+def _stack(ctx, Ws, bs, act=None):
+    native = pkg("_native")
+    dims = [Ws[0].shape[0]] + [W.shape[1] for W in Ws]
+    if act is None:
+        act = [1] * (len(Ws) - 1) + [0]
+    st = native.Stack(ctx, dims, act)
+    st.set_weights(ora.flatten_params(Ws, bs))
+    return st
+
+
+def _oracle_chain(Ws, bs, act, x):
+    h = np.asarray(x, np.float64)
+    for W, b, a in zip(Ws, bs, act):
+        h = h @ W.astype(np.float64) + b.astype(np.float64)
+        if a:
+            h = np.maximum(h, 0)
+    return h
+
+
+def _rel_err_percent(pred, true):
+    return np.sqrt(np.mean((pred - true) ** 2, axis=1)) / np.max(np.abs(true), axis=1) * 100
+
+
+S1 = [7, 352, 352, 352, 224, 451]
+S2 = [7, 288, 352, 288, 224, 451]
+
+
+@pytest.mark.parametrize("dims", [S1, S2])
+@pytest.mark.parametrize("n", [1, 31, 257, 1000])
+def test_fused_f32_matches_oracle(ctx, dims, n):
+    Ws, bs = ora.init_mlp(dims, seed=3)
+    rng = np.random.default_rng(n)
+    bs = [rng.normal(scale=0.05, size=b.shape).astype(np.float32) for b in bs]
+    x = rng.uniform(-1, 1, size=(n, 7)).astype(np.float32)
+    st = _stack(ctx, Ws, bs)
+    assert st.has_fused("f32")
+    y = st.forward(x, "f32")
+    ref = ora.mlp_forward(Ws, bs, x)
+    np.testing.assert_allclose(y, ref, atol=F32_ATOL, rtol=F32_RTOL)
+    # the generic per-layer path must agree too
+    yg = st.forward(x, "f32", flags=pkg("_native").FWD_FORCE_GENERIC)
+    np.testing.assert_allclose(yg, ref, atol=F32_ATOL, rtol=F32_RTOL)
+
+
+def test_fused_full_size_ragged_and_row_independent(ctx):
+    """BASELINE configs[1] size (+17 ragged rows): size-independent properties --
+    every row equals the same row evaluated alone / in a small batch, and a sample of
+    rows equals the oracle."""
+    n = 65536 + 17
+    Ws, bs = ora.init_mlp(S1, seed=3)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=(n, 7)).astype(np.float32)
+    st = _stack(ctx, Ws, bs)
+    for prec in ("f32", "f16", "bf16"):
+        y = st.forward(x, prec)
+        assert y.shape == (n, 451) and np.isfinite(y).all()
+        idx = np.r_[0:5, 255:258, 32767:32770, n - 20:n]
+        ysub = st.forward(x[idx], prec)
+        np.testing.assert_array_equal(y[idx], ysub)  # bit-identical: rows are independent
+    y32 = st.forward(x, "f32")
+    pick = rng.choice(n, size=300, replace=False)
+    np.testing.assert_allclose(y32[pick], ora.mlp_forward(Ws, bs, x[pick]), atol=F32_ATOL, rtol=F32_RTOL)
+
+
+def test_shipped_ae_chain_all_precisions(ctx, shipped):
+    """The reference's trained AE-emulator + decoder (emulator.py:789-790) as ONE
+    fused stack 7->352->352->352->224->9->32->352->451."""
+    We, be = shipped["ae_emulator"]
+    Wd, bd = shipped["decoder"]
+    Ws, bs = We + Wd, be + bd
+    act = [1, 1, 1, 1, 0, 1, 1, 0]
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=(2000, 7))
+    ref = _oracle_chain(Ws, bs, act, x)
+    st = _stack(ctx, Ws, bs, act)
+    assert st.has_fused("f16")
+    y32 = st.forward(x, "f32")  # float64 host input is accepted (Keras casts) [K]
+    np.testing.assert_allclose(y32, ref, atol=F32_ATOL, rtol=F32_RTOL)
+    yg = st.forward(x, "f32", flags=pkg("_native").FWD_FORCE_GENERIC)
+    np.testing.assert_allclose(yg, ref, atol=F32_ATOL, rtol=F32_RTOL)
+    e16 = _rel_err_percent(st.forward(x, "f16"), ref)
+    eb16 = _rel_err_percent(st.forward(x, "bf16"), ref)
+    print("added error %%: f16 mean %.4f max %.4f | bf16 mean %.4f max %.4f"
+          % (e16.mean(), e16.max(), eb16.mean(), eb16.max()))
+    assert e16.mean() < 0.05 and e16.max() < 0.25
+    assert eb16.mean() < 0.4
+    # implied ratio to the reference's 0.34 % if independent: must stay within 1.05x
+    assert np.sqrt(0.34 ** 2 + e16.mean() ** 2) / 0.34 < 1.05
+
+
+def test_encoder_and_decoder_generic_and_fused(ctx, shipped):
+    rng = np.random.default_rng(1)
+    We, be = shipped["encoder"]          # 451 -> 352 -> 9: no fused kernel -> generic path
+    Wd, bd = shipped["decoder"]          # 9 -> 32 -> 352 -> 451: fused S4
+    sig = rng.normal(size=(300, 451)).astype(np.float32)
+    enc = _stack(ctx, We, be)
+    assert not enc.has_fused("f32")
+    z = enc.forward(sig, "f32")
+    np.testing.assert_allclose(z, ora.mlp_forward(We, be, sig), atol=1e-4, rtol=1e-5)
+    dec = _stack(ctx, Wd, bd)
+    assert dec.has_fused("f32")
+    p = dec.forward(z, "f32")
+    np.testing.assert_allclose(p, ora.mlp_forward(Wd, bd, z), atol=F32_ATOL, rtol=F32_RTOL)
+
+
+def test_fused_transforms_equal_preprocess_functions(ctx):
+    """Prologue = preprocess.par_transform, epilogue = preprocess.unpreproc
+    (DirectEmulator.predict, emulator.py:401-403), incl. the fx == 0 -> 1e-6 branch."""
+    synth, pp, native = pkg("synth"), pkg("preprocess"), pkg("_native")
+    par_train = synth.make_params(2000, seed=1, corners=True)
+    sig_train = synth.make_signals(500, seed=2)
+    params = synth.make_params(600, seed=3)
+    assert (params[:, 2] == 0).any()
+    Ws, bs = ora.init_mlp(S1, seed=5)
+    st = _stack(ctx, Ws, bs)
+    ps, ss = pp.ParamStats.of(par_train), pp.SignalStats.of(sig_train)
+    st.set_input_transform(ps.log_mask, ps.zero_floor, ps.lo, ps.hi)
+    st.set_output_transform(ss.std, ss.mean)
+    flags = native.FWD_IN_TRANSFORM | native.FWD_OUT_TRANSFORM
+    ref = ora.direct_predict(Ws, bs, params, par_train, sig_train, dtype=np.float64)
+    scale = float(ss.std)
+    for f in (flags, flags | native.FWD_FORCE_GENERIC):
+        y = st.forward(params.astype(np.float32), "f32", flags=f)
+        # the device evaluates log10 in f32: allow its rounding through the stack (mK units)
+        np.testing.assert_allclose(y, ref, atol=2e-4 * scale, rtol=1e-5)
+    # host-side float64 transform + device stack + epilogue only: tight
+    y2 = st.forward(pp.par_transform(params, par_train), "f32", flags=native.FWD_OUT_TRANSFORM)
+    np.testing.assert_allclose(y2, ref, atol=F32_ATOL * scale, rtol=1e-5)
+
+
+def test_generic_path_odd_shapes(ctx):
+    for dims in ([7, 64, 128, 451], [3, 5], [9, 33, 65, 2], [451, 100, 451]):
+        Ws, bs = ora.init_mlp(dims, seed=11)
+        rng = np.random.default_rng(12)
+        bs = [rng.normal(scale=0.1, size=b.shape).astype(np.float32) for b in bs]
+        x = rng.normal(size=(77, dims[0])).astype(np.float32)
+        st = _stack(ctx, Ws, bs)
+        for prec, tol in (("f32", 3e-5), ("f16", 3e-2), ("bf16", 2e-1)):
+            y = st.forward(x, prec)
+            np.testing.assert_allclose(y, ora.mlp_forward(Ws, bs, x), atol=tol, rtol=tol)
+
+
+def test_argument_errors_are_reported(ctx):
+    native = pkg("_native")
+    with pytest.raises(native.EngineError):
+        native.Stack(ctx, [7, 0, 3], [1, 0])
+    st = native.Stack(ctx, [7, 8, 3], [1, 0])
+    with pytest.raises(native.EngineError):
+        st.set_weights(np.zeros(5, np.float32))
+    with pytest.raises(ValueError):
+        st.forward(np.zeros((4, 6), np.float32))
+    with pytest.raises(native.EngineError):  # transform requested but never set
+        st.forward(np.zeros((4, 7), np.float32), flags=native.FWD_OUT_TRANSFORM)
+    assert st.forward(np.zeros((0, 7), np.float32)).shape == (0, 3)

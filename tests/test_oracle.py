@@ -1,0 +1,181 @@
+"""CPU tests of the oracle: it must agree with everything the reference itself pins
+(golden vectors generated from the reference's preprocess.py, its shipped weights,
+the formula identities of its own tests, its optimizer step counters) before the
+GPU path is compared with it."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pkg
+from oracle import ref_numpy as ora
+
+
+@pytest.fixture(scope="module")
+def pg():
+    return np.load(os.path.join(GOLDEN, "preprocess_golden.npz"))
+
+
+def test_par_transform_matches_reference_golden(pg):
+    out = ora.par_transform(pg["par_in"], pg["par_train"])
+    assert out.dtype == np.float64  # preprocess.py:81
+    np.testing.assert_array_equal(out, pg["par_out"])
+    np.testing.assert_array_equal(ora.par_transform(pg["par_in"][5], pg["par_train"]), pg["par_out_1d"])
+    np.testing.assert_array_equal(
+        ora.par_transform([0.0003, 4.2, 0.0, 0.055, 1.0, 0.1, 10.0], pg["par_train"]), pg["par_out_list"])
+
+
+def test_par_transform_train_box_is_unit_box(pg):
+    # reference tests/test_preprocess.py:21-26
+    t = ora.par_transform(pg["par_train"], pg["par_train"])
+    np.testing.assert_allclose(t.max(axis=0), 1.0)
+    np.testing.assert_allclose(t.min(axis=0), -1.0)
+    np.testing.assert_array_equal(t, pg["par_train_out"])
+
+
+def test_preproc_unpreproc_match_reference_golden(pg):
+    pre = ora.preproc(pg["sig_in"], pg["sig_train"])
+    assert pre.dtype == np.float32  # dtype preserved, preprocess.py:21-23
+    np.testing.assert_array_equal(pre, pg["pre_out"])
+    np.testing.assert_array_equal(ora.unpreproc(pre, pg["sig_train"]), pg["unpre_out"])
+    np.testing.assert_array_equal(ora.preproc(pg["sig_in"].astype(np.float64), pg["sig_train"]), pg["pre_out_f64"])
+    # reference tests/test_preprocess.py:12-18
+    full = ora.preproc(pg["sig_train"], pg["sig_train"])
+    np.testing.assert_allclose(full.mean(axis=0), 0.0, atol=1e-3)
+    np.testing.assert_allclose(ora.unpreproc(full, pg["sig_train"]), pg["sig_train"], atol=5e-5)
+
+
+def test_product_preprocess_equals_reference_golden(pg):
+    pp = pkg("preprocess")
+    np.testing.assert_array_equal(pp.par_transform(pg["par_in"], pg["par_train"]), pg["par_out"])
+    np.testing.assert_array_equal(pp.par_transform(pg["par_in"][5], pg["par_train"]), pg["par_out_1d"])
+    np.testing.assert_array_equal(pp.preproc(pg["sig_in"], pg["sig_train"]), pg["pre_out"])
+    np.testing.assert_array_equal(pp.unpreproc(pg["pre_out"], pg["sig_train"]), pg["unpre_out"])
+    # cached statistics must notice an in-place edit of the training array
+    tr = pg["sig_train"].copy()
+    a = pp.preproc(pg["sig_in"], tr)
+    tr *= 2.0
+    b = pp.preproc(pg["sig_in"], tr)
+    assert not np.array_equal(a, b)
+    np.testing.assert_array_equal(b, ora.preproc(pg["sig_in"], tr))
+
+
+def test_shipped_weights_structure(shipped):
+    d = shipped["raw"]
+    Ws, bs = shipped["ae_emulator"]
+    assert [W.shape for W in Ws] == [(7, 352), (352, 352), (352, 352), (352, 224), (224, 9)]
+    assert sum(W.size + b.size for W, b in zip(Ws, bs)) == 332425  # notebooks/Training.ipynb cell 9
+    We, be = shipped["encoder"]
+    Wd, bd = shipped["decoder"]
+    assert sum(W.size + b.size for W, b in zip(We, be)) == 162281
+    assert sum(W.size + b.size for W, b in zip(Wd, bd)) == 171139
+    assert bool(d["autoencoder/equals_encoder_plus_decoder"])
+    # Keras kept the partial last batch: 96 steps per epoch
+    assert int(d["ae_emulator/adam_iter"]) == 183 * 96 and int(d["autoencoder/adam_iter"]) == 141 * 96
+    assert float(d["ae_emulator/adam_epsilon"]) == 1e-7
+
+
+def test_shipped_stack_self_consistency(shipped):
+    """KAT on the trained weights: encoder(decoder(z)) reproduces the latent z that the
+    latent emulator predicts (layout, activation placement and bias order all right)."""
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=(512, 7))
+    z = ora.mlp_forward(*shipped["ae_emulator"], x)
+    rec = ora.mlp_forward(*shipped["encoder"], ora.mlp_forward(*shipped["decoder"], z))
+    rel = np.sqrt(np.mean((rec - z) ** 2)) / np.sqrt(np.mean(z ** 2))
+    assert rel < 0.06, rel
+    # fp32 evaluation of the same stack stays within the stated fp32 tolerance
+    p64 = ora.mlp_forward(*shipped["decoder"], z)
+    p32 = ora.mlp_forward(*shipped["decoder"], z.astype(np.float32), dtype=np.float32)
+    np.testing.assert_allclose(p32, p64, atol=2e-5, rtol=1e-5)
+
+
+def test_relative_mse_identity():
+    """reference tests/test_emulator.py:24-33: loss == mse / max|signal/std|^2."""
+    synth = pkg("synth")
+    sig = synth.make_signals(64, seed=5)
+    y_true = ora.preproc(sig[:10], sig)
+    y_pred = ora.preproc(sig[-10:], sig)
+    w = ora.relative_mse_row_weight(y_true, sig)
+    loss = ora.per_sample_loss(y_pred, y_true, w)
+    mse = np.mean((y_true.astype(np.float64) - y_pred) ** 2, axis=1)
+    amp = np.max(np.abs(sig[:10] / np.std(sig)), axis=1)
+    np.testing.assert_allclose(loss, mse / amp ** 2, rtol=2e-5)
+
+
+def test_error_metric():
+    synth = pkg("synth")
+    sig = synth.make_signals(16, seed=6)
+    np.testing.assert_array_equal(ora.error(sig, sig), 0.0)  # tests/test_emulator.py:42-47
+    e = ora.error(sig[0], sig[0] + 1.0)
+    np.testing.assert_allclose(e, 100.0 / np.max(np.abs(sig[0])), rtol=1e-6)
+
+
+def test_backward_matches_finite_differences():
+    rng = np.random.default_rng(3)
+    dims = [7, 12, 9, 5]
+    Ws, bs = ora.init_mlp(dims, seed=4, dtype=np.float64)
+    bs = [rng.normal(size=b.shape) * 0.1 for b in bs]
+    x = rng.normal(size=(6, 7)); y = rng.normal(size=(6, 5)); w = rng.uniform(0.5, 2.0, size=6)
+    acts = ora.mlp_forward(Ws, bs, x, keep=True)
+    loss, g = ora.batch_loss_and_grad(acts[-1], y, w)
+    dWs, dbs, _ = ora.mlp_backward(Ws, acts, g)
+    flat = ora.flatten_params(Ws, bs)
+    gflat = ora.flatten_params(dWs, dbs)
+    eps = 1e-6
+    for i in rng.choice(flat.size, size=25, replace=False):
+        f2 = flat.copy(); f2[i] += eps
+        lp, _ = ora.batch_loss_and_grad(ora.mlp_forward(*ora.unflatten_params(f2, dims), x), y, w)
+        f2[i] -= 2 * eps
+        lm, _ = ora.batch_loss_and_grad(ora.mlp_forward(*ora.unflatten_params(f2, dims), x), y, w)
+        np.testing.assert_allclose(gflat[i], (lp - lm) / (2 * eps), rtol=1e-4, atol=1e-8)
+
+
+def test_backward_and_adam_match_torch():
+    """Independent second implementation: torch autograd for the gradient, and the Keras
+    epsilon placement restated by hand (torch.optim.Adam places epsilon differently)."""
+    torch = pytest.importorskip("torch")
+    dims = [7, 16, 8, 11]
+    Ws, bs = ora.init_mlp(dims, seed=9, dtype=np.float64)
+    rng = np.random.default_rng(10)
+    x = rng.normal(size=(32, 7)); y = rng.normal(size=(32, 11)); w = rng.uniform(0.1, 1.0, size=32)
+    tW = [torch.tensor(W, requires_grad=True) for W in Ws]
+    tb = [torch.tensor(b, requires_grad=True) for b in bs]
+    h = torch.tensor(x)
+    for l in range(3):
+        h = h @ tW[l] + tb[l]
+        if l < 2:
+            h = torch.relu(h)
+    loss_t = (torch.tensor(w) * ((h - torch.tensor(y)) ** 2).sum(dim=1)).mean()
+    loss_t.backward()
+    acts = ora.mlp_forward(Ws, bs, x, keep=True)
+    loss, g = ora.batch_loss_and_grad(acts[-1], y, w)
+    dWs, dbs, _ = ora.mlp_backward(Ws, acts, g)
+    np.testing.assert_allclose(loss, loss_t.item(), rtol=1e-12)
+    for l in range(3):
+        np.testing.assert_allclose(dWs[l], tW[l].grad.numpy(), rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(dbs[l], tb[l].grad.numpy(), rtol=1e-10, atol=1e-14)
+    # three Adam steps in float64 against the closed form
+    st = ora.AdamState(4, dtype=np.float64, lr=0.01)
+    wv = np.array([1.0, -2.0, 0.5, 3.0]); gv = np.array([0.1, -0.2, 0.3, 0.0])
+    m = np.zeros(4); v = np.zeros(4); ref = wv.copy()
+    for t in range(1, 4):
+        m = 0.9 * m + 0.1 * gv; v = 0.999 * v + 0.001 * gv * gv
+        ref -= 0.01 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-7)
+        wv = ora.adam_step(wv, gv, st)
+    np.testing.assert_allclose(wv, ref, rtol=1e-12)
+
+
+def test_fit_loop_keras_bookkeeping():
+    """partial last batch kept, sample-weighted epoch loss, one entry per epoch."""
+    dims = [7, 8, 5]
+    Ws, bs = ora.init_mlp(dims, seed=1, dtype=np.float64)
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(70, 7)); y = rng.normal(size=(70, 5)); w = ora.mse_row_weight(y)
+    st = ora.AdamState(ora.flatten_params(Ws, bs).size, dtype=np.float64, lr=1e-2)
+    Ws2, bs2, hist = ora.fit(Ws, bs, st, x, y, w, epochs=3, batch=32, seed=7, val=(x, y, w), dtype=np.float64)
+    assert st.t == 3 * 3 and len(hist["loss"]) == 3 and len(hist["val_loss"]) == 3
+    assert hist["loss"][-1] < hist["loss"][0]
+    p = ora.epoch_permutation(70, 7, 0)
+    assert sorted(p.tolist()) == list(range(70))
+    assert not np.array_equal(p, ora.epoch_permutation(70, 7, 1))
