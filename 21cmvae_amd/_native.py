@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libv21.so")
+LIB_PATH = os.environ.get("V21_LIB") or os.path.join(HERE, "libv21.so")
 
 PREC_F32, PREC_F16, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32,

@@ -35,12 +35,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kFragBytes = 1024;  // one MFMA operand fragment: 64 lanes x 16 B
 constexpr int kBlkFrags = 24;     // fragments per ring block
 constexpr int kRing = 4;          // LDS ring slots
 constexpr int kWaves = 4;         // one wave per SIMD
 constexpr int kFusedLds = kRing * kBlkFrags * kFragBytes;  // 96 KiB
+#ifdef V21_FUSED_STAMP
+constexpr int kFusedLdsAlloc = kFusedLds + 16384;  // + stamp area (diagnostic build)
+#else
+constexpr int kFusedLdsAlloc = kFusedLds;
+#endif
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>),
 // expanded in chunks of 256 so that fold expressions stay below clang's nesting limit
@@ -73,6 +83,7 @@ struct FusedArgs {
   float out_mean_scale;         // 1.0 / 0.0: output transform on / off
   int in_transform;
   v21_affine_in tin;
+  unsigned long long* dbg;      // diagnostic builds only (V21_FUSED_STAMP): cycle stamps
 };
 
 // ---- precision traits ------------------------------------------------------------
@@ -84,6 +95,12 @@ struct PrecF16 {
   using frag = f16x8;
   using elem = _Float16;
   static constexpr int FPI = 16, EPI = 8, CT = 2;
+  static constexpr int WPI = 4;  // 32-bit operand words per lane per item
+  // two f32 -> one packed word (round to nearest even)
+  static __device__ __forceinline__ unsigned pack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  }
   template <bool SWAP> static __device__ __forceinline__ f32x16 mfma(frag w, frag x, f32x16 c) {
     if constexpr (!SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0);
@@ -93,6 +110,11 @@ struct PrecBF16 {
   using frag = bf16x8;
   using elem = __bf16;
   static constexpr int FPI = 16, EPI = 8, CT = 2;
+  static constexpr int WPI = 4;
+  static __device__ __forceinline__ unsigned pack2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  }
   template <bool SWAP> static __device__ __forceinline__ f32x16 mfma(frag w, frag x, f32x16 c) {
     if constexpr (!SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, w, c, 0, 0, 0);
@@ -103,6 +125,7 @@ struct PrecF32 {
   using frag = f32x4;
   using elem = float;
   static constexpr int FPI = 8, EPI = 4, CT = 1;
+  static constexpr int WPI = 4;
   template <bool SWAP> static __device__ __forceinline__ f32x16 mfma(frag w, frag x, f32x16 c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -207,19 +230,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// One LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst+1 KiB).
+// One LDS-DMA: 64 lanes x 16 B, global [sbase + voff] -> LDS [dst, dst + 1 KiB).
 // Issued through inline asm ON PURPOSE: with the builtin form hipcc (ROCm 7.2) treats
 // the DMA as a pending LDS event and degrades every later LDS-read wait in the kernel
 // from a counted lgkmcnt(N) to lgkmcnt(0).  The statement has no VGPR destination, so
-// it is register-safe; completion is tracked by hand (wait_vmcnt_barrier).  M0 is
-// saved/restored inside the statement because the compiler owns it.
-__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
+// it is register-safe; completion is tracked by hand (wait_vmcnt_barrier).  M0 (the
+// LDS destination) is written in the same statement that reads it; nothing else in
+// this kernel uses M0 (checked in the .s: no m0 outside ASMSTART/ASMEND).
+__device__ __forceinline__ void glds16(const unsigned char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
@@ -232,12 +254,32 @@ __device__ __forceinline__ void issue_block(const unsigned char* gstream, unsign
                                             int wave, int lane) {
   if constexpr (B >= 0 && B < G::n_blocks()) {
     constexpr int NG = G::blk_glds(B);
-    const unsigned char* g = gstream + (size_t)B * kBlkFrags * kFragBytes + wave * kFragBytes + lane * 16;
+    const unsigned char* g = gstream + (size_t)B * kBlkFrags * kFragBytes;  // wave-uniform
+    const unsigned voff = wave * kFragBytes + lane * 16;
     const unsigned s = lds_addr(smem) + (B % kRing) * kBlkFrags * kFragBytes + wave * kFragBytes;
     static_for<NG>([&](auto i) __attribute__((always_inline)) {
       constexpr int I = decltype(i)::value;
-      glds16(g + I * kWaves * kFragBytes, s + I * kWaves * kFragBytes);
+      glds16(g + I * kWaves * kFragBytes, voff, s + I * kWaves * kFragBytes);
     });
+  }
+}
+
+// One piece (fragment I*4 + wave) of block B, issued by the wave whose turn it is.
+// Spreading a block's DMA over the k-steps of the block being consumed -- one wave per
+// step -- keeps each 1-KiB DMA's issue (tens of cycles, during which the in-order wave
+// cannot issue MFMAs) inside the shadow of the MFMAs already in flight; issuing all of
+// them right after the rendezvous stalled all four SIMDs at once.
+template <class G, int B, int I>
+__device__ __forceinline__ void issue_piece(const unsigned char* gstream, unsigned char* smem,
+                                            int wave, int lane) {
+  if constexpr (B >= 0 && B < G::n_blocks()) {
+    if constexpr (I < G::blk_glds(B)) {
+      const unsigned char* g = gstream + (size_t)B * kBlkFrags * kFragBytes + I * kWaves * kFragBytes;
+      const unsigned voff = wave * kFragBytes + lane * 16;
+      const unsigned s = lds_addr(smem) + (B % kRing) * kBlkFrags * kFragBytes + wave * kFragBytes +
+                         I * kWaves * kFragBytes;
+      glds16(g, voff, s);
+    }
   }
 }
 
@@ -245,9 +287,9 @@ __device__ __forceinline__ void issue_block(const unsigned char* gstream, unsign
 // share of block B has landed, rendezvous (now every wave's share has), then refill
 // the slot of block B-2, which every wave has finished consuming (D <= kBlkFrags).
 // The prologue issued blocks 0..kRing-1; boundary B' >= 2 issues block B'+kRing-2.
-template <class G, int CT, int D, int S>
+template <class G, int CT, int D, int S, bool SPREAD>
 __device__ __forceinline__ void ring_boundary(const unsigned char* gstream, unsigned char* smem,
-                                              int wave, int lane) {
+                                              int wave, int lane, unsigned long long* g_dbg = nullptr) {
   if constexpr (S % kBlkFrags == 0 && S < G::padded()) {
     constexpr int B = S / kBlkFrags;
     constexpr int last_issued = (B + kRing - 3 > kRing - 1) ? B + kRing - 3 : kRing - 1;
@@ -256,12 +298,22 @@ __device__ __forceinline__ void ring_boundary(const unsigned char* gstream, unsi
       for (int i = B + 1; i <= last_issued; ++i) s += G::blk_glds(i);
       return s;
     }();
-    // stores younger than block B's DMA: issued in steps [S_issue, S)
-    constexpr int S_issue = (B < kRing) ? 0 : (B - kRing + 2) * kBlkFrags;
+    // stores younger than block B's DMA.  With SPREAD the pieces of block B were issued
+    // during the consumption of block B-kRing+2; counting only stores issued after that
+    // whole block (a lower bound of the true number) keeps the wait on the safe side.
+    constexpr int S_issue = (B < kRing) ? 0 : (B - kRing + 2 + (SPREAD ? 1 : 0)) * kBlkFrags;
     constexpr int SA = G::stores_before_step(S, CT, D) - G::stores_before_step(S_issue, CT, D);
     constexpr int N = (GA + SA) > 63 ? 63 : (GA + SA);
+#ifdef V21_FUSED_STAMP
+    { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      ((unsigned long long*)(smem + kFusedLds))[wave * 512 + 2 * B] = t; }
+#endif
     wait_vmcnt_barrier<N>();
-    if constexpr (B >= 2) issue_block<G, B + kRing - 2>(gstream, smem, wave, lane);
+#ifdef V21_FUSED_STAMP
+    { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      ((unsigned long long*)(smem + kFusedLds))[wave * 512 + 2 * B + 1] = t; }
+#endif
+    if constexpr (B >= 2 && !SPREAD) issue_block<G, B + kRing - 2>(gstream, smem, wave, lane);
   }
 }
 
@@ -269,6 +321,12 @@ template <int F> __device__ __forceinline__ const unsigned char* frag_ptr(const 
   constexpr int B = F / kBlkFrags;
   return smem + ((B % kRing) * kBlkFrags + (F % kBlkFrags)) * kFragBytes + lane * 16;
 }
+
+// Hook for pinning operand words to a register class.  Pinning them to AGPRs through
+// an inline-asm v_accvgpr_write was tried and REJECTED: hipcc cannot see the
+// VALU-write -> MFMA-operand-read wait states inside the asm (wrong results on the
+// single-tile layers of the S3 stack) and the VALU instructions it saved bought < 3 %.
+__device__ __forceinline__ unsigned to_areg(unsigned v) { return v; }
 
 // ---- the kernel -------------------------------------------------------------------
 // grid.x = ceil(n_rows / (kWaves*CT*32)); block = 256 threads; dynamic LDS kFusedLds.
@@ -281,7 +339,14 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
   using Item = typename G::Item;
   constexpr int L = G::L, CT = P::CT, EPI = P::EPI, FPI = P::FPI, IPT = G::IPT;
   constexpr int KSM = G::ks_max();
-  constexpr int D = 2;  // LDS read-ahead, in fragments
+#ifndef V21_FUSED_D
+#define V21_FUSED_D 2
+#endif
+#ifndef V21_FUSED_SPREAD
+#define V21_FUSED_SPREAD 0
+#endif
+  constexpr int D = V21_FUSED_D;  // LDS read-ahead, in fragments
+  constexpr bool SPREAD = V21_FUSED_SPREAD != 0;
   constexpr int TOTAL = G::total();
   constexpr int NOUT = G::dim(L);
   constexpr int NCH = CT * 8;  // epilogue chunks per tile
@@ -294,7 +359,8 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
   const long long wg_row0 = (long long)blockIdx.x * (kWaves * CT * 32);
   const long long row0 = wg_row0 + wave * (CT * 32);
 
-  frag bufA[CT][KSM], bufB[CT][KSM];
+  // Operand registers of the two layers in flight, as 32-bit words (4 per item).
+  unsigned bufA[CT][KSM][4], bufB[CT][KSM][4];
 
   // ---- layer-0 operand: x rows -> operand registers; optional fused par_transform
   {
@@ -306,7 +372,7 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
       const float* xr = a.x + (ok ? row : 0) * a.ldx;
       static_for<G::ks_of(0)>([&](auto ks_) __attribute__((always_inline)) {
         constexpr int ks = decltype(ks_)::value;
-        frag v;
+        float v[EPI];
         static_for<EPI>([&](auto e_) __attribute__((always_inline)) {
           constexpr int e = decltype(e_)::value;
           constexpr int f0 = FPI * ks + 8 * (e >> 2) + (e & 3);  // lanes h = 0
@@ -329,9 +395,13 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
               }
             }
           }
-          v[e] = (elem)t;
+          v[e] = t;
         });
-        bufA[ct][ks] = v;
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+          if constexpr (EPI == 8) bufA[ct][ks][wd] = to_areg(P::pack2(v[2 * wd], v[2 * wd + 1]));
+          else bufA[ct][ks][wd] = to_areg(__builtin_bit_cast(unsigned, v[wd]));
+        }
       });
     });
   }
@@ -351,13 +421,15 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
   __amdgpu_buffer_rsrc_t orsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + wg_row0 * a.ldy), 0, out_bytes, 0x00020000);
   const unsigned ldy_b = (unsigned)a.ldy * 4u;
+  // per-lane part of the store offset: row 4h of this wave's rows, column r
+  const unsigned ovoff = (unsigned)(wave * (CT * 32) + 4 * h) * ldy_b + (unsigned)r * 4u;
 
   frag q[D + 1];      // fragments in flight LDS -> registers
   f32x16 auxb[2];     // aux fragment of the tile being started (by tile parity)
   f32x16 acc[2][CT];  // accumulators, double-buffered by tile parity
 
   // chunk c = (ct, register pair) of the epilogue of global tile GT (compile-time):
-  // hidden layer -> ReLU (+ pack) two values into the next layer's operand registers;
+  // hidden layer -> pack (+ ReLU) two values into the next layer's operand registers;
   // output layer -> Dense bias + preprocess.unpreproc + two row-segment stores.
   auto epilogue_chunk = [&](auto g_, auto c_) __attribute__((always_inline)) {
     constexpr int GT = decltype(g_)::value;
@@ -369,28 +441,39 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
       constexpr int item = IPT * nt + (2 * pr) / EPI, e0 = (2 * pr) % EPI;
       if constexpr (item < G::ks_of(l + 1)) {
         auto& out = (l & 1) ? bufA : bufB;
-        float x0 = acc[GT & 1][ct][2 * pr], x1 = acc[GT & 1][ct][2 * pr + 1];
-        if constexpr (G::act(l) != 0) {
-          // ReLU as a signed-integer max on the bit pattern: one VALU op, no
-          // canonicalising pre-pass (negative floats are negative integers)
-          x0 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x0), 0));
-          x1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x1), 0));
+        const float x0 = acc[GT & 1][ct][2 * pr], x1 = acc[GT & 1][ct][2 * pr + 1];
+        if constexpr (EPI == 8) {
+          // pack first, then ReLU on the packed pair as a signed 16-bit max with 0
+          // (negative f16/bf16 are negative integers): 2 VALU ops per 2 values
+          unsigned w = P::pack2(x0, x1);
+          if constexpr (G::act(l) != 0) {
+            const i16x2 z = {0, 0};
+            w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), z));
+          }
+          out[ct][item][e0 / 2] = to_areg(w);
+        } else {
+          int b0 = __builtin_bit_cast(int, x0), b1 = __builtin_bit_cast(int, x1);
+          if constexpr (G::act(l) != 0) { b0 = max(b0, 0); b1 = max(b1, 0); }
+          out[ct][item][e0] = to_areg((unsigned)b0);
+          out[ct][item][e0 + 1] = to_areg((unsigned)b1);
         }
-        out[ct][item][e0] = (elem)x0;
-        out[ct][item][e0 + 1] = (elem)x1;
       }
     } else {
       const float obias = auxb[GT & 1][0], omean = auxb[GT & 1][1] * a.out_mean_scale;
-      const int col = 32 * nt + r;
+      unsigned voff = ovoff + (unsigned)(32 * nt) * 4u;
+      if (32 * nt + r >= NOUT) voff = 0xFFFFFFF0u;  // column past out_dim -> dropped
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int i = 2 * pr + u;
-        const unsigned row_in_wg = wave * (CT * 32) + ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        // (acc + bias) * std + mean, each rounded to f32 as numpy does (unpreproc)
-        const float y = (acc[GT & 1][ct][i] + obias) * a.out_std + omean;
-        unsigned off = row_in_wg * ldy_b + (unsigned)col * 4u;
-        if (col >= NOUT) off = 0xFFFFFFF0u;  // out of range -> dropped by the range check
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), orsrc, off, 0, 0);
+        const unsigned soff = (unsigned)(ct * 32 + (i & 3) + 8 * (i >> 2)) * ldy_b;  // wave-uniform
+        float y;
+        if constexpr (EPI == 8) {
+          y = __builtin_fmaf(acc[GT & 1][ct][i], a.out_std, __builtin_fmaf(obias, a.out_std, omean));
+        } else {
+          // exact mode: (acc + bias) * std + mean, each rounded to f32 as numpy does
+          y = (acc[GT & 1][ct][i] + obias) * a.out_std + omean;
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), orsrc, voff, soff, 0);
       }
     }
   };
@@ -400,12 +483,21 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
       epilogue_chunk(g_, std::integral_constant<int, LO + decltype(k)::value>{});
     });
   };
+  auto operand = [&](auto& buf, int ct, int ks) __attribute__((always_inline)) {
+    const u32x4 wds = {buf[ct][ks][0], buf[ct][ks][1], buf[ct][ks][2], buf[ct][ks][3]};
+    return __builtin_bit_cast(frag, wds);
+  };
 
   static_for<TOTAL + D>([&](auto s_) __attribute__((always_inline)) {
     constexpr int S = decltype(s_)::value;
     // ---- load side: item S
     if constexpr (S < TOTAL) {
-      ring_boundary<G, CT, D, S>(a.stream, smem, wave, lane);
+      ring_boundary<G, CT, D, S, SPREAD>(a.stream, smem, wave, lane, a.dbg);
+      if constexpr (SPREAD && S / kBlkFrags >= 2) {
+        // refill of slot (B-2): piece o/4 of block B+kRing-2, by wave o%4, at offset o
+        constexpr int Bc = S / kBlkFrags, o = S % kBlkFrags;
+        if (wave == (o & 3)) issue_piece<G, Bc + kRing - 2, o / 4>(a.stream, smem, wave, lane);
+      }
       constexpr Item it = G::item_at(S);
       if constexpr (it.ks >= 0) {
         q[S % (D + 1)] = *(const frag*)frag_ptr<S>(smem, lane);
@@ -436,9 +528,15 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
         constexpr int GP = GT > 0 ? GT - 1 : 0;  // previous tile: its epilogue is pending
         constexpr int CPK = G::chunks_per_kstep(GP, NCH);
         constexpr bool whole_first = (GT > 0) && (G::spread_limit(GP) == 0);
-        if constexpr (whole_first && it.ks == 0)
+        if constexpr (whole_first && it.ks == 0) {
           epilogue_range(std::integral_constant<int, GP>{}, std::integral_constant<int, 0>{},
                          std::integral_constant<int, NCH>{});
+        }
+#ifdef V21_FUSED_STAMP
+        if constexpr (it.ks == 0) {
+          unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+          ((unsigned long long*)(smem + kFusedLds))[wave * 512 + 128 + GT] = t; }
+#endif
         auto& in = (it.l & 1) ? bufB : bufA;
         const frag w = q[C % (D + 1)];
 #pragma unroll
@@ -452,7 +550,7 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
           } else {
             c0 = acc[GT & 1][ct];
           }
-          acc[GT & 1][ct] = P::template mfma<(it.l == L - 1)>(w, in[ct][it.ks], c0);
+          acc[GT & 1][ct] = P::template mfma<(it.l == L - 1)>(w, operand(in, ct, it.ks), c0);
         }
         if constexpr (GT > 0 && !whole_first) {
           constexpr int lo = it.ks * CPK < NCH ? it.ks * CPK : NCH;
@@ -466,6 +564,17 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
   });
   epilogue_range(std::integral_constant<int, G::n_tiles() - 1>{}, std::integral_constant<int, 0>{},
                  std::integral_constant<int, NCH>{});
+#ifdef V21_FUSED_STAMP
+  if (a.dbg) {  // stamps were kept in LDS so that they add no VMEM operation to the counted waits
+    unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    unsigned long long* sd = (unsigned long long*)(smem + kFusedLds) + wave * 512;
+    sd[127] = t;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    unsigned long long* gd = a.dbg + ((size_t)blockIdx.x * kWaves + wave) * 512;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gd[64 * k + lane] = sd[64 * k + lane];
+  }
+#endif
 }
 
 }  // namespace v21

@@ -457,6 +457,7 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
   a.out_mean_scale = tout ? 1.0f : 0.0f;
   a.in_transform = (flags & V21_FWD_IN_TRANSFORM) ? 1 : 0;
   if (a.in_transform) a.tin = m->tin;
+  a.dbg = (unsigned long long*)(getenv("V21_FUSED_DBG_PTR") ? strtoull(getenv("V21_FUSED_DBG_PTR"), nullptr, 0) : 0ull);
   static const int pin = getenv("V21_FUSED_PIN") ? atoi(getenv("V21_FUSED_PIN")) : 0;
   HIPCHK(g_fused[m->fused_id].fn[precision](a, pin, m->ctx->stream));
   return V21_OK;

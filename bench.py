@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the 21cmVAE hot path on MI355X.
+
+Metric (BASELINE.json): emulated signals/sec of batched predict, 1/2/4/8 GPU
+(+ train steps/sec as an auxiliary object).  Workload (configs[1]): the direct emulator
+7 -> [352,352,352,224] -> 451, one batch of 65,536 seven-parameter vectors per GPU,
+inputs resident in HBM, full DirectEmulator.predict arithmetic on the device
+(par_transform prologue, five dense layers, unpreproc epilogue), output 65,536 x 451
+float32 written to HBM.  One "step" = one such pass.  Weak scaling: every rank runs its
+own batch (rows are independent; no data-path collective).
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DIMS = [7, 352, 352, 352, 224, 451]
+ACT = [1, 1, 1, 1, 0]
+BATCH = 65536
+FLOP_PER_SIGNAL = 2 * sum(a * b for a, b in zip(DIMS[:-1], DIMS[1:]))  # 860,288
+BYTES_PER_SIGNAL = 4 * (DIMS[0] + DIMS[-1])                            # 1,832
+PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}            # dense MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def glorot(dims, seed):
+    rng = np.random.default_rng(seed)
+    flat = []
+    for k, n in zip(dims[:-1], dims[1:]):
+        lim = np.sqrt(6.0 / (k + n))
+        flat.append(rng.uniform(-lim, lim, size=(k, n)).astype(np.float32).ravel())
+        flat.append(rng.normal(scale=0.05, size=n).astype(np.float32))
+    return np.concatenate(flat)
+
+
+def cpu_baseline(weights_flat, x_f32, budget_s=12.0):
+    """The CPU oracle (numpy fp32 restatement, oracle/ref_numpy.py) on a bounded sample of
+    the same workload: 8,192 of the 65,536 rows per pass, repeated for ~budget_s."""
+    from oracle import ref_numpy as ora
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    Ws, bs = ora.unflatten_params(weights_flat, DIMS)
+    rows = 8192
+    xs = x_f32[:rows]
+    ora.mlp_forward(Ws, bs, xs, dtype=np.float32)  # warm-up
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        ora.mlp_forward(Ws, bs, xs, dtype=np.float32)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": rows * n / dt, "unit": "signals/s", "cores": int(threads), "kind": "port",
+            "sample": "%d passes over the first %d rows of the batch, numpy fp32 (BLAS sgemm), %.1f s" % (n, rows, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with torch.distributed.run" % args.gpus)
+        args.gpus = world
+
+    torch = None
+    dist = None
+    try:
+        import torch  # plumbing only: barrier / max-over-ranks / synchronize of the contract
+    except Exception:
+        torch = None
+    if world > 1:
+        if torch is None:
+            raise SystemExit("multi-GPU bench needs torch.distributed")
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    native = importlib.import_module("21cmvae_amd._native")
+    synth = importlib.import_module("21cmvae_amd.synth")
+    pp = importlib.import_module("21cmvae_amd.preprocess")
+
+    ctx = native.Context(local_rank)
+    stack = native.Stack(ctx, DIMS, ACT)
+    wflat = glorot(DIMS, seed=3)
+    stack.set_weights(wflat)
+    par_train = synth.make_params(synth.N_TRAIN, seed=1, corners=True)
+    sig_train = synth.make_signals(4096, seed=301)
+    ps, ss = pp.ParamStats.of(par_train), pp.SignalStats.of(sig_train)
+    stack.set_input_transform(ps.log_mask, ps.zero_floor, ps.lo, ps.hi)
+    stack.set_output_transform(ss.std, ss.mean)
+    flags = native.FWD_IN_TRANSFORM | native.FWD_OUT_TRANSFORM
+
+    B = args.batch
+    params = synth.make_params(B, seed=1000 + rank, dtype=np.float32)
+    d_x = ctx.malloc(params.nbytes)
+    d_y = ctx.malloc(B * DIMS[-1] * 4)
+    ctx.h2d(d_x, params)
+
+    def sync_all():
+        ctx.sync()
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def timed(prec, steps, warmup):
+        for _ in range(warmup):
+            stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
+        sync_all(); barrier(); sync_all()
+        e0, e1 = ctx.event(), ctx.event()
+        t0 = time.perf_counter()
+        ctx.record(e0)
+        for _ in range(steps):
+            stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
+        ctx.record(e1)
+        sync_all(); barrier(); sync_all()
+        wall = time.perf_counter() - t0
+        ev_ms = ctx.elapsed_ms(e0, e1)
+        if dist is not None:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, ev_ms
+
+    wall, ev_ms = timed(args.precision, args.steps, args.warmup)
+    value = world * B * args.steps / wall
+    kern_s = ev_ms * 1e-3 / args.steps  # average launch duration on the launch stream (HIP events)
+    achieved_tf = FLOP_PER_SIGNAL * B / kern_s / 1e12
+    out = {
+        "metric": "emulated signals/sec (batched predict)",
+        "value": value,
+        "unit": "signals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": {"f16": "f16 (f32 accumulate)", "bf16": "bf16 (f32 accumulate)", "f32": "f32"}[args.precision],
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: direct emulator 7->[352,352,352,224]->451 batched predict, "
+                               "batch=%d per GPU, device-resident in/out, fused par_transform+unpreproc" % B,
+                   "batch_per_gpu": B, "weights": "Glorot-uniform seed 3", "parallelism": "rows sharded, no collective"},
+        "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_TFLOPS[args.precision],
+                     "unit": "TFLOP/s", "frac": achieved_tf / PEAK_TFLOPS[args.precision], "traffic": None,
+                     "kernel": "fused_fwd<ArchS1>", "kernel_ms": kern_s * 1e3,
+                     "hbm_GBps_algorithmic": BYTES_PER_SIGNAL * B / kern_s / 1e9,
+                     "hbm_frac_of_8TBps": BYTES_PER_SIGNAL * B / kern_s / 1e9 / PEAK_HBM_GBS},
+    }
+
+    if rank == 0 and not args.no_extras:
+        modes = {}
+        for prec in ("f32", "bf16", "f16"):
+            if prec == args.precision:
+                continue
+            try:
+                # local (rank-0 only) side measurement: no barriers involved
+                for _ in range(2):
+                    stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
+                ctx.sync()
+                a, b = ctx.event(), ctx.event()
+                n = max(5, args.steps // 5)
+                ctx.record(a)
+                for _ in range(n):
+                    stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
+                ctx.record(b)
+                ctx.sync()
+                ms = ctx.elapsed_ms(a, b) / n
+                modes[prec] = {"signals_per_s": B / (ms * 1e-3), "kernel_ms": ms,
+                               "frac_of_peak": FLOP_PER_SIGNAL * B / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[prec]}
+            except Exception as e:  # pragma: no cover
+                modes[prec] = {"error": str(e)}
+        out["other_precisions_1gpu"] = modes
+        # host numpy -> numpy predict (PCIe-inclusive); never the headline value
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            stack.forward(params, args.precision, flags)
+        out["host_roundtrip_signals_per_s"] = B * reps / (time.perf_counter() - t0)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        xt = pp.par_transform(params.astype(np.float64), par_train).astype(np.float32)
+        out["cpu_baseline"] = cpu_baseline(wflat, xt)
+
+    barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.free(d_x)
+    ctx.free(d_y)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
