@@ -1,0 +1,302 @@
+"""User-facing emulator classes: the reference's ``VeryAccurateEmulator.emulator`` surface
+(``DirectEmulator`` emulator.py:207-442, ``AutoEncoder`` :445-518, ``AutoEncoderEmulator``
+:528-842, ``_gen_model`` :12-48, ``relative_mse_loss`` :51-83, ``error`` :129-192 and the
+redshift/frequency helpers) on top of the MI355X engine instead of TensorFlow.
+
+Same names, arguments, return values and error behaviour; the differences a user can
+observe are listed in INTEGRATION.md (no dataset download, ``precision=`` option,
+training-set statistics cached, AE predict evaluated as one fused device stack).
+"""
+import os
+
+import numpy as np
+
+from . import preprocess as pp
+from .callbacks import TqdmCallback
+from .engine import ChainedModel, Dense, Input, Model, Sequential, sequential_from_arrays
+from .losses import mean_squared_error, relative_mse_loss  # noqa: F401  (public, as in the reference)
+
+PATH = os.path.dirname(os.path.abspath(__file__)) + "/"
+_native = None
+
+
+def _gen_model(in_dim, hidden_dims, out_dim, activation_func, name=None):
+    """Generate a new model: Dense(h, activation) per hidden dim, then a linear
+    Dense(out_dim).  ``in_dim`` None defers weight creation until ``build``/first call
+    (a decoder that follows another model)."""
+    layers = []
+    if in_dim is not None:
+        layers.append(Input(shape=(in_dim,)))
+    for dim in hidden_dims or []:
+        layers.append(Dense(dim, activation=activation_func))
+    layers.append(Dense(out_dim))
+    return Sequential(layers, name=name)
+
+
+NU_0 = 1420405751.7667  # Hz, rest frequency of the 21-cm line
+
+
+def redshift2freq(z):
+    """Redshift -> frequency in MHz."""
+    nu = NU_0 / (1 + z)
+    nu /= 1e6
+    return nu
+
+
+def freq2redshift(nu):
+    """Frequency in MHz -> redshift.  (Unlike the reference, emulator.py:124, the
+    argument is not modified in place.)"""
+    return NU_0 / (np.asarray(nu, dtype=float) * 1e6) - 1 if np.ndim(nu) else NU_0 / (nu * 1e6) - 1
+
+
+def error(true_signal, pred_signal, relative=True, nu_arr=None, flow=None, fhigh=None):
+    """Eq. 1 of Bye et al. (2022): rms over bins, optionally as % of the signal amplitude
+    and restricted to a frequency band (emulator.py:129-192)."""
+    if (flow or fhigh) and nu_arr is None:
+        raise ValueError("No frequency array is given, cannot compute error in specified frequency band.")
+    pred_signal, true_signal = np.asarray(pred_signal), np.asarray(true_signal)
+    if pred_signal.ndim == 1:
+        pred_signal = pred_signal[None, :]
+        true_signal = true_signal[None, :]
+    if flow or fhigh:
+        sel = np.ones(len(nu_arr), bool)
+        if flow:
+            sel &= nu_arr >= flow
+        if fhigh:
+            sel &= nu_arr <= fhigh
+        f = np.flatnonzero(sel)
+        pred_signal, true_signal = pred_signal[:, f], true_signal[:, f]
+    err = np.sqrt(np.mean((pred_signal - true_signal) ** 2, axis=1))
+    if relative:
+        err = err / np.max(np.abs(true_signal), axis=1) * 100
+    return err
+
+
+# ---- default data (emulator.py:196-204) ---------------------------------------------
+hidden_dims = [288, 352, 288, 224]
+redshifts = np.linspace(5, 50, 451)
+_DATASET_KEYS = ("par_train", "par_val", "par_test", "signal_train", "signal_val", "signal_test")
+_dataset = None
+
+
+def load_dataset(path=None):
+    """The six arrays of ``dataset_21cmVAE.h5``.  The reference reads that file at import and
+    downloads it when missing; this package NEVER downloads: the file is looked for at
+    ``path``, ``$V21_DATASET`` or next to this module, and otherwise the constructors
+    require the arrays to be passed explicitly."""
+    global _dataset
+    if _dataset is not None and path is None:
+        return _dataset
+    cands = [path, os.environ.get("V21_DATASET"), PATH + "dataset_21cmVAE.h5"]
+    for c in cands:
+        if c and os.path.exists(c):
+            from . import h5lite
+            with h5lite.File(c) as hf:
+                _dataset = {k: hf[k][:] for k in _DATASET_KEYS}
+            return _dataset
+    return None
+
+
+def _resolve_data(given):
+    if all(v is not None for v in given.values()):
+        return given
+    ds = load_dataset()
+    if ds is None:
+        missing = [k for k, v in given.items() if v is None]
+        raise ValueError("dataset_21cmVAE.h5 was not found (this package does not download it): pass %s, or "
+                         "set V21_DATASET" % ", ".join(missing))
+    return {k: (v if v is not None else ds[k]) for k, v in given.items()}
+
+
+def _grid(redshifts_, frequencies):
+    if frequencies is None:
+        if redshifts_ is not None:
+            frequencies = redshift2freq(redshifts_)
+    elif redshifts_ is None:
+        redshifts_ = freq2redshift(frequencies)
+    return redshifts_, frequencies
+
+
+class _EmulatorBase:
+    par_labels = ["fstar", "Vc", "fx", "tau", "alpha", "nu_min", "Rmfp"]
+
+    def _set_data(self, par_train, par_val, par_test, signal_train, signal_val, signal_test):
+        d = _resolve_data(dict(par_train=par_train, par_val=par_val, par_test=par_test,
+                               signal_train=signal_train, signal_val=signal_val, signal_test=signal_test))
+        for k, v in d.items():
+            setattr(self, k, v)
+        self.par_labels = list(_EmulatorBase.par_labels)
+
+    def _predict_stack(self, model, params):
+        """par_transform -> device stack -> unpreproc, squeezing a single row
+        (emulator.py:401-407 / :788-795).  The parameter transform is done on the host in
+        float64 exactly as the reference does; the un-preprocessing is fused into the
+        last layer's epilogue on the device."""
+        x = pp.par_transform(params, self.par_train)
+        st = model._ensure_stack()
+        ss = pp.SignalStats.of(self.signal_train)
+        key = (id(self.signal_train), float(ss.std))
+        if getattr(st, "_out_key", None) != key:
+            st.set_output_transform(ss.std, ss.mean)
+            st._out_key = key
+        from . import _native as nat
+        pred = st.forward(x, model.precision, flags=nat.FWD_OUT_TRANSFORM)
+        return pred[0, :] if pred.shape[0] == 1 else pred
+
+    def save(self):
+        raise NotImplementedError("Not implemented yet.")
+
+
+class DirectEmulator(_EmulatorBase):
+    """The direct emulator (21cmVAE proper): 7 parameters -> 451-bin global signal."""
+
+    def __init__(self, par_train=None, par_val=None, par_test=None, signal_train=None, signal_val=None,
+                 signal_test=None, hidden_dims=hidden_dims, activation_func="relu", redshifts=redshifts,
+                 frequencies=None, precision="f32"):
+        self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test)
+        self.emulator = _gen_model(self.par_train.shape[-1], hidden_dims, self.signal_train.shape[-1],
+                                   activation_func, name="emulator")
+        self.emulator.precision = precision
+        self.redshifts, self.frequencies = _grid(redshifts, frequencies)
+
+    def load_model(self, model_path=PATH + "models/emulator.h5"):
+        """Load a saved model (Keras legacy .h5 or the engine's .npz).  Raises IOError if the
+        path does not hold one (the reference's default file is not redistributed)."""
+        from . import h5lite
+        prec = self.emulator.precision
+        self.emulator = h5lite.load_model(model_path)
+        self.emulator.precision = prec
+
+    def train(self, epochs, callbacks=[], verbose="tqdm"):
+        """Train the emulator; returns (loss, val_loss) lists, one entry per epoch."""
+        X_train = pp.par_transform(self.par_train, self.par_train)
+        X_val = pp.par_transform(self.par_val, self.par_train)
+        y_train = pp.preproc(self.signal_train, self.signal_train)
+        y_val = pp.preproc(self.signal_val, self.signal_train)
+        callbacks = list(callbacks)  # (the reference appends to its default-argument list)
+        if verbose == "tqdm":
+            callbacks.append(TqdmCallback())
+            verbose = 0
+        hist = self.emulator.fit(x=X_train, y=y_train, batch_size=256, epochs=epochs,
+                                 validation_data=(X_val, y_val), validation_batch_size=256,
+                                 callbacks=callbacks, verbose=verbose)
+        return hist.history["loss"], hist.history["val_loss"]
+
+    def predict(self, params):
+        """Global signal(s) for one parameter vector (-> 1-D) or an (N, 7) array (-> (N, 451))."""
+        return self._predict_stack(self.emulator, params)
+
+    def test_error(self, relative=True, flow=None, fhigh=None):
+        return error(self.signal_test, self.predict(self.par_test), relative=relative,
+                     nu_arr=self.frequencies, flow=flow, fhigh=fhigh)
+
+
+class AutoEncoder(ChainedModel):
+    """Encoder + decoder pair of the autoencoder-based emulator; ``call`` reconstructs."""
+
+    def __init__(self, signal_train=None, enc_hidden_dims=[], dec_hidden_dims=[], latent_dim=9,
+                 activation_func="relu"):
+        if signal_train is None:
+            signal_train = _resolve_data(dict(signal_train=None))["signal_train"]
+        super().__init__([], name="auto_encoder")
+        d = signal_train.shape[-1]
+        self.encoder = _gen_model(d, enc_hidden_dims, latent_dim, activation_func, name="encoder")
+        self.decoder = _gen_model(None, dec_hidden_dims, d, activation_func, name="decoder")
+
+    def _chain(self):  # plain attribute assignment of .encoder/.decoder re-wires the chain
+        return [self.encoder, self.decoder]
+
+    def call(self, signals):
+        return self.predict(signals)
+
+
+# default parameters (emulator.py:522-525)
+latent_dim = 9
+enc_hidden_dims = [352]
+dec_hidden_dims = [32, 352]
+em_hidden_dims = [352, 352, 352, 224]
+
+
+class AutoEncoderEmulator(_EmulatorBase):
+    """The autoencoder-based emulator of Appendix A: parameters -> latent -> decoder."""
+
+    AE_PATH = PATH + "models/autoencoder_based_emulator/"
+
+    def __init__(self, par_train=None, par_val=None, par_test=None, signal_train=None, signal_val=None,
+                 signal_test=None, latent_dim=latent_dim, enc_hidden_dims=enc_hidden_dims,
+                 dec_hidden_dims=dec_hidden_dims, em_hidden_dims=em_hidden_dims, activation_func="relu",
+                 redshifts=redshifts, frequencies=None, precision="f32"):
+        self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test)
+        self.redshifts, self.frequencies = _grid(redshifts, frequencies)
+        autoencoder = AutoEncoder(self.signal_train, enc_hidden_dims, dec_hidden_dims, latent_dim, activation_func)
+        autoencoder.build((None, self.signal_train.shape[-1]))
+        autoencoder.precision = precision
+        self.autoencoder = autoencoder
+        self.emulator = _gen_model(self.par_train.shape[-1], em_hidden_dims, latent_dim, activation_func,
+                                   name="ae_emulator")
+        self.emulator.precision = precision
+        self.precision = precision
+        self._chain_model = None
+
+    def load_model(self, emulator_path=AE_PATH + "ae_emulator.h5", encoder_path=AE_PATH + "encoder.h5",
+                   decoder_path=AE_PATH + "decoder.h5"):
+        from . import h5lite
+        self.emulator = h5lite.load_model(emulator_path)
+        encoder = h5lite.load_model(encoder_path)
+        decoder = h5lite.load_model(decoder_path)
+        autoencoder = AutoEncoder(signal_train=self.signal_train)
+        autoencoder.encoder = encoder
+        autoencoder.decoder = decoder
+        for m in (self.emulator, autoencoder):
+            m.precision = self.precision
+        self.autoencoder = autoencoder
+        self._chain_model = None
+
+    def train(self, epochs, ae_callbacks=[], em_callbacks=[], verbose="tqdm"):
+        """Sequential two-phase recipe of the reference (emulator.py:701-768): fit the
+        autoencoder x -> x, encode the signals with the frozen encoder, fit the emulator
+        parameters -> latent.  Returns (ae_loss, ae_val_loss, loss, val_loss)."""
+        y_train = pp.preproc(self.signal_train, self.signal_train)
+        y_val = pp.preproc(self.signal_val, self.signal_train)
+        ae_callbacks, em_callbacks = list(ae_callbacks), list(em_callbacks)
+        if verbose == "tqdm":
+            ae_callbacks.append(TqdmCallback())
+            em_callbacks.append(TqdmCallback())
+            verbose = 0
+        hist = self.autoencoder.fit(x=y_train, y=y_train, batch_size=256, epochs=epochs,
+                                    validation_data=(y_val, y_val), callbacks=ae_callbacks, verbose=verbose)
+        ae_loss, ae_val_loss = hist.history["loss"], hist.history["val_loss"]
+        X_train = pp.par_transform(self.par_train, self.par_train)
+        X_val = pp.par_transform(self.par_val, self.par_train)
+        z_train = self.autoencoder.encoder.predict(y_train)
+        z_val = self.autoencoder.encoder.predict(y_val)
+        hist = self.emulator.fit(x=X_train, y=z_train, batch_size=256, epochs=epochs,
+                                 validation_data=(X_val, z_val), callbacks=em_callbacks, verbose=verbose)
+        self._chain_model = None
+        return ae_loss, ae_val_loss, hist.history["loss"], hist.history["val_loss"]
+
+    def _predict_chain(self):
+        blocks = [self.emulator, self.autoencoder.decoder]
+        cm = self._chain_model
+        if cm is None or cm._blocks[0] is not blocks[0] or cm._blocks[1] is not blocks[1]:
+            cm = ChainedModel(blocks, name="ae_emulator_decoder")
+            self._chain_model = cm
+        cm.precision = self.emulator.precision
+        return cm
+
+    def predict(self, params):
+        """emulator.predict then decoder.predict then unpreproc (emulator.py:788-795),
+        evaluated as ONE fused device stack 7 -> ... -> 9 -> 32 -> 352 -> 451."""
+        return self._predict_stack(self._predict_chain(), params)
+
+    def test_error(self, use_autoencoder=False, relative=True, flow=None, fhigh=None):
+        if use_autoencoder:
+            pred = pp.unpreproc(self.autoencoder(pp.preproc(self.signal_test, self.signal_train)), self.signal_train)
+        else:
+            pred = self.predict(self.par_test)
+        return error(self.signal_test, pred, relative=relative, nu_arr=self.frequencies, flow=flow, fhigh=fhigh)
+
+
+# names used by BASELINE.json's north_star
+Emulator = DirectEmulator
+VAEEmulator = AutoEncoderEmulator

@@ -51,13 +51,28 @@ def make_signals(n, seed, basis_seed=2):
     return (Z @ B * 50.0 - 40.0).astype(np.float32)
 
 
+def signals_from_params(par, basis_seed=2, map_seed=4):
+    """(n,451) float32 signals that are a smooth deterministic function of the parameters
+    (so that an emulator has something to learn): box-normalised log-parameters ->
+    tanh of a fixed random linear map -> the smooth basis."""
+    par = np.asarray(par, dtype=np.float64)
+    u = np.empty_like(par)
+    for j, (lo, hi, logu) in enumerate(_BOX):
+        col = par[:, j].copy()
+        if logu:
+            col[col == 0] = lo
+            u[:, j] = (np.log10(col) - np.log10(lo)) / (np.log10(hi) - np.log10(lo))
+        else:
+            u[:, j] = (col - lo) / (hi - lo)
+    B = signal_basis(basis_seed)
+    A = np.random.default_rng(map_seed).normal(size=(N_PAR, B.shape[0]))
+    Z = np.tanh((2 * u - 1) @ A)
+    return (Z @ B * 50.0 - 40.0).astype(np.float32)
+
+
 def make_dataset(n_train=N_TRAIN, n_val=N_VAL, n_test=N_TEST, seed=1):
-    """The six arrays the reference reads at import, same names (emulator.py:198-204)."""
-    return dict(
-        par_train=make_params(n_train, seed, corners=True),
-        par_val=make_params(n_val, seed + 100),
-        par_test=make_params(n_test, seed + 200),
-        signal_train=make_signals(n_train, seed + 300),
-        signal_val=make_signals(n_val, seed + 400),
-        signal_test=make_signals(n_test, seed + 500),
-    )
+    """The six arrays the reference reads at import, same names (emulator.py:198-204);
+    signals are a smooth function of the parameters."""
+    pt, pv, pe = make_params(n_train, seed, corners=True), make_params(n_val, seed + 100), make_params(n_test, seed + 200)
+    return dict(par_train=pt, par_val=pv, par_test=pe, signal_train=signals_from_params(pt),
+                signal_val=signals_from_params(pv), signal_test=signals_from_params(pe))

@@ -1,0 +1,154 @@
+"""GPU: the reference's class surface (emulator.py) on the MI355X engine.  The tests mirror
+the reference's own tests/test_emulator.py and tests/test_preprocess.py on synthetic data
+of the same shapes (the real dataset is not redistributable/offline)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pkg
+from oracle import ref_numpy as ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data():
+    synth = pkg("synth")
+    return synth.make_dataset(n_train=3000, n_val=400, n_test=300, seed=1)
+
+
+def test_gen_model():
+    # reference tests/test_emulator.py:12-21
+    emulator = pkg("emulator")
+    hidden = [32, 64, 256]
+    model = emulator._gen_model(7, hidden, 451, "relu")
+    all_dims = hidden + [451]
+    assert len(model.layers) == len(all_dims)
+    for i, layer in enumerate(model.layers):
+        assert layer.output_shape[-1] == all_dims[i]
+    assert model.count_params() == 7 * 32 + 32 + 32 * 64 + 64 + 64 * 256 + 256 + 256 * 451 + 451
+
+
+def test_z_nu_and_error():
+    emulator = pkg("emulator")
+    assert np.isclose(30, emulator.freq2redshift(emulator.redshift2freq(30)))  # test_emulator.py:36-39
+    sig = pkg("synth").make_signals(20, seed=1)
+    assert np.allclose(emulator.error(sig, sig), 0)                            # :42-47
+    nu = emulator.redshift2freq(np.linspace(5, 50, 451))
+    e_band = emulator.error(sig, sig + 1.0, relative=False, nu_arr=nu, flow=50, fhigh=100)
+    assert e_band.shape == (20,) and np.allclose(e_band, 1.0)
+    with pytest.raises(ValueError):
+        emulator.error(sig, sig, flow=50)
+
+
+def test_direct_emulator_predict_contract(data):
+    """reference tests/test_emulator.py:55-69 (shape, batched == single to 5e-5) + oracle parity."""
+    emulator = pkg("emulator")
+    direm = emulator.DirectEmulator(**data)
+    pars = direm.par_test[0]
+    pred = direm.predict(pars)
+    assert pred.shape == direm.signal_test[0].shape and pred.dtype == np.float32
+    preds = direm.predict(direm.par_test[:10])
+    assert preds.shape == (10, 451)
+    assert np.allclose(preds[0], pred, atol=5e-5)
+    assert direm.predict(direm.par_test[:1]).shape == (451,)        # any single row is squeezed (:404-405)
+    assert direm.predict(list(map(float, pars))).shape == (451,)    # lists are accepted (sample notebook)
+    Ws = [l.kernel for l in direm.emulator.layers]; bs = [l.bias for l in direm.emulator.layers]
+    ref = ora.direct_predict(Ws, bs, direm.par_test[:50], direm.par_train, direm.signal_train, dtype=np.float64)
+    np.testing.assert_allclose(direm.predict(direm.par_test[:50]), ref, atol=2e-5 * float(np.std(direm.signal_train)) + 1e-4, rtol=1e-5)
+    err = direm.test_error()
+    assert err.shape == (direm.signal_test.shape[0],)
+    assert direm.test_error(relative=False, flow=50, fhigh=100).shape == err.shape
+    with pytest.raises(NotImplementedError):
+        direm.save()
+    with pytest.raises(IOError):
+        direm.load_model()  # the reference's models/emulator.h5 is not redistributed
+
+
+def test_direct_emulator_train_returns_keras_history(data):
+    emulator, cbm, optm, eng = pkg("emulator"), pkg("callbacks"), pkg("optimizers"), pkg("engine")
+    eng.set_random_seed(0)
+    direm = emulator.DirectEmulator(hidden_dims=[64, 128], **data)  # the sample notebook's toy model
+    direm.emulator.compile(optimizer=optm.Adam(0.01), loss=emulator.relative_mse_loss(direm.signal_train))
+    before = direm.test_error().mean()
+    es = cbm.EarlyStopping(monitor="val_loss", patience=15, min_delta=1e-5, restore_best_weights=True)
+    rl = cbm.ReduceLROnPlateau(monitor="val_loss", factor=0.7, min_delta=1e-4)
+    loss, val_loss = direm.train(epochs=12, callbacks=[es, rl], verbose=0)
+    assert isinstance(loss, list) and len(loss) == len(val_loss) == 12
+    assert all(isinstance(v, float) for v in loss)
+    assert loss[-1] < loss[0] and val_loss[-1] < val_loss[0]
+    after = direm.test_error().mean()
+    assert after < before
+    assert direm.emulator.optimizer.iterations == 12 * int(np.ceil(3000 / 256))
+    # weights trained on the device are visible through get_weights and drive predict
+    Ws = direm.emulator.get_weights()[0::2]; bs = direm.emulator.get_weights()[1::2]
+    ref = ora.direct_predict(Ws, bs, direm.par_test[:20], direm.par_train, direm.signal_train, dtype=np.float64)
+    np.testing.assert_allclose(direm.predict(direm.par_test[:20]), ref, atol=1e-3, rtol=1e-4)
+    with pytest.raises(RuntimeError):
+        emulator.DirectEmulator(hidden_dims=[8], **data).train(epochs=1, verbose=0)  # not compiled
+
+
+def test_autoencoder_emulator_load_predict_shipped_weights(data, shipped):
+    """AutoEncoderEmulator.load_model default paths (packaged conversions of the reference's
+    files) + predict through the fused chain; reference tests/test_emulator.py:88-102."""
+    emulator = pkg("emulator")
+    ae_em = emulator.AutoEncoderEmulator(**data)
+    ae_em.load_model()
+    assert [l.units for l in ae_em.emulator.layers] == [352, 352, 352, 224, 9]
+    assert [l.units for l in ae_em.autoencoder.layers] == [352, 9, 32, 352, 451]
+    pars = ae_em.par_test[:10]
+    preds = ae_em.predict(pars)
+    assert preds.shape == (10, 451)
+    assert np.allclose(ae_em.predict(pars[0]), preds[0], atol=5e-5)
+    ref = ora.ae_predict(shipped["ae_emulator"], shipped["decoder"], pars, ae_em.par_train, ae_em.signal_train, dtype=np.float64)
+    np.testing.assert_allclose(preds, ref, atol=2e-5 * float(np.std(ae_em.signal_train)) + 1e-4, rtol=1e-5)
+    e1 = ae_em.test_error()
+    e2 = ae_em.test_error(use_autoencoder=True)
+    assert e1.shape == e2.shape == (ae_em.signal_test.shape[0],)
+    # f16 operands: same predictions to well within the emulation-error budget
+    ae16 = emulator.AutoEncoderEmulator(precision="f16", **data)
+    ae16.load_model()
+    d = emulator.error(preds, ae16.predict(pars))
+    assert d.mean() < 0.05
+
+
+def test_autoencoder_emulator_two_phase_training(data):
+    emulator, optm, eng = pkg("emulator"), pkg("optimizers"), pkg("engine")
+    eng.set_random_seed(1)
+    ae_em = emulator.AutoEncoderEmulator(latent_dim=6, enc_hidden_dims=[32], dec_hidden_dims=[16, 32],
+                                         em_hidden_dims=[32, 32], **data)
+    ae_em.autoencoder.compile(optimizer=optm.Adam(0.001), loss=emulator.relative_mse_loss(ae_em.signal_train))
+    ae_em.emulator.compile(optimizer=optm.Adam(0.01), loss=emulator.mean_squared_error)
+    out = ae_em.train(epochs=5, verbose=0)
+    assert len(out) == 4 and all(len(o) == 5 for o in out)
+    ae_loss, ae_val, em_loss, em_val = out
+    assert ae_loss[-1] < ae_loss[0] and em_loss[-1] < em_loss[0]
+    # decoder trained inside the autoencoder chain is the one predict() uses
+    z = ae_em.emulator.predict(pkg("preprocess").par_transform(ae_em.par_test[:5], ae_em.par_train))
+    dec = ae_em.autoencoder.decoder.predict(z)
+    full = ae_em.predict(ae_em.par_test[:5])
+    np.testing.assert_allclose(full, pkg("preprocess").unpreproc(dec, ae_em.signal_train), atol=1e-3, rtol=1e-4)
+
+
+def test_load_keras_h5_and_alias_package(data):
+    import VeryAccurateEmulator as VAE
+    assert VAE.emulator.Emulator is VAE.emulator.DirectEmulator
+    assert VAE.emulator.VAEEmulator is VAE.emulator.AutoEncoderEmulator
+    exp = np.load(os.path.join(GOLDEN, "tiny_h5_expected.npz"))
+    d = dict(data); d["signal_train"] = data["signal_train"][:, :5]; d["signal_val"] = data["signal_val"][:, :5]
+    d["signal_test"] = data["signal_test"][:, :5]
+    em = VAE.emulator.DirectEmulator(hidden_dims=[12], **d)
+    em.load_model(os.path.join(GOLDEN, "tiny_keras_model.h5"))
+    x = VAE.preprocess.par_transform(em.par_test[:7], em.par_train)
+    ref = ora.mlp_forward([exp["W0"], exp["W1"]], [exp["b0"], exp["b1"]], x)
+    np.testing.assert_allclose(em.emulator.predict(x), ref, atol=2e-5, rtol=1e-5)
+    assert em.predict(em.par_test[:7]).shape == (7, 5)
+
+
+def test_missing_dataset_is_an_error_not_a_download():
+    emulator = pkg("emulator")
+    if emulator.load_dataset() is not None:
+        pytest.skip("a dataset file is present")
+    with pytest.raises(ValueError, match="not found"):
+        emulator.DirectEmulator()

@@ -1,0 +1,188 @@
+"""GPU parity of the training path (K2 loss/grad, K3 backward GEMMs, K4 Adam, K5 batch
+gather + Keras-shaped epoch loop) against the CPU oracle, through the C ABI.
+
+Tolerances: the device sums in a different order from numpy (and in f32), so f32 mode
+is compared with the float64 oracle at rtol 2e-4 on gradients / 1e-4 on weights after a
+few steps (relative to the tensor's scale); f16/bf16 operand modes are checked on the
+gradient direction (cosine) and on the loss trajectory."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import ref_numpy as ora
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(ctx, dims, act=None, seed=0, prec="f32", max_batch=256):
+    native = pkg("_native")
+    act = act or [1] * (len(dims) - 2) + [0]
+    Ws, bs = ora.init_mlp(dims, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    bs = [rng.normal(scale=0.05, size=b.shape).astype(np.float32) for b in bs]
+    st = native.Stack(ctx, dims, act)
+    st.set_weights(ora.flatten_params(Ws, bs))
+    tr = native.Trainer(st, prec, max_batch)
+    return st, tr, Ws, bs
+
+
+def _close(a, b, rtol, what):
+    scale = np.abs(b).max() + 1e-30
+    err = np.abs(a - b).max() / scale
+    assert err < rtol, "%s: max err / scale = %.3e (limit %.1e)" % (what, err, rtol)
+
+
+def test_single_step_grad_adam_state(ctx):
+    dims = [7, 32, 16, 5]
+    st, tr, Ws, bs = _make(ctx, dims, seed=3)
+    rng = np.random.default_rng(0)
+    n = 64
+    x = rng.normal(size=(n, 7)).astype(np.float32)
+    y = rng.normal(size=(n, 5)).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, size=n).astype(np.float32)
+    tr.set_adam(lr=1e-2)
+    tr.set_data(0, x, y, w)
+    loss = tr.run_epoch(None, n)  # one step, rows in order
+    # oracle, float64
+    W64 = [W.astype(np.float64) for W in Ws]; b64 = [b.astype(np.float64) for b in bs]
+    sto = ora.AdamState(st.num_params, dtype=np.float64, lr=1e-2)
+    W2, b2, loss_o, g_o = ora.train_step(W64, b64, sto, x.astype(np.float64), y.astype(np.float64), w.astype(np.float64), np.float64)
+    assert abs(loss - loss_o) / loss_o < 1e-5
+    _close(tr.get_grad(), g_o, 2e-4, "gradient")
+    it, m, v = tr.get_state()
+    assert it == 1
+    _close(m, sto.m, 2e-4, "adam m")
+    _close(v, sto.v, 4e-4, "adam v")
+    _close(st.get_weights(), ora.flatten_params(W2, b2), 1e-5, "weights after 1 step")
+    # the forward of the updated weights is served by the fused/generic predict path too
+    np.testing.assert_allclose(st.forward(x, "f32"), ora.mlp_forward(W2, b2, x), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n,batch", [(100, 32), (96, 32), (50, 64)])
+def test_epochs_match_oracle_fit(ctx, n, batch):
+    """Keras bookkeeping: shuffled order, partial last batch kept, sample-weighted epoch
+    loss, validation pass after the epoch."""
+    dims = [7, 24, 12, 9]
+    st, tr, Ws, bs = _make(ctx, dims, seed=5, max_batch=64)
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(n, 7)).astype(np.float32); y = rng.normal(size=(n, 9)).astype(np.float32)
+    xv = rng.normal(size=(40, 7)).astype(np.float32); yv = rng.normal(size=(40, 9)).astype(np.float32)
+    w = ora.mse_row_weight(y).astype(np.float32); wv = ora.mse_row_weight(yv).astype(np.float32)
+    tr.set_adam(lr=3e-3)
+    tr.set_data(0, x, y, w); tr.set_data(1, xv, yv, wv)
+    sto = ora.AdamState(st.num_params, dtype=np.float64, lr=3e-3)
+    W, b = [a.astype(np.float64) for a in Ws], [a.astype(np.float64) for a in bs]
+    for ep in range(3):
+        perm = ora.epoch_permutation(n, 7, ep)
+        loss = tr.run_epoch(perm, batch)
+        vloss = tr.evaluate(1, batch)
+        W, b, hist = ora.fit(W, b, sto, x.astype(np.float64), y.astype(np.float64), w.astype(np.float64), 1, batch, seed=7,
+                             val=(xv.astype(np.float64), yv.astype(np.float64), wv.astype(np.float64)),
+                             dtype=np.float64, start_epoch=ep)
+        assert abs(loss - hist["loss"][0]) / hist["loss"][0] < 2e-5, (ep, loss, hist["loss"][0])
+        assert abs(vloss - hist["val_loss"][0]) / hist["val_loss"][0] < 2e-5
+    it, _, _ = tr.get_state()
+    assert it == sto.t == 3 * ((n + batch - 1) // batch)
+    _close(st.get_weights(), ora.flatten_params(W, b), 2e-4, "weights after 3 epochs")
+
+
+def test_autoencoder_fit_y_is_x_relative_mse(ctx):
+    """AutoEncoderEmulator phase 1 (emulator.py:739-747): x -> x with relative_mse_loss,
+    linear latent layer in the middle of the stack."""
+    synth = pkg("synth")
+    dims = [451, 48, 9, 16, 451]
+    act = [1, 0, 1, 0]
+    st, tr, Ws, bs = _make(ctx, dims, act=act, seed=8, max_batch=128)
+    sig = synth.make_signals(200, seed=3)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    tr.set_adam(lr=1e-3)
+    tr.set_data(0, y, None, w)
+    perm = ora.epoch_permutation(200, 1, 0)
+    loss = tr.run_epoch(perm, 128)
+    # oracle with the same activations
+    def fwd(Wl, bl, x):
+        acts = [x]
+        for W_, b_, a in zip(Wl, bl, act):
+            z = acts[-1] @ W_ + b_
+            acts.append(np.maximum(z, 0) if a else z)
+        return acts
+    W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
+    sto = ora.AdamState(st.num_params, dtype=np.float64, lr=1e-3)
+    tot = 0.0
+    for s in range(0, 200, 128):
+        idx = perm[s:s + 128]
+        acts = fwd(W, b, y[idx].astype(np.float64))
+        l, g = ora.batch_loss_and_grad(acts[-1], y[idx].astype(np.float64), w[idx].astype(np.float64))
+        tot += l * len(idx)
+        dz = g; dWs = [None] * 4; dbs = [None] * 4
+        for li in range(3, -1, -1):
+            dWs[li] = acts[li].T @ dz; dbs[li] = dz.sum(0)
+            dh = dz @ W[li].T
+            dz = dh * (acts[li] > 0) if li > 0 and act[li - 1] else dh
+        flat = ora.adam_step(ora.flatten_params(W, b), ora.flatten_params(dWs, dbs), sto)
+        W, b = ora.unflatten_params(flat, dims)
+    assert abs(loss - tot / 200) / (tot / 200) < 2e-5
+    _close(st.get_weights(), ora.flatten_params(W, b), 2e-4, "AE weights after 1 epoch")
+
+
+def test_reference_architecture_step_all_precisions(ctx):
+    """DirectEmulator default stack (emulator.py:196), batch 256 as emulator.py:372."""
+    synth = pkg("synth")
+    dims = [7, 288, 352, 288, 224, 451]
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, size=(256, 7)).astype(np.float32)
+    sig = synth.make_signals(256, seed=4)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    ref = None
+    for prec, cos_min in (("f32", 0.999999), ("f16", 0.9995), ("bf16", 0.99)):
+        st, tr, Ws, bs = _make(ctx, dims, seed=6, prec=prec)
+        tr.set_adam(lr=1e-3)
+        tr.set_data(0, x, y, w)
+        loss = tr.run_epoch(None, 256)
+        g = tr.get_grad()
+        if ref is None:
+            W64 = [W.astype(np.float64) for W in Ws]; b64 = [b.astype(np.float64) for b in bs]
+            sto = ora.AdamState(st.num_params, dtype=np.float64, lr=1e-3)
+            _, _, loss_o, g_o = ora.train_step(W64, b64, sto, x.astype(np.float64), y.astype(np.float64),
+                                               w.astype(np.float64), np.float64)
+            ref = (loss_o, g_o)
+            _close(g, g_o, 5e-4, "f32 gradient of the reference stack")
+        cos = float(g @ ref[1] / (np.linalg.norm(g) * np.linalg.norm(ref[1])))
+        print("%s: loss rel err %.2e, grad cosine %.7f" % (prec, abs(loss - ref[0]) / ref[0], cos))
+        assert cos > cos_min
+        assert abs(loss - ref[0]) / ref[0] < (1e-5 if prec == "f32" else 2e-2)
+
+
+def test_loss_decreases_and_state_roundtrip(ctx):
+    dims = [7, 64, 64, 20]
+    st, tr, Ws, bs = _make(ctx, dims, seed=9, max_batch=128)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, size=(1000, 7)).astype(np.float32)
+    y = np.tanh(x @ rng.normal(size=(7, 20))).astype(np.float32)
+    w = ora.mse_row_weight(y).astype(np.float32)
+    tr.set_adam(lr=3e-3)
+    tr.set_data(0, x, y, w)
+    losses = [tr.run_epoch(ora.epoch_permutation(1000, 0, ep), 128) for ep in range(8)]
+    assert losses[-1] < 0.5 * losses[0], losses
+    assert abs(tr.evaluate(0, 128) - tr.evaluate(0, 100)) < 1e-6 * losses[-1] + 1e-9
+    it, m, v = tr.get_state()
+    tr.set_state(it, m, v)
+    it2, m2, v2 = tr.get_state()
+    assert it2 == it and np.array_equal(m, m2) and np.array_equal(v, v2)
+    tr.set_lr(1e-4)
+    assert tr.get_lr() == float(np.float32(1e-4))
+
+
+def test_trainer_argument_errors(ctx):
+    native = pkg("_native")
+    st, tr, _, _ = _make(ctx, [7, 8, 3], max_batch=16)
+    with pytest.raises(native.EngineError):
+        tr.run_epoch(None, 8)  # no data yet
+    x = np.zeros((20, 7), np.float32); y = np.zeros((20, 3), np.float32); w = np.ones(20, np.float32)
+    tr.set_data(0, x, y, w)
+    with pytest.raises(native.EngineError):
+        tr.run_epoch(None, 64)  # exceeds max_batch
+    with pytest.raises(native.EngineError):
+        tr.set_data(0, x, None, w)  # y = x needs in_dim == out_dim
