@@ -8,11 +8,18 @@
 //     weights   [dW; db] = [H^T; 1^T] dZ           (A m-contiguous, B n-contiguous)
 // The bias gradient rides along as one extra row of ones appended to H^T, so that the
 // (K+1) x N result is exactly the [kernel | bias] slice of the flat gradient arena.
+// The weight-gradient contraction runs over the batch; it is split over blockIdx.z
+// (SPLIT-K) into per-slice slabs that adam/reduce kernels sum in a fixed order, so the
+// result is bitwise reproducible (no float atomics).
 //
 // 64x64 output tile per 256-thread workgroup (4 waves as 2x2, one 32x32 MFMA tile
-// each), BK = 32.  Operands are fp32 in memory and are converted to the compute type
-// while being staged into LDS ([row][k] images, k contiguous, rows padded by 16 B).
-// f32 mode uses v_mfma_f32_32x32x2_f32 (exact); f16/bf16 use v_mfma_f32_32x32x16.
+// each), BK = 32.  Operands are fp32 in memory; each thread fetches its 8 elements of
+// the NEXT k-tile into registers before the MFMAs of the current one (so the global
+// latency hides under compute), converts them to the compute type and writes them to
+// the [row][k] LDS images after the barrier.  k-contiguous operands are fetched as
+// 128-byte row segments (float4 per lane when 16-byte aligned), row-contiguous operands
+// as 256-byte column segments.  f32 mode uses v_mfma_f32_32x32x2_f32 (exact);
+// f16/bf16 use v_mfma_f32_32x32x16.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,6 +36,8 @@ struct GemmArgs {
   const float* mask; long long ldmask;    // EP_MASK: multiply by [mask(m,n) > 0]
   int ones_row;                           // A(m == ones_row, k) = 1  (-1: none)
   float alpha;                            // C = alpha * acc (EP_PLAIN)
+  int k_chunk;                            // split-K: k range of slice z = [z*k_chunk, ...)
+  long long slab_stride;                  // C of slice z = C + z*slab_stride (floats)
 };
 
 enum { EP_PLAIN = 0, EP_BIAS = 1, EP_BIAS_RELU = 2, EP_MASK = 3 };
@@ -40,7 +49,64 @@ template <> struct GemmTraits<PrecF32> { using T = float; static constexpr int P
 template <> struct GemmTraits<PrecF16> { using T = _Float16; static constexpr int PITCH = kBK + 8; };
 template <> struct GemmTraits<PrecBF16> { using T = __bf16; static constexpr int PITCH = kBK + 8; };
 
-template <class P, int EP>
+// One operand tile (64 rows x 32 k) : fetch this thread's 8 values.
+//   KC (k-contiguous):  thread -> rows {t/8, t/8+32}, k = 4*(t%8) .. +3
+//   RC (row-contiguous): thread -> row t%64, k = 8*(t/64) .. +7
+template <bool KC>
+__device__ __forceinline__ void fetch_tile(float (&v)[8], const float* __restrict__ base, long long s_row,
+                                           long long s_k, int row0, int nrows, int k0, int kend, int tid,
+                                           int ones_row) {
+  if constexpr (KC) {
+    const int kk = k0 + 4 * (tid & 7);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row = row0 + (tid >> 3) + 32 * half;
+      float* o = v + 4 * half;
+      o[0] = o[1] = o[2] = o[3] = 0.f;
+      if (row < nrows) {
+        if (row == ones_row) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (kk + i < kend) ? 1.f : 0.f;
+        } else {
+          const float* p = base + (long long)row * s_row + kk;  // s_k == 1
+          if (kk + 3 < kend && ((reinterpret_cast<unsigned long long>(p) & 15ull) == 0)) {
+            const float4 q = *reinterpret_cast<const float4*>(p);
+            o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (kk + i < kend) o[i] = p[i];
+          }
+        }
+      }
+    }
+  } else {
+    const int row = row0 + (tid & 63);
+    const int kk = k0 + 8 * (tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float x = 0.f;
+      if (row < nrows && kk + i < kend) x = (row == ones_row) ? 1.f : base[(long long)row * s_row + (long long)(kk + i) * s_k];
+      v[i] = x;
+    }
+  }
+}
+template <bool KC, class T, int PITCH>
+__device__ __forceinline__ void store_tile(T* __restrict__ lds, const float (&v)[8], int tid) {
+  if constexpr (KC) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      T* o = lds + ((tid >> 3) + 32 * half) * PITCH + 4 * (tid & 7);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (T)v[4 * half + i];
+    }
+  } else {
+    T* o = lds + (tid & 63) * PITCH + 8 * (tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (T)v[i];
+  }
+}
+
+template <class P, int EP, bool AKC, bool BKC>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   using T = typename GemmTraits<P>::T;
   constexpr int PITCH = GemmTraits<P>::PITCH;
@@ -51,38 +117,30 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
   const int li = lane & 31, lh = lane >> 5;
+  const int kbeg = blockIdx.z * g.k_chunk;
+  const int kend = min(g.K, kbeg + g.k_chunk);
 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  // staging maps: "k-contiguous" operand -> thread owns (row = tid/4, 8 k's);
-  // "row-contiguous" operand -> thread owns (row = tid%64, 8 k's) so that consecutive
-  // lanes touch consecutive addresses either way
-  const bool a_kc = (g.sa_k == 1), b_kc = (g.sb_k == 1);
-  const int a_row = a_kc ? (tid >> 2) : (tid & 63), a_k8 = a_kc ? (tid & 3) * 8 : (tid >> 6) * 8;
-  const int b_row = b_kc ? (tid >> 2) : (tid & 63), b_k8 = b_kc ? (tid & 3) * 8 : (tid >> 6) * 8;
+  // A(m,k): rows = m.  KC: s_row = sa_m (sa_k == 1); RC: rows contiguous (sa_m == 1), s_k = sa_k
+  const long long a_srow = AKC ? g.sa_m : 1, a_sk = AKC ? 1 : g.sa_k;
+  // B(k,n): rows = n.  KC: s_row = sb_n (sb_k == 1); RC: s_row = 1 (sb_n == 1), s_k = sb_k
+  const long long b_srow = BKC ? g.sb_n : 1, b_sk = BKC ? 1 : g.sb_k;
 
-  for (int k0 = 0; k0 < g.K; k0 += kBK) {
-    {
-      const int m = m0 + a_row;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = k0 + a_k8 + i;
-        float v = 0.f;
-        if (m < g.M && k < g.K) v = (m == g.ones_row) ? 1.0f : g.A[m * g.sa_m + k * g.sa_k];
-        As[a_row * PITCH + a_k8 + i] = (T)v;
-      }
-      const int n = n0 + b_row;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = k0 + b_k8 + i;
-        float v = 0.f;
-        if (n < g.N && k < g.K) v = g.B[k * g.sb_k + n * g.sb_n];
-        Bs[b_row * PITCH + b_k8 + i] = (T)v;
-      }
-    }
+  float va[8], vb[8];
+  fetch_tile<AKC>(va, g.A, a_srow, a_sk, m0, g.M, kbeg, kend, tid, g.ones_row);
+  fetch_tile<BKC>(vb, g.B, b_srow, b_sk, n0, g.N, kbeg, kend, tid, -1);
+
+  for (int k0 = kbeg; k0 < kend; k0 += kBK) {
+    store_tile<AKC, T, PITCH>(As, va, tid);
+    store_tile<BKC, T, PITCH>(Bs, vb, tid);
     __syncthreads();
+    if (k0 + kBK < kend) {  // next tile's global loads fly while this tile is multiplied
+      fetch_tile<AKC>(va, g.A, a_srow, a_sk, m0, g.M, k0 + kBK, kend, tid, g.ones_row);
+      fetch_tile<BKC>(vb, g.B, b_srow, b_sk, n0, g.N, k0 + kBK, kend, tid, -1);
+    }
     const T* ap = As + (wm * 32 + li) * PITCH;
     const T* bp = Bs + (wn * 32 + li) * PITCH;
     if constexpr (std::is_same<P, PrecF32>::value) {
@@ -106,6 +164,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   }
 
   // C/D map of the 32x32 tile: col = lane&31, row = (i&3) + 8(i>>2) + 4(lane>>5)
+  float* C = g.C + (long long)blockIdx.z * g.slab_stride;
   const int n = n0 + wn * 32 + li;
   if (n < g.N) {
     float bias = 0.f;
@@ -117,9 +176,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         float v = acc[i];
         if constexpr (EP == EP_BIAS) v = v + bias;
         if constexpr (EP == EP_BIAS_RELU) v = fmaxf(v + bias, 0.f);
-        if constexpr (EP == EP_MASK) v = (g.mask[m * g.ldmask + n] > 0.f) ? v : 0.f;
+        if constexpr (EP == EP_MASK) v = (g.mask[(long long)m * g.ldmask + n] > 0.f) ? v : 0.f;
         if constexpr (EP == EP_PLAIN) v = v * g.alpha;
-        g.C[m * g.ldc + n] = v;
+        C[(long long)m * g.ldc + n] = v;
       }
     }
   }

@@ -71,6 +71,26 @@ __global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict
   }
 }
 
+// deterministic split-K reduction: g[i] = slab_0[i] + slab_1[i] + ... (fixed order)
+__global__ void reduce_slabs_kernel(float* __restrict__ g, const float* __restrict__ slabs, int nslab,
+                                    long long stride, long long n) {
+  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    float4 s = *(const float4*)(slabs + i4);
+    for (int k = 1; k < nslab; ++k) {
+      const float4 t = *(const float4*)(slabs + k * stride + i4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *(float4*)(g + i4) = s;
+  } else {
+    for (long long i = i4; i < n; ++i) {
+      float s = slabs[i];
+      for (int k = 1; k < nslab; ++k) s += slabs[k * stride + i];
+      g[i] = s;
+    }
+  }
+}
+
 // K4: Keras-2.7 Adam (tf.raw_ops.ResourceApplyAdam [K]):
 //   m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);  w -= alpha m / (sqrt(v) + eps)
 // alpha = lr sqrt(1-b2^t)/(1-b1^t) is computed by the host in f32.  One flat arena,

@@ -366,19 +366,26 @@ static int ensure_stream(v21_mlp* m, int prec) {
 }
 
 template <class P, int EP>
-static int launch_gemm(const GemmArgs& g, hipStream_t st) {
+static int launch_gemm(GemmArgs g, hipStream_t st, int nslice = 1) {
   if (g.M <= 0 || g.N <= 0) return V21_OK;
-  dim3 grid((g.N + kBN - 1) / kBN, (g.M + kBM - 1) / kBM);
-  hipLaunchKernelGGL((gemm_kernel<P, EP>), grid, dim3(256), 0, st, g);
+  if (nslice <= 1) { nslice = 1; g.k_chunk = g.K > 0 ? g.K : 1; g.slab_stride = 0; }
+  dim3 grid((g.N + kBN - 1) / kBN, (g.M + kBM - 1) / kBM, nslice);
+  const bool akc = g.sa_k == 1, bkc = g.sb_k == 1;
+  if (!akc && g.sa_m != 1) return fail(V21_ERR_ARG, "gemm: A must be contiguous along m or k");
+  if (!bkc && g.sb_n != 1) return fail(V21_ERR_ARG, "gemm: B must be contiguous along k or n");
+  if (akc && bkc) hipLaunchKernelGGL((gemm_kernel<P, EP, true, true>), grid, dim3(256), 0, st, g);
+  else if (akc) hipLaunchKernelGGL((gemm_kernel<P, EP, true, false>), grid, dim3(256), 0, st, g);
+  else if (bkc) hipLaunchKernelGGL((gemm_kernel<P, EP, false, true>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_kernel<P, EP, false, false>), grid, dim3(256), 0, st, g);
   HIPCHK(hipGetLastError());
   return V21_OK;
 }
 template <int EP>
-static int launch_gemm_prec(int prec, const GemmArgs& g, hipStream_t st) {
+static int launch_gemm_prec(int prec, const GemmArgs& g, hipStream_t st, int nslice = 1) {
   switch (prec) {
-    case V21_PREC_F32: return launch_gemm<PrecF32, EP>(g, st);
-    case V21_PREC_F16: return launch_gemm<PrecF16, EP>(g, st);
-    case V21_PREC_BF16: return launch_gemm<PrecBF16, EP>(g, st);
+    case V21_PREC_F32: return launch_gemm<PrecF32, EP>(g, st, nslice);
+    case V21_PREC_F16: return launch_gemm<PrecF16, EP>(g, st, nslice);
+    case V21_PREC_BF16: return launch_gemm<PrecBF16, EP>(g, st, nslice);
   }
   return fail(V21_ERR_ARG, "precision %d unknown", prec);
 }
@@ -566,6 +573,8 @@ struct v21_trainer {
   float* d_steploss = nullptr;
   long long steploss_cap = 0;
   float* d_evalsum = nullptr;
+  float* d_slab = nullptr;  // split-K partial gradients: kMaxSlices x (P + 4)
+  int max_slices = 1;
 };
 
 extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_trainer** out) {
@@ -589,6 +598,8 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
   for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc((void**)&t->d_dz[i], (size_t)max_batch * m->maxdim * sizeof(float)));
   HIPCHK(hipMalloc((void**)&t->d_rowloss, (size_t)max_batch * sizeof(float)));
   HIPCHK(hipMalloc((void**)&t->d_evalsum, 16));
+  t->max_slices = std::max(1, std::min(16, (max_batch + 255) / 256));
+  if (t->max_slices > 1) HIPCHK(hipMalloc((void**)&t->d_slab, (size_t)t->max_slices * (t->P + 4) * sizeof(float)));
   *out = t;
   return V21_OK;
 }
@@ -607,6 +618,7 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   for (float* p : t->d_h) hipFree(p);
   hipFree(t->d_yb); hipFree(t->d_wb); hipFree(t->d_rowloss); hipFree(t->d_evalsum);
   if (t->d_steploss) hipFree(t->d_steploss);
+  if (t->d_slab) hipFree(t->d_slab);
   delete t;
   return V21_OK;
 }
@@ -684,6 +696,12 @@ static int trainer_step(v21_trainer* t, const float* h0, const float* yb, const 
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_g + t->P, 0);
     HIPCHK(hipGetLastError());
+    // the weight-gradient contractions run over the batch: split it into slices of
+    // >= 256 rows, one slab per slice, summed afterwards in a fixed order
+    int nslice = std::min(t->max_slices, (rows + 255) / 256);
+    int k_chunk = ((rows + nslice - 1) / nslice + kBK - 1) / kBK * kBK;
+    nslice = (rows + k_chunk - 1) / k_chunk;
+    const long long slab_stride = (long long)t->P + 4;
     int cur = 0;
     for (int l = L - 1; l >= 0; --l) {
       const float* hin = l == 0 ? h0 : t->d_h[l];
@@ -691,10 +709,11 @@ static int trainer_step(v21_trainer* t, const float* h0, const float* yb, const 
       GemmArgs g{};  // [dW; db] = [H^T; 1^T] dZ
       g.A = hin; g.sa_m = 1; g.sa_k = K;
       g.B = t->d_dz[cur]; g.sb_k = N; g.sb_n = 1;
-      g.C = t->d_g + m->w_off[l]; g.ldc = N;
+      g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = N;
       g.M = K + 1; g.N = N; g.K = rows;
       g.ones_row = K; g.alpha = 1.f;
-      CHK(launch_gemm_prec<EP_PLAIN>(t->prec, g, st));
+      g.k_chunk = k_chunk; g.slab_stride = slab_stride;
+      CHK(launch_gemm_prec<EP_PLAIN>(t->prec, g, st, nslice));
       if (l > 0) {  // dH = dZ W^T, masked by the ReLU of the layer below
         GemmArgs d{};
         d.A = t->d_dz[cur]; d.sa_m = N; d.sa_k = 1;
@@ -710,6 +729,12 @@ static int trainer_step(v21_trainer* t, const float* h0, const float* yb, const 
         }
         cur ^= 1;
       }
+    }
+    if (nslice > 1) {
+      const long long n4 = ((long long)t->P + 3) / 4;
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
+                         (const float*)t->d_slab, nslice, slab_stride, (long long)t->P);
+      HIPCHK(hipGetLastError());
     }
   } else {
     HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));

@@ -1,0 +1,70 @@
+"""Data-parallel plumbing: one process per GPU, launched by ``torch.distributed.run``.
+
+The gradient all-reduce itself runs inside libv21.so on RCCL (``v21_comm_*``); this
+module only (a) bootstraps that communicator by broadcasting the RCCL unique id over
+``torch.distributed`` (backend ``nccl`` on GPUs, ``gloo`` in the CPU tests), (b) states the
+batch-sharding rule the C++ epoch driver uses, so it can be tested without a GPU, and
+(c) offers the same flat-buffer all-reduce over ``torch.distributed`` for hosts that
+drive the steps from Python.
+"""
+import numpy as np
+
+
+def shard_bounds(first, batch_rows, rank, world):
+    """Rows [lo, hi) of the global batch [first, first + batch_rows) that `rank` trains on:
+    contiguous, as even as possible, every row exactly once (v21_trainer_run_epoch)."""
+    lo = first + batch_rows * rank // world
+    hi = first + batch_rows * (rank + 1) // world
+    return lo, hi
+
+
+def epoch_plan(n, batch, rank, world):
+    """[(lo, hi, global_rows)] for every step of an epoch, partial last batch kept."""
+    out = []
+    for first in range(0, n, batch):
+        rows = min(batch, n - first)
+        lo, hi = shard_bounds(first, rows, rank, world)
+        out.append((lo, hi, rows))
+    return out
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def broadcast_bytes(payload, nbytes, src=0, device=None):
+    """Rank `src` passes `payload` (bytes); every rank gets the same bytes back."""
+    import torch
+    dist = _dist()
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    if dist.get_rank() == src:
+        buf.copy_(torch.tensor(list(payload), dtype=torch.uint8))
+    dist.broadcast(buf, src=src)
+    return bytes(buf.cpu().tolist())
+
+
+def init_engine_comm(ctx):
+    """Create the in-library RCCL communicator on `ctx` for the current process group."""
+    from . import _native
+    dist = _dist()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        return
+    uid = ctx.comm_unique_id() if rank == 0 else b""
+    uid = broadcast_bytes(uid, _native.COMM_ID_BYTES)
+    ctx.comm_init(world, rank, uid)
+
+
+def allreduce_flat(arr):
+    """Sum a flat float32 numpy buffer over the process group (CPU tests / Python-driven
+    loops); returns a new array."""
+    import torch
+    dist = _dist()
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).copy())
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()

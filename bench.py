@@ -67,6 +67,48 @@ def cpu_baseline(weights_flat, x_f32, budget_s=12.0):
             "sample": "%d passes over the first %d rows of the batch, numpy fp32 (BLAS sgemm), %.1f s" % (n, rows, dt)}
 
 
+AE_DIMS = [451, 352, 9, 32, 352, 451]   # encoder 451->352->9, decoder 9->32->352->451 (emulator.py:522-524)
+AE_ACT = [1, 0, 1, 1, 0]
+AE_FLOP_PER_SAMPLE = 1675840             # 6 x 332,224 - 2 x 158,752
+
+
+def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_all, batch, precision, steps, warmup):
+    """Auxiliary metric: optimizer steps/s of the autoencoder stack (relative-MSE loss, Adam),
+    per-GPU batch `batch`, gradients all-reduced over RCCL when world > 1."""
+    synth = importlib.import_module("21cmvae_amd.synth")
+    pp = importlib.import_module("21cmvae_amd.preprocess")
+    losses = importlib.import_module("21cmvae_amd.losses")
+    st = native.Stack(ctx, AE_DIMS, AE_ACT)
+    st.set_weights(glorot(AE_DIMS, seed=4))
+    tr = native.Trainer(st, precision, batch)
+    tr.set_adam(lr=1e-3)
+    sig = synth.make_signals(batch, seed=2000 + rank)
+    y = pp.preproc(sig, sig)
+    rw = losses.relative_mse_loss(sig)._v21_row_weight(y).astype(np.float32)
+    d_x, d_rw = ctx.malloc(y.nbytes), ctx.malloc(rw.nbytes)
+    ctx.h2d(d_x, y); ctx.h2d(d_rw, rw)
+    for _ in range(warmup):
+        tr.step_dev(d_x, None, d_rw, batch, batch * world)
+    sync_all(); barrier(); sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step_dev(d_x, None, d_rw, batch, batch * world)
+    sync_all(); barrier(); sync_all()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    loss = tr.last_step_loss() / (batch * world)
+    ctx.free(d_x); ctx.free(d_rw)
+    sps = steps / wall
+    return {"steps_per_s": sps, "samples_per_s": sps * batch * world, "ms_per_step": 1e3 / sps,
+            "batch_per_gpu": batch, "global_batch": batch * world, "precision": precision,
+            "model": "autoencoder 451-352-9-32-352-451, relative-MSE, Adam", "steps": steps,
+            "achieved_TFLOPs": sps * batch * world * AE_FLOP_PER_SAMPLE / 1e12, "final_batch_loss": loss,
+            "collective": "RCCL all-reduce of the flat gradient arena (%d floats)" % (st.num_params + 1) if world > 1 else "none"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +118,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=4096)
+    ap.add_argument("--train-steps", type=int, default=40)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -208,6 +253,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         xt = pp.par_transform(params.astype(np.float64), par_train).astype(np.float32)
         out["cpu_baseline"] = cpu_baseline(wflat, xt)
+
+    if not args.no_train:
+        try:
+            if world > 1:
+                importlib.import_module("21cmvae_amd.parallel").init_engine_comm(ctx)
+            tl = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
+                           args.train_batch, args.precision, args.train_steps, 5)
+            out["train"] = tl
+            if world == 1 and not args.no_extras:
+                out["train_ref_batch256_f32"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
+                                                          sync_all, 256, "f32", 200, 10)
+        except Exception as e:  # the headline metric must survive a failure of the auxiliary leg
+            out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     barrier()
     if rank == 0:

@@ -186,3 +186,23 @@ def test_trainer_argument_errors(ctx):
         tr.run_epoch(None, 64)  # exceeds max_batch
     with pytest.raises(native.EngineError):
         tr.set_data(0, x, None, w)  # y = x needs in_dim == out_dim
+
+
+def test_rccl_single_rank_communicator_is_identity():
+    """K6 plumbing on one GPU: a 1-rank RCCL communicator must not change an epoch."""
+    native = pkg("_native")
+    c2 = native.Context(0)
+    res = []
+    for use_comm in (False, True):
+        st, tr, Ws, bs = _make(c2, [7, 24, 9], seed=2, max_batch=64)
+        rng = np.random.default_rng(4)
+        x = rng.normal(size=(90, 7)).astype(np.float32); y = rng.normal(size=(90, 9)).astype(np.float32)
+        w = ora.mse_row_weight(y).astype(np.float32)
+        tr.set_data(0, x, y, w)
+        if use_comm:
+            c2.comm_init(1, 0, c2.comm_unique_id())
+        loss = tr.run_epoch(ora.epoch_permutation(90, 1, 0), 32)
+        res.append((loss, st.get_weights()))
+    c2.comm_destroy()
+    assert res[0][0] == res[1][0]
+    np.testing.assert_array_equal(res[0][1], res[1][1])
