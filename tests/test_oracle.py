@@ -179,3 +179,33 @@ def test_fit_loop_keras_bookkeeping():
     p = ora.epoch_permutation(70, 7, 0)
     assert sorted(p.tolist()) == list(range(70))
     assert not np.array_equal(p, ora.epoch_permutation(70, 7, 1))
+
+
+def test_c_oracle_agrees_with_numpy_oracle(shipped):
+    """oracle/mlp_oracle.c (gcc) vs oracle/ref_numpy.py on the reference's trained decoder."""
+    import ctypes as C
+    import subprocess
+    from conftest import ROOT
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+    Ws, bs = shipped["decoder"]
+    flat = ora.flatten_params(Ws, bs).astype(np.float32)
+    dims = (C.c_int * 4)(9, 32, 352, 451); act = (C.c_int * 3)(1, 1, 0)
+    x = np.random.default_rng(0).normal(size=(40, 9)).astype(np.float32)
+    y = np.empty((40, 451), np.float32)
+    fp = C.POINTER(C.c_float)
+    assert lib.oracle_mlp_forward(flat.ctypes.data_as(fp), dims, act, 3, x.ctypes.data_as(fp), C.c_long(40),
+                                  y.ctypes.data_as(fp), 1) == 0
+    np.testing.assert_allclose(y, ora.mlp_forward(Ws, bs, x), atol=2e-6, rtol=1e-6)
+    # Keras-Adam step, f32
+    rng = np.random.default_rng(1)
+    w = rng.normal(size=100).astype(np.float32); g = rng.normal(size=100).astype(np.float32)
+    st = ora.AdamState(100, dtype=np.float32, lr=1e-2)
+    ref = w.copy()
+    m = np.zeros(100, np.float32); v = np.zeros(100, np.float32)
+    lib.oracle_adam_step.argtypes = [fp, fp, fp, fp, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_long]
+    for t in (1, 2, 3):
+        ref = ora.adam_step(ref, g, st)
+        lib.oracle_adam_step(w.ctypes.data_as(fp), g.ctypes.data_as(fp), m.ctypes.data_as(fp), v.ctypes.data_as(fp),
+                             100, 1e-2, 0.9, 0.999, 1e-7, t)
+    np.testing.assert_allclose(w, ref, rtol=2e-6, atol=1e-7)
