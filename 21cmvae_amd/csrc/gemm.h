@@ -13,7 +13,7 @@
 // result is bitwise reproducible (no float atomics).
 //
 // 64x64 output tile per 256-thread workgroup (4 waves as 2x2, one 32x32 MFMA tile
-// each), BK = 32.  Operands are fp32 in memory; each thread fetches its 8 elements of
+// each), BK = 64, double-buffered LDS (one barrier per k-tile).  Operands are fp32 in memory; each thread fetches its 8 elements of
 // the NEXT k-tile into registers before the MFMAs of the current one (so the global
 // latency hides under compute), converts them to the compute type and writes them to
 // the [row][k] LDS images after the barrier.  k-contiguous operands are fetched as
@@ -42,25 +42,25 @@ struct GemmArgs {
 
 enum { EP_PLAIN = 0, EP_BIAS = 1, EP_BIAS_RELU = 2, EP_MASK = 3 };
 
-constexpr int kBM = 64, kBN = 64, kBK = 32;
+constexpr int kBM = 64, kBN = 64, kBK = 64;
 
 template <class P> struct GemmTraits;
 template <> struct GemmTraits<PrecF32> { using T = float; static constexpr int PITCH = kBK + 4; };
 template <> struct GemmTraits<PrecF16> { using T = _Float16; static constexpr int PITCH = kBK + 8; };
 template <> struct GemmTraits<PrecBF16> { using T = __bf16; static constexpr int PITCH = kBK + 8; };
 
-// One operand tile (64 rows x 32 k) : fetch this thread's 8 values.
-//   KC (k-contiguous):  thread -> rows {t/8, t/8+32}, k = 4*(t%8) .. +3
-//   RC (row-contiguous): thread -> row t%64, k = 8*(t/64) .. +7
+// One operand tile (64 rows x 64 k) : fetch this thread's 16 values.
+//   KC (k-contiguous):  thread -> rows t/16 + 16*{0..3}, k = 4*(t%16) .. +3   (256-B row segments)
+//   RC (row-contiguous): thread -> row t%64, k = 16*(t/64) .. +15            (256-B column segments)
 template <bool KC>
-__device__ __forceinline__ void fetch_tile(float (&v)[8], const float* __restrict__ base, long long s_row,
+__device__ __forceinline__ void fetch_tile(float (&v)[16], const float* __restrict__ base, long long s_row,
                                            long long s_k, int row0, int nrows, int k0, int kend, int tid,
                                            int ones_row) {
   if constexpr (KC) {
-    const int kk = k0 + 4 * (tid & 7);
+    const int kk = k0 + 4 * (tid & 15);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int row = row0 + (tid >> 3) + 32 * half;
+    for (int half = 0; half < 4; ++half) {
+      const int row = row0 + (tid >> 4) + 16 * half;
       float* o = v + 4 * half;
       o[0] = o[1] = o[2] = o[3] = 0.f;
       if (row < nrows) {
@@ -81,9 +81,9 @@ __device__ __forceinline__ void fetch_tile(float (&v)[8], const float* __restric
     }
   } else {
     const int row = row0 + (tid & 63);
-    const int kk = k0 + 8 * (tid >> 6);
+    const int kk = k0 + 16 * (tid >> 6);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 16; ++i) {
       float x = 0.f;
       if (row < nrows && kk + i < kend) x = (row == ones_row) ? 1.f : base[(long long)row * s_row + (long long)(kk + i) * s_k];
       v[i] = x;
@@ -91,18 +91,21 @@ __device__ __forceinline__ void fetch_tile(float (&v)[8], const float* __restric
   }
 }
 template <bool KC, class T, int PITCH>
-__device__ __forceinline__ void store_tile(T* __restrict__ lds, const float (&v)[8], int tid) {
+__device__ __forceinline__ void store_tile(T* __restrict__ lds, const float (&v)[16], int tid) {
+  typedef T T4 __attribute__((ext_vector_type(4)));
   if constexpr (KC) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      T* o = lds + ((tid >> 3) + 32 * half) * PITCH + 4 * (tid & 7);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = (T)v[4 * half + i];
+    for (int half = 0; half < 4; ++half) {
+      T4 q = {(T)v[4 * half], (T)v[4 * half + 1], (T)v[4 * half + 2], (T)v[4 * half + 3]};
+      *(T4*)(lds + ((tid >> 4) + 16 * half) * PITCH + 4 * (tid & 15)) = q;  // one 8/16-byte LDS write
     }
   } else {
-    T* o = lds + (tid & 63) * PITCH + 8 * (tid >> 6);
+    T* o = lds + (tid & 63) * PITCH + 16 * (tid >> 6);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (T)v[i];
+    for (int i = 0; i < 4; ++i) {
+      T4 q = {(T)v[4 * i], (T)v[4 * i + 1], (T)v[4 * i + 2], (T)v[4 * i + 3]};
+      *(T4*)(o + 4 * i) = q;
+    }
   }
 }
 
@@ -110,8 +113,8 @@ template <class P, int EP, bool AKC, bool BKC>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   using T = typename GemmTraits<P>::T;
   constexpr int PITCH = GemmTraits<P>::PITCH;
-  __shared__ __attribute__((aligned(16))) T As[kBM * PITCH];
-  __shared__ __attribute__((aligned(16))) T Bs[kBN * PITCH];
+  __shared__ __attribute__((aligned(16))) T As[2][kBM * PITCH];  // double-buffered: one barrier per k-tile
+  __shared__ __attribute__((aligned(16))) T Bs[2][kBN * PITCH];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -129,20 +132,22 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   // B(k,n): rows = n.  KC: s_row = sb_n (sb_k == 1); RC: s_row = 1 (sb_n == 1), s_k = sb_k
   const long long b_srow = BKC ? g.sb_n : 1, b_sk = BKC ? 1 : g.sb_k;
 
-  float va[8], vb[8];
+  float va[16], vb[16];
   fetch_tile<AKC>(va, g.A, a_srow, a_sk, m0, g.M, kbeg, kend, tid, g.ones_row);
   fetch_tile<BKC>(vb, g.B, b_srow, b_sk, n0, g.N, kbeg, kend, tid, -1);
 
-  for (int k0 = kbeg; k0 < kend; k0 += kBK) {
-    store_tile<AKC, T, PITCH>(As, va, tid);
-    store_tile<BKC, T, PITCH>(Bs, vb, tid);
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += kBK, buf ^= 1) {
+    // buffer `buf` was last read two iterations ago, before the previous barrier
+    store_tile<AKC, T, PITCH>(As[buf], va, tid);
+    store_tile<BKC, T, PITCH>(Bs[buf], vb, tid);
     __syncthreads();
     if (k0 + kBK < kend) {  // next tile's global loads fly while this tile is multiplied
       fetch_tile<AKC>(va, g.A, a_srow, a_sk, m0, g.M, k0 + kBK, kend, tid, g.ones_row);
       fetch_tile<BKC>(vb, g.B, b_srow, b_sk, n0, g.N, k0 + kBK, kend, tid, -1);
     }
-    const T* ap = As + (wm * 32 + li) * PITCH;
-    const T* bp = Bs + (wn * 32 + li) * PITCH;
+    const T* ap = As[buf] + (wm * 32 + li) * PITCH;
+    const T* bp = Bs[buf] + (wn * 32 + li) * PITCH;
     if constexpr (std::is_same<P, PrecF32>::value) {
 #pragma unroll
       for (int q = 0; q < kBK / 8; ++q) {
@@ -160,7 +165,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         acc = P::template mfma<false>(av, bv, acc);
       }
     }
-    __syncthreads();
   }
 
   // C/D map of the 32x32 tile: col = lane&31, row = (i&3) + 8(i>>2) + 4(lane>>5)

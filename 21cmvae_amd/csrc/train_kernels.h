@@ -27,6 +27,16 @@ __global__ void gather_vec_kernel(float* __restrict__ dst, const float* __restri
   if (i < n) dst[i] = src[idx ? (long long)idx[first + i] : first + i];
 }
 
+// dst[r][c] (pitch ldd) = src[r][c] (pitch lds_): row-padded copy of a kernel matrix
+__global__ void repitch_kernel(float* __restrict__ dst, long long ldd, const float* __restrict__ src, long long lds_,
+                               int rows, int cols) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * cols) return;
+  const long long r = i / cols;
+  const int c = (int)(i % cols);
+  dst[r * ldd + c] = src[r * lds_ + c];
+}
+
 // K2: loss_i = w_i sum_j (p - y)^2 (relative_mse_loss, emulator.py:68-81, with
 // w_i = 1/(D amp_i^2); plain MSE w_i = 1/D) and dL/dp = scale * w_i * (p - y),
 // scale = 2 / B_global ([K]: batch loss = mean of per-sample losses).
@@ -119,6 +129,90 @@ __global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
       m[i] = mi; v[i] = vi;
       w[i] = w[i] - (mi * alpha) / (sqrtf(vi) + eps);
     }
+  }
+}
+
+// ---- kernels of the NT training path (gemm_nt.h) ------------------------------------
+// K5': one wave per batch row: x[idx] -> H0 row and H0^T column, y[idx] -> Y row, w[idx]
+__global__ void gather_batch_kernel(const float* __restrict__ x, int din, float* __restrict__ h0, long long ldh,
+                                    float* __restrict__ h0t, long long ldt, const float* __restrict__ y, int dout,
+                                    float* __restrict__ yb, long long ldy, const float* __restrict__ w,
+                                    float* __restrict__ wb, const int* __restrict__ idx, long long first, int n,
+                                    long long ldx_src, long long ldy_src) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const long long s = idx ? (long long)idx[first + row] : first + row;
+  const float* xs = x + s * ldx_src;
+  for (int j = lane; j < din; j += 64) {
+    const float v = xs[j];
+    h0[(long long)row * ldh + j] = v;
+    h0t[(long long)j * ldt + row] = v;
+  }
+  if (y) {
+    const float* ys = y + s * ldy_src;
+    for (int j = lane; j < dout; j += 64) yb[(long long)row * ldy + j] = ys[j];
+  }
+  if (lane == 0 && w) wb[row] = w[s];
+}
+
+// K2': like loss_grad_kernel, also writes the transposed gradient dZ^T (dout x batch)
+__global__ void loss_grad_t_kernel(const float* __restrict__ p, long long ldp, const float* __restrict__ y,
+                                   long long ldy, const float* __restrict__ w, float* __restrict__ dz,
+                                   long long lddz, float* __restrict__ dzt, long long ldt,
+                                   float* __restrict__ rowloss, int n, int d, float scale) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float wi = w[row];
+  const float gs = scale * wi;
+  const float* pr = p + (long long)row * ldp;
+  const float* yr = y + (long long)row * ldy;
+  float s = 0.f;
+  for (int j = lane; j < d; j += 64) {
+    const float df = pr[j] - yr[j];
+    s += df * df;
+    const float gr = gs * df;
+    dz[(long long)row * lddz + j] = gr;
+    dzt[(long long)j * ldt + row] = gr;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) rowloss[row] = wi * s;
+}
+
+// K4': Adam over the flat arena + refresh of the two GEMM-friendly weight copies:
+// W^T (rows = outputs, padded) for the forward, row-padded W for the backward.
+struct AdamLayer { long long w_off, wt_off, wp_off; int K, N; long long ldwt, ldwp; };
+struct AdamArgs {
+  float *w, *m, *v;
+  const float* g;
+  float *wt, *wp;
+  long long n;
+  float alpha, omb1, omb2, eps;
+  int do_adam, L;
+  AdamLayer lt[16];
+};
+__global__ void adam_repack_kernel(const AdamArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  float wi = a.w[i];
+  if (a.do_adam) {
+    const float gi = a.g[i];
+    const float mi = a.m[i] + (gi - a.m[i]) * a.omb1;
+    const float vi = a.v[i] + (gi * gi - a.v[i]) * a.omb2;
+    a.m[i] = mi; a.v[i] = vi;
+    wi = wi - (mi * a.alpha) / (sqrtf(vi) + a.eps);
+    a.w[i] = wi;
+  }
+  int l = 0;
+  while (l + 1 < a.L && i >= a.lt[l + 1].w_off) ++l;
+  const AdamLayer L = a.lt[l];
+  const long long r = i - L.w_off;
+  if (r < (long long)L.K * L.N) {  // a kernel element (biases have no copies)
+    const int k = (int)(r / L.N), n = (int)(r % L.N);
+    a.wt[L.wt_off + (long long)n * L.ldwt + k] = wi;
+    a.wp[L.wp_off + (long long)k * L.ldwp + n] = wi;
   }
 }
 

@@ -21,6 +21,7 @@
 #include "archs.h"
 #include "fused_fwd.h"
 #include "gemm.h"
+#include "gemm_nt.h"
 #include "train_kernels.h"
 
 using namespace v21;
@@ -225,8 +226,13 @@ struct v21_mlp {
   float *d_xs = nullptr, *d_ys = nullptr;
   long long stage_rows = 0;
   int maxdim = 0;
+  // copy of the kernels with rows padded to 16 bytes (backward GEMM operand)
+  float* d_wpad = nullptr;
+  std::vector<long long> wpad_off;
+  bool wpad_ok = false;
 };
 
+static inline long long ldp(int d) { return (d + 3) & ~3; }  // row pitch of internal buffers: 16-byte rows
 static int fpi_of(int prec) { return prec == V21_PREC_F32 ? 8 : 16; }
 static void stream_geometry(const v21_mlp* m, int prec, int* total, int* padded) {
   int f = 0;
@@ -276,6 +282,7 @@ extern "C" int v21_mlp_destroy(v21_mlp* m) {
   hipFree(m->d_w);
   for (int i = 0; i < 3; ++i) if (m->d_stream[i]) hipFree(m->d_stream[i]);
   if (m->d_mean) hipFree(m->d_mean);
+  if (m->d_wpad) hipFree(m->d_wpad);
   for (int i = 0; i < 2; ++i) if (m->d_act[i]) hipFree(m->d_act[i]);
   if (m->d_xs) hipFree(m->d_xs);
   if (m->d_ys) hipFree(m->d_ys);
@@ -287,7 +294,7 @@ extern "C" int v21_mlp_num_params(const v21_mlp* m, size_t* n) {
   *n = m->nparams;
   return V21_OK;
 }
-static void invalidate_streams(v21_mlp* m) { m->stream_ok[0] = m->stream_ok[1] = m->stream_ok[2] = false; }
+static void invalidate_streams(v21_mlp* m) { m->stream_ok[0] = m->stream_ok[1] = m->stream_ok[2] = false; m->wpad_ok = false; }
 
 extern "C" int v21_mlp_set_weights(v21_mlp* m, const float* flat, size_t n) {
   if (!m || !flat) return fail(V21_ERR_ARG, "null argument");
@@ -362,6 +369,25 @@ static int ensure_stream(v21_mlp* m, int prec) {
   hipLaunchKernelGGL(pack_stream_kernel, dim3((padded + 3) / 4), dim3(256), 0, m->ctx->stream, pa);
   HIPCHK(hipGetLastError());
   m->stream_ok[prec] = true;
+  return V21_OK;
+}
+
+static int ensure_wpad(v21_mlp* m) {
+  if (m->wpad_ok) return V21_OK;
+  if (!m->d_wpad) {
+    long long o = 0;
+    for (int l = 0; l < m->L; ++l) { m->wpad_off.push_back(o); o += (long long)m->dims[l] * ldp(m->dims[l + 1]); }
+    HIPCHK(hipMalloc((void**)&m->d_wpad, (size_t)(o + 4) * sizeof(float)));
+    HIPCHK(hipMemsetAsync(m->d_wpad, 0, (size_t)(o + 4) * sizeof(float), m->ctx->stream));
+  }
+  for (int l = 1; l < m->L; ++l) {  // layer 0 never needs dX
+    const int K = m->dims[l], N = m->dims[l + 1];
+    const long long tot = (long long)K * N;
+    hipLaunchKernelGGL(repitch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, m->ctx->stream,
+                       m->d_wpad + m->wpad_off[l], ldp(N), (const float*)(m->d_w + m->w_off[l]), (long long)N, K, N);
+    HIPCHK(hipGetLastError());
+  }
+  m->wpad_ok = true;
   return V21_OK;
 }
 
@@ -548,8 +574,16 @@ extern "C" int v21_comm_allreduce_f32(v21_ctx* c, float* d_buf, size_t n) {
 }
 
 // ---------------------------------------------------------------------------------
-// trainer
+// trainer (NT path: gemm_nt.h).  Every contraction of a step reads operands whose
+// contraction index is contiguous; the producers write the transposed copies.
+//   h[l]   (batch x p16(dims[l]))      activations, row-major          (forward A operand, ReLU mask)
+//   ht[l]  ((dims[l]+1) x Bp)          activations transposed + a row of ones (weight-gradient A operand)
+//   dz[l]  (batch x p16(dims[l]))      gradient w.r.t. pre-activation of layer l-1's output (backward A operand)
+//   dzt[l] (dims[l] x Bp)              its transpose                    (weight-gradient B operand)
+//   wt[l]  (N x p16(K)) = W^T          forward B operand;   wp[l] (K x p16(N)) = row-padded W: backward B operand
 // ---------------------------------------------------------------------------------
+static inline long long p16(int d) { return (d + 15) & ~15; }
+
 struct v21_trainer {
   v21_mlp* mlp = nullptr;
   v21_ctx* ctx = nullptr;
@@ -565,41 +599,69 @@ struct v21_trainer {
   bool y_is_x[2] = {false, false};
   int* d_perm = nullptr;
   long long perm_cap = 0;
-  std::vector<float*> d_h;  // L+1 activation buffers (h[0] = batch input)
+  long long Bp = 0;  // row pitch of the transposed buffers (batch padded to 32, + slack)
+  std::vector<float*> d_h, d_ht, d_dz, d_dzt;
+  float *d_wt = nullptr, *d_wp = nullptr;
+  std::vector<long long> wt_off, wp_off;
+  bool copies_ok = false;
   float* d_yb = nullptr;
   float* d_wb = nullptr;
-  float* d_dz[2] = {nullptr, nullptr};
   float* d_rowloss = nullptr;
   float* d_steploss = nullptr;
   long long steploss_cap = 0;
   float* d_evalsum = nullptr;
-  float* d_slab = nullptr;  // split-K partial gradients: kMaxSlices x (P + 4)
+  float* d_slab = nullptr;  // split-K partial gradients: max_slices x (P + 4)
   int max_slices = 1;
 };
+
+static int zalloc(float** p, size_t nfloat, hipStream_t st) {
+  HIPCHK(hipMalloc((void**)p, nfloat * sizeof(float)));
+  HIPCHK(hipMemsetAsync(*p, 0, nfloat * sizeof(float), st));
+  return V21_OK;
+}
 
 extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_trainer** out) {
   if (!m || !out) return fail(V21_ERR_ARG, "null argument");
   if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
   if (max_batch < 1 || max_batch > (1 << 20)) return fail(V21_ERR_ARG, "max_batch %d out of range", max_batch);
   CHK(use(m->ctx));
+  hipStream_t st = m->ctx->stream;
   v21_trainer* t = new v21_trainer();
   t->mlp = m; t->ctx = m->ctx; t->prec = precision; t->max_batch = max_batch; t->P = m->nparams;
-  const size_t ab = (t->P + 4) * sizeof(float);
-  HIPCHK(hipMalloc((void**)&t->d_g, ab));
-  HIPCHK(hipMalloc((void**)&t->d_m, ab));
-  HIPCHK(hipMalloc((void**)&t->d_v, ab));
-  HIPCHK(hipMemsetAsync(t->d_g, 0, ab, t->ctx->stream));
-  HIPCHK(hipMemsetAsync(t->d_m, 0, ab, t->ctx->stream));
-  HIPCHK(hipMemsetAsync(t->d_v, 0, ab, t->ctx->stream));
-  t->d_h.resize(m->L + 1, nullptr);
-  for (int l = 0; l <= m->L; ++l) HIPCHK(hipMalloc((void**)&t->d_h[l], (size_t)max_batch * m->dims[l] * sizeof(float)));
-  HIPCHK(hipMalloc((void**)&t->d_yb, (size_t)max_batch * m->dims[m->L] * sizeof(float)));
-  HIPCHK(hipMalloc((void**)&t->d_wb, (size_t)max_batch * sizeof(float)));
-  for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc((void**)&t->d_dz[i], (size_t)max_batch * m->maxdim * sizeof(float)));
-  HIPCHK(hipMalloc((void**)&t->d_rowloss, (size_t)max_batch * sizeof(float)));
-  HIPCHK(hipMalloc((void**)&t->d_evalsum, 16));
-  t->max_slices = std::max(1, std::min(16, (max_batch + 255) / 256));
-  if (t->max_slices > 1) HIPCHK(hipMalloc((void**)&t->d_slab, (size_t)t->max_slices * (t->P + 4) * sizeof(float)));
+  const int L = m->L;
+  CHK(zalloc(&t->d_g, t->P + 4, st));
+  CHK(zalloc(&t->d_m, t->P + 4, st));
+  CHK(zalloc(&t->d_v, t->P + 4, st));
+  t->Bp = ((long long)max_batch + 31) / 32 * 32 + 32;
+  t->d_h.assign(L + 1, nullptr); t->d_ht.assign(L + 1, nullptr);
+  t->d_dz.assign(L + 1, nullptr); t->d_dzt.assign(L + 1, nullptr);
+  std::vector<float> ones((size_t)t->Bp, 1.0f);
+  for (int l = 0; l <= L; ++l) {
+    CHK(zalloc(&t->d_h[l], (size_t)(max_batch + 32) * p16(m->dims[l]), st));
+    if (l < L) {  // the output activation is never a weight-gradient operand
+      CHK(zalloc(&t->d_ht[l], (size_t)(m->dims[l] + 1 + 32) * t->Bp, st));
+      HIPCHK(hipMemcpyAsync(t->d_ht[l] + (size_t)m->dims[l] * t->Bp, ones.data(), (size_t)t->Bp * sizeof(float),
+                            hipMemcpyHostToDevice, st));  // the row of ones -> bias gradient
+    }
+    if (l >= 1) {
+      CHK(zalloc(&t->d_dz[l], (size_t)(max_batch + 32) * p16(m->dims[l]), st));
+      CHK(zalloc(&t->d_dzt[l], (size_t)(m->dims[l] + 32) * t->Bp, st));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(st));  // `ones` is a host temporary
+  long long ot = 0, op = 0;
+  for (int l = 0; l < L; ++l) {
+    t->wt_off.push_back(ot); ot += (long long)(m->dims[l + 1] + 32) * p16(m->dims[l]);
+    t->wp_off.push_back(op); op += (long long)(m->dims[l] + 32) * p16(m->dims[l + 1]);
+  }
+  CHK(zalloc(&t->d_wt, (size_t)ot + 64, st));
+  CHK(zalloc(&t->d_wp, (size_t)op + 64, st));
+  CHK(zalloc(&t->d_yb, (size_t)(max_batch + 32) * p16(m->dims[L]), st));
+  CHK(zalloc(&t->d_wb, (size_t)max_batch + 32, st));
+  CHK(zalloc(&t->d_rowloss, (size_t)max_batch + 32, st));
+  CHK(zalloc(&t->d_evalsum, 4, st));
+  t->max_slices = std::max(1, (max_batch + kNtMaxKPerWg - 1) / kNtMaxKPerWg);
+  CHK(zalloc(&t->d_slab, (size_t)t->max_slices * (t->P + 4), st));
   *out = t;
   return V21_OK;
 }
@@ -612,10 +674,11 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
     if (t->d_x[i]) hipFree(t->d_x[i]);
     if (t->d_y[i] && !t->y_is_x[i]) hipFree(t->d_y[i]);
     if (t->d_rw[i]) hipFree(t->d_rw[i]);
-    hipFree(t->d_dz[i]);
   }
   if (t->d_perm) hipFree(t->d_perm);
-  for (float* p : t->d_h) hipFree(p);
+  for (auto* v : {&t->d_h, &t->d_ht, &t->d_dz, &t->d_dzt})
+    for (float* p : *v) if (p) hipFree(p);
+  hipFree(t->d_wt); hipFree(t->d_wp);
   hipFree(t->d_yb); hipFree(t->d_wb); hipFree(t->d_rowloss); hipFree(t->d_evalsum);
   if (t->d_steploss) hipFree(t->d_steploss);
   if (t->d_slab) hipFree(t->d_slab);
@@ -668,67 +731,115 @@ static float adam_alpha(const v21_adam& a, long long t) {
   return a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
 }
 
-// forward through the stack on a device batch; h0 = input rows (ld = dims[0])
-static int trainer_forward(v21_trainer* t, const float* h0, int rows) {
+static int launch_nt(int prec, NtGroup& grp, hipStream_t st) {
+  int blocks = 0;
+  for (int i = 0; i < grp.count; ++i) {
+    NtArgs& g = grp.p[i];
+    g.nx = (g.N + 31) / 32; g.ny = (g.M + 31) / 32;
+    if (g.nz < 1) g.nz = 1;
+    if (g.nz == 1) { g.k_chunk = g.K > 0 ? g.K : 1; g.slab_stride = 0; }
+    if (g.k_chunk > kNtMaxKPerWg) return fail(V21_ERR_UNSUPPORTED, "contraction range %d > %d per workgroup", g.k_chunk, kNtMaxKPerWg);
+    blocks += g.nx * g.ny * g.nz;
+  }
+  if (blocks <= 0) return V21_OK;
+  switch (prec) {
+    case V21_PREC_F32: hipLaunchKernelGGL(gemm_nt_kernel<PrecF32>, dim3(blocks), dim3(256), 0, st, grp); break;
+    case V21_PREC_F16: hipLaunchKernelGGL(gemm_nt_kernel<PrecF16>, dim3(blocks), dim3(256), 0, st, grp); break;
+    default: hipLaunchKernelGGL(gemm_nt_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, st, grp); break;
+  }
+  HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+
+// Adam (do_adam) and/or refresh of the W^T / padded-W copies from the arena
+static int adam_and_copies(v21_trainer* t, bool do_adam, float alpha) {
   v21_mlp* m = t->mlp;
-  const float* in = h0;
+  AdamArgs a{};
+  a.w = m->d_w; a.m = t->d_m; a.v = t->d_v; a.g = t->d_g; a.wt = t->d_wt; a.wp = t->d_wp;
+  a.n = (long long)t->P; a.alpha = alpha; a.omb1 = 1.0f - t->adam.beta1; a.omb2 = 1.0f - t->adam.beta2;
+  a.eps = t->adam.eps; a.do_adam = do_adam ? 1 : 0; a.L = m->L;
   for (int l = 0; l < m->L; ++l) {
-    CHK(dense_forward(m, l, in, m->dims[l], t->d_h[l + 1], m->dims[l + 1], rows, t->prec, t->ctx->stream));
-    in = t->d_h[l + 1];
+    AdamLayer& al = a.lt[l];
+    al.w_off = m->w_off[l]; al.wt_off = t->wt_off[l]; al.wp_off = t->wp_off[l];
+    al.K = m->dims[l]; al.N = m->dims[l + 1]; al.ldwt = p16(al.K); al.ldwp = p16(al.N);
+  }
+  hipLaunchKernelGGL(adam_repack_kernel, dim3((unsigned)((t->P + 255) / 256)), dim3(256), 0, t->ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  t->copies_ok = true;
+  return V21_OK;
+}
+static int ensure_copies(v21_trainer* t) {
+  // the arena may have been rewritten behind our back (set_weights): wpad_ok doubles as the dirty flag
+  if (t->copies_ok && t->mlp->wpad_ok) return V21_OK;
+  CHK(adam_and_copies(t, false, 0.f));
+  t->mlp->wpad_ok = true;
+  return V21_OK;
+}
+
+// forward through the stack; h[0] / ht[0] hold the batch
+static int trainer_forward(v21_trainer* t, int rows, bool want_t) {
+  v21_mlp* m = t->mlp;
+  for (int l = 0; l < m->L; ++l) {
+    NtGroup grp{};
+    grp.count = 1;
+    NtArgs& g = grp.p[0];
+    g.A = t->d_h[l]; g.lda = p16(m->dims[l]);
+    g.B = t->d_wt + t->wt_off[l]; g.ldb = p16(m->dims[l]);
+    g.C = t->d_h[l + 1]; g.ldc = p16(m->dims[l + 1]);
+    g.CT = (want_t && l + 1 < m->L) ? t->d_ht[l + 1] : nullptr; g.ldct = t->Bp;
+    g.M = rows; g.N = m->dims[l + 1]; g.K = m->dims[l];
+    g.bias = m->d_w + m->b_off[l];
+    g.ep = m->act[l] == V21_ACT_RELU ? NT_FWD_RELU : NT_FWD;
+    g.nz = 1;
+    CHK(launch_nt(t->prec, grp, t->ctx->stream));
   }
   return V21_OK;
 }
 
-// one optimizer step on a device-resident batch of `rows` local rows out of a
-// global batch of `brows`; the batch loss numerator lands in loss_out[0] (device).
-static int trainer_step(v21_trainer* t, const float* h0, const float* yb, const float* wb, int rows, int brows,
-                        float* loss_out) {
+// one optimizer step on the batch already gathered into h[0]/ht[0], yb, wb
+static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out) {
   v21_mlp* m = t->mlp;
   hipStream_t st = t->ctx->stream;
   const int L = m->L, dout = m->dims[L];
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
-    CHK(trainer_forward(t, h0, rows));
+    CHK(ensure_copies(t));
+    CHK(trainer_forward(t, rows, true));
     const int wpb = 4;  // waves (rows) per block
-    hipLaunchKernelGGL(loss_grad_kernel<true>, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, st, t->d_h[L],
-                       (long long)dout, yb, (long long)dout, wb, t->d_dz[0], (long long)dout, t->d_rowloss, rows, dout,
+    hipLaunchKernelGGL(loss_grad_t_kernel, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, st, t->d_h[L], p16(dout), yb,
+                       ldy, t->d_wb, t->d_dz[L], p16(dout), t->d_dzt[L], t->Bp, t->d_rowloss, rows, dout,
                        2.0f / (float)brows);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_g + t->P, 0);
     HIPCHK(hipGetLastError());
-    // the weight-gradient contractions run over the batch: split it into slices of
-    // >= 256 rows, one slab per slice, summed afterwards in a fixed order
-    int nslice = std::min(t->max_slices, (rows + 255) / 256);
-    int k_chunk = ((rows + nslice - 1) / nslice + kBK - 1) / kBK * kBK;
+    // weight gradients contract over the batch: slices of <= kNtMaxKPerWg rows -> slabs
+    int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
+    const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
     nslice = (rows + k_chunk - 1) / k_chunk;
     const long long slab_stride = (long long)t->P + 4;
-    int cur = 0;
     for (int l = L - 1; l >= 0; --l) {
-      const float* hin = l == 0 ? h0 : t->d_h[l];
       const int K = m->dims[l], N = m->dims[l + 1];
-      GemmArgs g{};  // [dW; db] = [H^T; 1^T] dZ
-      g.A = hin; g.sa_m = 1; g.sa_k = K;
-      g.B = t->d_dz[cur]; g.sb_k = N; g.sb_n = 1;
+      NtGroup grp{};
+      NtArgs& g = grp.p[0];  // [dW; db] = [H^T; 1^T] dZ
+      g.A = t->d_ht[l]; g.lda = t->Bp;
+      g.B = t->d_dzt[l + 1]; g.ldb = t->Bp;
       g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = N;
       g.M = K + 1; g.N = N; g.K = rows;
-      g.ones_row = K; g.alpha = 1.f;
-      g.k_chunk = k_chunk; g.slab_stride = slab_stride;
-      CHK(launch_gemm_prec<EP_PLAIN>(t->prec, g, st, nslice));
-      if (l > 0) {  // dH = dZ W^T, masked by the ReLU of the layer below
-        GemmArgs d{};
-        d.A = t->d_dz[cur]; d.sa_m = N; d.sa_k = 1;
-        d.B = m->d_w + m->w_off[l]; d.sb_k = 1; d.sb_n = N;
-        d.C = t->d_dz[cur ^ 1]; d.ldc = K;
+      g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
+      grp.count = 1;
+      if (l > 0) {  // dH = dZ W^T, masked by the ReLU of the layer below -> dz[l], dzt[l]
+        NtArgs& d = grp.p[1];
+        d.A = t->d_dz[l + 1]; d.lda = p16(N);
+        d.B = t->d_wp + t->wp_off[l]; d.ldb = p16(N);
+        d.C = t->d_dz[l]; d.ldc = p16(K);
+        d.CT = t->d_dzt[l]; d.ldct = t->Bp;
         d.M = rows; d.N = K; d.K = N;
-        d.ones_row = -1; d.alpha = 1.f;
-        if (m->act[l - 1] == V21_ACT_RELU) {
-          d.mask = t->d_h[l]; d.ldmask = K;
-          CHK(launch_gemm_prec<EP_MASK>(t->prec, d, st));
-        } else {
-          CHK(launch_gemm_prec<EP_PLAIN>(t->prec, d, st));
-        }
-        cur ^= 1;
+        d.mask = t->d_h[l]; d.ldmask = p16(K);
+        d.ep = m->act[l - 1] == V21_ACT_RELU ? NT_DX_MASK : NT_DX;
+        d.nz = 1;
+        grp.count = 2;
       }
+      CHK(launch_nt(t->prec, grp, st));
     }
     if (nslice > 1) {
       const long long n4 = ((long long)t->P + 3) / 4;
@@ -741,32 +852,21 @@ static int trainer_step(v21_trainer* t, const float* h0, const float* yb, const 
   }
   CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
   t->iter += 1;
-  const float alpha = adam_alpha(t->adam, t->iter);
-  const long long n4 = ((long long)t->P + 3) / 4;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, m->d_w, t->d_g, t->d_m, t->d_v,
-                     (long long)t->P, alpha, 1.0f - t->adam.beta1, 1.0f - t->adam.beta2, t->adam.eps);
-  HIPCHK(hipGetLastError());
+  CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter)));
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
   invalidate_streams(m);
+  m->wpad_ok = true;  // ... but our own copies were just refreshed
   return V21_OK;
 }
 
-static int gather_batch(v21_trainer* t, int which, const int* d_idx, long long first, int rows, bool want_y) {
+static int gather_batch(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy_src,
+                        const float* rw, const int* d_idx, long long first, int rows) {
   v21_mlp* m = t->mlp;
-  hipStream_t st = t->ctx->stream;
   const int din = m->dims[0], dout = m->dims[m->L];
   const int wpb = 4;
-  dim3 grid((rows + wpb - 1) / wpb), block(64 * wpb);
-  hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, st, t->d_h[0], (const float*)t->d_x[which], d_idx, first, rows,
-                     din, (long long)din, (long long)din);
-  HIPCHK(hipGetLastError());
-  if (want_y && !t->y_is_x[which]) {
-    hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, st, t->d_yb, (const float*)t->d_y[which], d_idx, first, rows,
-                       dout, (long long)dout, (long long)dout);
-    HIPCHK(hipGetLastError());
-  }
-  hipLaunchKernelGGL(gather_vec_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, t->d_wb, (const float*)t->d_rw[which],
-                     d_idx, first, rows);
+  hipLaunchKernelGGL(gather_batch_kernel, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, t->ctx->stream, x, din,
+                     t->d_h[0], p16(din), t->d_ht[0], t->Bp, y, dout, t->d_yb, p16(dout), rw, t->d_wb, d_idx, first,
+                     rows, ldx, ldy_src);
   HIPCHK(hipGetLastError());
   return V21_OK;
 }
@@ -776,6 +876,7 @@ extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int ba
   if (t->n[0] < 1) return fail(V21_ERR_STATE, "no training data set");
   CHK(use(t->ctx));
   hipStream_t st = t->ctx->stream;
+  v21_mlp* m = t->mlp;
   const long long n = t->n[0];
   const int R = t->ctx->nranks, rk = t->ctx->rank;
   if (batch < 1) return fail(V21_ERR_ARG, "batch must be >= 1");
@@ -796,14 +897,16 @@ extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int ba
     HIPCHK(hipMalloc((void**)&t->d_steploss, (size_t)steps * sizeof(float)));
     t->steploss_cap = steps;
   }
+  const int din = m->dims[0], dout = m->dims[m->L];
   for (long long s = 0; s < steps; ++s) {
     const long long first = s * batch;
     const int brows = (int)std::min<long long>(batch, n - first);  // rows of the global batch
     const long long lo = first + (long long)brows * rk / R, hi = first + (long long)brows * (rk + 1) / R;
     const int rows = (int)(hi - lo);
-    if (rows > 0) CHK(gather_batch(t, 0, d_idx, lo, rows, true));
+    if (rows > 0)
+      CHK(gather_batch(t, t->d_x[0], din, t->y_is_x[0] ? nullptr : t->d_y[0], dout, t->d_rw[0], d_idx, lo, rows));
     const float* yb = t->y_is_x[0] ? t->d_h[0] : t->d_yb;
-    CHK(trainer_step(t, t->d_h[0], yb, t->d_wb, rows, brows, t->d_steploss + s));
+    CHK(trainer_step(t, yb, t->y_is_x[0] ? p16(din) : p16(dout), rows, brows, t->d_steploss + s));
   }
   std::vector<float> h(steps);
   HIPCHK(hipMemcpyAsync(h.data(), t->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -821,18 +924,21 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
   hipStream_t st = t->ctx->stream;
   v21_mlp* m = t->mlp;
   const long long n = t->n[which];
-  const int dout = m->dims[m->L];
+  const int din = m->dims[0], dout = m->dims[m->L];
   if (batch < 1) return fail(V21_ERR_ARG, "batch must be >= 1");
   const int b = std::min(batch, t->max_batch);
+  CHK(ensure_copies(t));
   HIPCHK(hipMemsetAsync(t->d_evalsum, 0, 16, st));
   for (long long first = 0; first < n; first += b) {
     const int rows = (int)std::min<long long>(b, n - first);
-    CHK(gather_batch(t, which, nullptr, first, rows, true));
-    CHK(trainer_forward(t, t->d_h[0], rows));
+    CHK(gather_batch(t, t->d_x[which], din, t->y_is_x[which] ? nullptr : t->d_y[which], dout, t->d_rw[which], nullptr,
+                     first, rows));
+    CHK(trainer_forward(t, rows, false));
     const float* yb = t->y_is_x[which] ? t->d_h[0] : t->d_yb;
     const int wpb = 4;
     hipLaunchKernelGGL(loss_grad_kernel<false>, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, st, t->d_h[m->L],
-                       (long long)dout, yb, (long long)dout, t->d_wb, (float*)nullptr, 0ll, t->d_rowloss, rows, dout, 0.f);
+                       p16(dout), yb, t->y_is_x[which] ? p16(din) : p16(dout), t->d_wb, (float*)nullptr, 0ll,
+                       t->d_rowloss, rows, dout, 0.f);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_evalsum, 1);
     HIPCHK(hipGetLastError());
@@ -848,8 +954,14 @@ extern "C" int v21_trainer_step_dev(v21_trainer* t, const float* d_x, const floa
                                     int global_rows) {
   if (!t || !d_x || !d_rw) return fail(V21_ERR_ARG, "null argument");
   if (n_rows < 0 || global_rows < std::max(n_rows, 1)) return fail(V21_ERR_ARG, "bad row counts");
+  if (n_rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", n_rows, t->max_batch);
   CHK(use(t->ctx));
-  return trainer_step(t, d_x, d_y ? d_y : d_x, d_rw, n_rows, global_rows, nullptr);
+  v21_mlp* m = t->mlp;
+  const int din = m->dims[0], dout = m->dims[m->L];
+  if (!d_y && din != dout) return fail(V21_ERR_ARG, "d_y == NULL (y = x) needs in_dim == out_dim");
+  if (n_rows > 0) CHK(gather_batch(t, d_x, din, d_y, dout, d_rw, nullptr, 0, n_rows));
+  const float* yb = d_y ? t->d_yb : t->d_h[0];
+  return trainer_step(t, yb, d_y ? p16(dout) : p16(din), n_rows, global_rows, nullptr);
 }
 extern "C" int v21_trainer_last_step_loss(v21_trainer* t, double* loss) {
   if (!t || !loss) return fail(V21_ERR_ARG, "null argument");
