@@ -42,14 +42,14 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kFragBytes = 1024;  // one MFMA operand fragment: 64 lanes x 16 B
-constexpr int kBlkFrags = 24;     // fragments per ring block
-constexpr int kRing = 4;          // LDS ring slots
-constexpr int kWaves = 4;         // one wave per SIMD
-constexpr int kFusedLds = kRing * kBlkFrags * kFragBytes;  // 96 KiB
+constexpr int kWaves = 4;         // waves per workgroup
+// ring geometry comes from the precision/variant traits: P::BLK fragments per block,
+// P::RING slots; LDS per workgroup = RING * BLK KiB
+template <class P> constexpr int fused_lds() { return P::RING * P::BLK * kFragBytes; }
 #ifdef V21_FUSED_STAMP
-constexpr int kFusedLdsAlloc = kFusedLds + 16384;  // + stamp area (diagnostic build)
+template <class P> constexpr int fused_lds_alloc() { return fused_lds<P>() + 16384; }  // + stamp area
 #else
-constexpr int kFusedLdsAlloc = kFusedLds;
+template <class P> constexpr int fused_lds_alloc() { return fused_lds<P>(); }
 #endif
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>),
@@ -84,6 +84,8 @@ struct FusedArgs {
   int in_transform;
   v21_affine_in tin;
   unsigned long long* dbg;      // diagnostic builds only (V21_FUSED_STAMP): cycle stamps
+  unsigned* phase_ctr;          // x2 variants: per-CU arrival counters (2048 words) for de-phasing
+  int delay_sleeps;             // x2 variants: start delay of the second workgroup of a CU, in s_sleep 127 units
 };
 
 // ---- precision traits ------------------------------------------------------------
@@ -92,6 +94,7 @@ struct FusedArgs {
 // i % EPI of item (16/EPI)*nt + i / EPI of the next layer's operand, and element e of
 // item ku held by lane half h is feature  FPI*ku + 8*(e>>2) + 4*h + (e&3).
 struct PrecF16 {
+  static constexpr int BLK = 24, RING = 4, WPS = 1;  // 96 KiB ring, one wave per SIMD
   using frag = f16x8;
   using elem = _Float16;
   static constexpr int FPI = 16, EPI = 8, CT = 2;
@@ -107,6 +110,7 @@ struct PrecF16 {
   }
 };
 struct PrecBF16 {
+  static constexpr int BLK = 24, RING = 4, WPS = 1;  // 96 KiB ring, one wave per SIMD
   using frag = bf16x8;
   using elem = __bf16;
   static constexpr int FPI = 16, EPI = 8, CT = 2;
@@ -122,6 +126,7 @@ struct PrecBF16 {
 };
 // exact f32: v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain (no reduced precision)
 struct PrecF32 {
+  static constexpr int BLK = 24, RING = 4, WPS = 1;
   using frag = f32x4;
   using elem = float;
   static constexpr int FPI = 8, EPI = 4, CT = 1;
@@ -136,12 +141,19 @@ struct PrecF32 {
   }
 };
 
+// Variant "x2": one column tile per wave (128 signals per workgroup), <= 256 registers,
+// 80 KiB ring -> TWO workgroups per CU, i.e. two waves per SIMD that cover each other's
+// stalls (LDS latency, DMA issue, epilogue VALU, output-layer stores).
+struct PrecF16x2 : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
+struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
+
 // ---- compile-time geometry of (architecture, precision) ---------------------------
 // Arch::L layers, Arch::dims[L+1], Arch::act[L] (1 = ReLU).  The last layer is the
 // "output orientation" layer and must be linear.
 template <class Arch, class P> struct Geo {
   static constexpr int L = Arch::L;
   static constexpr int FPI = P::FPI;
+  static constexpr int BLK = P::BLK, RING = P::RING;
   static constexpr int IPT = 16 / P::EPI;  // operand items produced per 32-wide tile
   static constexpr int dim(int i) { return Arch::dims[i]; }
   static constexpr int act(int l) { return Arch::act[l]; }
@@ -155,11 +167,11 @@ template <class Arch, class P> struct Geo {
   }
   static constexpr int total() { return tile_base(L, 0); }
   static constexpr int padded() { return (total() + 3) / 4 * 4; }
-  static constexpr int n_blocks() { return (padded() + kBlkFrags - 1) / kBlkFrags; }
+  static constexpr int n_blocks() { return (padded() + BLK - 1) / BLK; }
   static constexpr int blk_glds(int b) {  // LDS-DMA instructions per wave in block b
     if (b < 0 || b >= n_blocks()) return 0;
-    const int rem = padded() - b * kBlkFrags;
-    return (rem < kBlkFrags ? rem : kBlkFrags) / kWaves;
+    const int rem = padded() - b * BLK;
+    return (rem < BLK ? rem : BLK) / kWaves;
   }
   static constexpr int ks_max() {
     int m = 0;
@@ -254,9 +266,9 @@ __device__ __forceinline__ void issue_block(const unsigned char* gstream, unsign
                                             int wave, int lane) {
   if constexpr (B >= 0 && B < G::n_blocks()) {
     constexpr int NG = G::blk_glds(B);
-    const unsigned char* g = gstream + (size_t)B * kBlkFrags * kFragBytes;  // wave-uniform
+    const unsigned char* g = gstream + (size_t)B * G::BLK * kFragBytes;  // wave-uniform
     const unsigned voff = wave * kFragBytes + lane * 16;
-    const unsigned s = lds_addr(smem) + (B % kRing) * kBlkFrags * kFragBytes + wave * kFragBytes;
+    const unsigned s = lds_addr(smem) + (B % G::RING) * G::BLK * kFragBytes + wave * kFragBytes;
     static_for<NG>([&](auto i) __attribute__((always_inline)) {
       constexpr int I = decltype(i)::value;
       glds16(g + I * kWaves * kFragBytes, voff, s + I * kWaves * kFragBytes);
@@ -274,9 +286,9 @@ __device__ __forceinline__ void issue_piece(const unsigned char* gstream, unsign
                                             int wave, int lane) {
   if constexpr (B >= 0 && B < G::n_blocks()) {
     if constexpr (I < G::blk_glds(B)) {
-      const unsigned char* g = gstream + (size_t)B * kBlkFrags * kFragBytes + I * kWaves * kFragBytes;
+      const unsigned char* g = gstream + (size_t)B * G::BLK * kFragBytes + I * kWaves * kFragBytes;
       const unsigned voff = wave * kFragBytes + lane * 16;
-      const unsigned s = lds_addr(smem) + (B % kRing) * kBlkFrags * kFragBytes + wave * kFragBytes +
+      const unsigned s = lds_addr(smem) + (B % G::RING) * G::BLK * kFragBytes + wave * kFragBytes +
                          I * kWaves * kFragBytes;
       glds16(g, voff, s);
     }
@@ -290,6 +302,7 @@ __device__ __forceinline__ void issue_piece(const unsigned char* gstream, unsign
 template <class G, int CT, int D, int S, bool SPREAD>
 __device__ __forceinline__ void ring_boundary(const unsigned char* gstream, unsigned char* smem,
                                               int wave, int lane, unsigned long long* g_dbg = nullptr) {
+  constexpr int kBlkFrags = G::BLK, kRing = G::RING;
   if constexpr (S % kBlkFrags == 0 && S < G::padded()) {
     constexpr int B = S / kBlkFrags;
     constexpr int last_issued = (B + kRing - 3 > kRing - 1) ? B + kRing - 3 : kRing - 1;
@@ -306,20 +319,20 @@ __device__ __forceinline__ void ring_boundary(const unsigned char* gstream, unsi
     constexpr int N = (GA + SA) > 63 ? 63 : (GA + SA);
 #ifdef V21_FUSED_STAMP
     { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-      ((unsigned long long*)(smem + kFusedLds))[wave * 512 + 2 * B] = t; }
+      ((unsigned long long*)(smem + G::RING * G::BLK * kFragBytes))[wave * 512 + 2 * B] = t; }
 #endif
     wait_vmcnt_barrier<N>();
 #ifdef V21_FUSED_STAMP
     { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-      ((unsigned long long*)(smem + kFusedLds))[wave * 512 + 2 * B + 1] = t; }
+      ((unsigned long long*)(smem + G::RING * G::BLK * kFragBytes))[wave * 512 + 2 * B + 1] = t; }
 #endif
     if constexpr (B >= 2 && !SPREAD) issue_block<G, B + kRing - 2>(gstream, smem, wave, lane);
   }
 }
 
-template <int F> __device__ __forceinline__ const unsigned char* frag_ptr(const unsigned char* smem, int lane) {
-  constexpr int B = F / kBlkFrags;
-  return smem + ((B % kRing) * kBlkFrags + (F % kBlkFrags)) * kFragBytes + lane * 16;
+template <class G, int F> __device__ __forceinline__ const unsigned char* frag_ptr(const unsigned char* smem, int lane) {
+  constexpr int B = F / G::BLK;
+  return smem + ((B % G::RING) * G::BLK + (F % G::BLK)) * kFragBytes + lane * 16;
 }
 
 // Hook for pinning operand words to a register class.  Pinning them to AGPRs through
@@ -329,9 +342,11 @@ template <int F> __device__ __forceinline__ const unsigned char* frag_ptr(const 
 __device__ __forceinline__ unsigned to_areg(unsigned v) { return v; }
 
 // ---- the kernel -------------------------------------------------------------------
-// grid.x = ceil(n_rows / (kWaves*CT*32)); block = 256 threads; dynamic LDS kFusedLds.
+// grid.x = ceil(n_rows / (kWaves*CT*32)); block = 256 threads; dynamic LDS fused_lds<P>().
 template <class Arch, class P, bool PIN>
-__global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
+__global__ void __launch_bounds__(256, P::WPS) fused_fwd(const FusedArgs a) {
+  constexpr int kBlkFrags = P::BLK, kRing = P::RING, kFusedLds = fused_lds<P>();
+  (void)kFusedLds;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = Geo<Arch, P>;
   using frag = typename P::frag;
@@ -358,6 +373,28 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
   const int r = lane & 31, h = lane >> 5;
   const long long wg_row0 = (long long)blockIdx.x * (kWaves * CT * 32);
   const long long row0 = wg_row0 + wave * (CT * 32);
+
+  // ---- de-phasing (two workgroups per CU): every workgroup reaches the store-heavy output
+  // layer at the same point of its own timeline, so if all start together the whole chip
+  // writes its 118 MB in one burst while the matrix pipes idle.  The second workgroup to
+  // arrive on a CU (per-CU arrival counter keyed by XCC/SE/SH/CU id; parity, so no reset is
+  // needed between launches) sleeps first: its hidden layers then overlap the first one's
+  // stores.  Placement only changes speed, never results.
+  if constexpr (P::WPS == 2) {
+    if (a.phase_ctr != nullptr && a.delay_sleeps > 0) {
+      if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+        const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu);
+        *(volatile unsigned*)smem = atomicAdd(a.phase_ctr + key, 1u) & 1u;
+      }
+      __syncthreads();
+      const unsigned late = *(volatile unsigned*)smem;
+      __syncthreads();
+      if (late)
+        for (int i = 0; i < a.delay_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
 
   // Operand registers of the two layers in flight, as 32-bit words (4 per item).
   unsigned bufA[CT][KSM][4], bufB[CT][KSM][4];
@@ -500,10 +537,10 @@ __global__ void __launch_bounds__(256, 1) fused_fwd(const FusedArgs a) {
       }
       constexpr Item it = G::item_at(S);
       if constexpr (it.ks >= 0) {
-        q[S % (D + 1)] = *(const frag*)frag_ptr<S>(smem, lane);
+        q[S % (D + 1)] = *(const frag*)frag_ptr<G, S>(smem, lane);
       } else {
         constexpr int GT = G::gtile(it.l, it.nt);
-        const unsigned char* aux = frag_ptr<S>(smem, 0);
+        const unsigned char* aux = frag_ptr<G, S>(smem, 0);
         if constexpr (it.l < L - 1) {
           // bias[32nt + rho(reg) + 4h]: the accumulator's initial value
           const f32x4* bp = (const f32x4*)(aux + h * 64);

@@ -19,14 +19,14 @@ static hipError_t launch_one(const FusedArgs& a, hipStream_t st) {
   auto kern = fused_fwd<A, P, PIN>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLdsAlloc);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_alloc<P>());
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   constexpr int rows = kWaves * P::CT * 32;
   const long long nwg = (a.n_rows + rows - 1) / rows;
   if (nwg <= 0) return hipSuccess;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), kFusedLdsAlloc, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), fused_lds_alloc<P>(), st, a);
   return hipGetLastError();
 }
 

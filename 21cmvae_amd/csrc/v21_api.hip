@@ -188,6 +188,11 @@ namespace v21 {
   hipError_t launch_fused_##a##_BF16(const FusedArgs&, int, hipStream_t);
 V21_ARCH_LIST(V21_DECL)
 #undef V21_DECL
+#define V21_DECL2(a)                                                       \
+  hipError_t launch_fused_##a##_F16x2(const FusedArgs&, int, hipStream_t); \
+  hipError_t launch_fused_##a##_BF16x2(const FusedArgs&, int, hipStream_t);
+V21_ARCH_LIST(V21_DECL2)
+#undef V21_DECL2
 }  // namespace v21
 
 typedef hipError_t (*fused_launcher)(const FusedArgs&, int, hipStream_t);
@@ -195,10 +200,12 @@ struct FusedEntry {
   int L;
   const int* dims;
   const int* act;
-  fused_launcher fn[3];
+  fused_launcher fn[3];    // one wave per SIMD, two column tiles per wave (f32: one)
+  fused_launcher fn_x2[3]; // two workgroups per CU, one column tile per wave (f16/bf16)
 };
-#define V21_ENTRY(a) \
-  {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_##a##_F32, launch_fused_##a##_F16, launch_fused_##a##_BF16}},
+#define V21_ENTRY(a)                                                                                          \
+  {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_##a##_F32, launch_fused_##a##_F16, launch_fused_##a##_BF16}, \
+   {nullptr, launch_fused_##a##_F16x2, launch_fused_##a##_BF16x2}},
 static const FusedEntry g_fused[] = {V21_ARCH_LIST(V21_ENTRY)};
 #undef V21_ENTRY
 
@@ -228,6 +235,7 @@ struct v21_mlp {
   int maxdim = 0;
   // copy of the kernels with rows padded to 16 bytes (backward GEMM operand)
   float* d_wpad = nullptr;
+  unsigned* d_phase = nullptr;  // per-CU arrival counters of the x2 fused variants
   std::vector<long long> wpad_off;
   bool wpad_ok = false;
 };
@@ -283,6 +291,7 @@ extern "C" int v21_mlp_destroy(v21_mlp* m) {
   for (int i = 0; i < 3; ++i) if (m->d_stream[i]) hipFree(m->d_stream[i]);
   if (m->d_mean) hipFree(m->d_mean);
   if (m->d_wpad) hipFree(m->d_wpad);
+  if (m->d_phase) hipFree(m->d_phase);
   for (int i = 0; i < 2; ++i) if (m->d_act[i]) hipFree(m->d_act[i]);
   if (m->d_xs) hipFree(m->d_xs);
   if (m->d_ys) hipFree(m->d_ys);
@@ -492,6 +501,18 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
   if (a.in_transform) a.tin = m->tin;
   a.dbg = (unsigned long long*)(getenv("V21_FUSED_DBG_PTR") ? strtoull(getenv("V21_FUSED_DBG_PTR"), nullptr, 0) : 0ull);
   static const int pin = getenv("V21_FUSED_PIN") ? atoi(getenv("V21_FUSED_PIN")) : 0;
+  static const int x2 = getenv("V21_FUSED_X2") ? atoi(getenv("V21_FUSED_X2")) : 1;
+  if (x2 && g_fused[m->fused_id].fn_x2[precision]) {  // default for f16/bf16: two 128-signal workgroups per CU
+    static const int delay = getenv("V21_FUSED_DELAY") ? atoi(getenv("V21_FUSED_DELAY")) : 0;
+    if (delay > 0 && !m->d_phase) {
+      HIPCHK(hipMalloc((void**)&m->d_phase, 2048 * sizeof(unsigned)));
+      HIPCHK(hipMemsetAsync(m->d_phase, 0, 2048 * sizeof(unsigned), m->ctx->stream));
+    }
+    a.phase_ctr = m->d_phase;
+    a.delay_sleeps = delay;
+    HIPCHK(g_fused[m->fused_id].fn_x2[precision](a, pin, m->ctx->stream));
+    return V21_OK;
+  }
   HIPCHK(g_fused[m->fused_id].fn[precision](a, pin, m->ctx->stream));
   return V21_OK;
 }

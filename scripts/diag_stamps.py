@@ -15,7 +15,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 x = rng.uniform(-1, 1, size=(B, 7)).astype(np.float32)
 d_x, d_y = ctx.malloc(x.nbytes), ctx.malloc(B * 451 * 4)
 ctx.h2d(d_x, x)
-rows_per_wg = 256 if prec != "f32" else 128
+rows_per_wg = 128 if (prec == "f32" or os.environ.get("V21_FUSED_X2") == "1") else 256
 nwg = B // rows_per_wg
 dbg = np.zeros((nwg * 4, 512), np.uint64)
 d_dbg = ctx.malloc(dbg.nbytes)
@@ -28,9 +28,14 @@ st.forward_dev(d_x, 7, B, d_y, 451, prec, 0)
 ctx.sync()
 ctx.d2h(dbg, d_dbg)
 t = dbg.astype(np.int64)
-nb = int(sys.argv[3]) if len(sys.argv) > 3 else 39
+nb = int(sys.argv[3]) if len(sys.argv) > 3 else (58 if os.environ.get("V21_FUSED_X2") == "1" else 39)
 start, end = t[:, 0], t[:, 127]
 print("precision", prec, "blocks", nb, "waves", t.shape[0])
+half = t.shape[0] // 2
+for nm, sl in (("WGs 0..255 (first on their CU)", slice(0, half)), ("WGs 256..511 (second)", slice(half, None))):
+    tt = t[sl]
+    print(nm, ": start %d..%d  end %d..%d (cycles rel. to global first start)" % (
+        (tt[:, 0] - t[:, 0].min()).min(), (tt[:, 0] - t[:, 0].min()).max(), (tt[:, 127] - t[:, 0].min()).min(), (tt[:, 127] - t[:, 0].min()).max()))
 print("wave lifetime cycles: mean %.0f min %d max %d" % ((end - start).mean(), (end - start).min(), (end - start).max()))
 print("first-start to last-end over the chip: %d cycles" % (end.max() - start.min()))
 wait = np.stack([t[:, 2 * b + 1] - t[:, 2 * b] for b in range(nb)], 1)
