@@ -220,6 +220,18 @@ def main():
                      "hbm_frac_of_8TBps": BYTES_PER_SIGNAL * B / kern_s / 1e9 / PEAK_HBM_GBS},
     }
 
+    # HBM traffic per launch of the headline kernel: PMC counters cannot be read from inside the timed
+    # process; they were collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) on
+    # this same command and are kept under profiles/ (hbm_bytes = 2*FETCH*1024 + WRITE*1024 on gfx950).
+    pmc = os.path.join(ROOT, "profiles", "r1_final", "pmc_fused_%s.json" % args.precision)
+    if os.path.exists(pmc) and B == BATCH:
+        try:
+            out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r1_final/pmc_fused_%s.json (rocprofv3 --pmc)" % args.precision
+            out["roofline"]["algorithmic_bytes"] = BYTES_PER_SIGNAL * B
+        except Exception:
+            pass
+
     if rank == 0 and not args.no_extras:
         modes = {}
         for prec in ("f32", "bf16", "f16"):
