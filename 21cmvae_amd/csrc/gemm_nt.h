@@ -37,6 +37,7 @@ struct NtArgs {
   long long slab_stride;
   int ep;                          // NT_* epilogue
   int nx, ny, nz;                  // tiles along n, m and contraction slices (set by the launcher)
+  int tile;                        // 32 or 64: workgroup tile edge (set by the launcher)
 };
 // up to two independent contractions per launch (the backward of one layer: dW and dX
 // both consume dZ of that layer); blocks [0, nx0*ny0*nz0) belong to the first
@@ -53,7 +54,10 @@ template <> struct NtTraits<PrecF32> { static constexpr int KSTEP = 8, MAXSTEPS 
 template <> struct NtTraits<PrecF16> { static constexpr int KSTEP = 16, MAXSTEPS = 8, REGS = 8; };
 template <> struct NtTraits<PrecBF16> { static constexpr int KSTEP = 16, MAXSTEPS = 8, REGS = 8; };
 
-template <class P>
+// T = MFMA tiles per side of the workgroup tile: T = 1 -> 32x32 (latency: small batches),
+// T = 2 -> 64x64 (twice the arithmetic intensity per loaded byte: large batches; the
+// contraction range of a wave is then walked in rounds of <= MAXSTEPS/2 k-steps).
+template <class P, int T>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const NtGroup grp) {
   using TR = NtTraits<P>;
   int bid = blockIdx.x;
@@ -63,13 +67,15 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const NtGroup grp) {
   const NtArgs& g = second ? grp.p[1] : grp.p[0];
   const int bx = bid % g.nx, by = (bid / g.nx) % g.ny, bz = bid / (g.nx * g.ny);
   const int EP = g.ep;
-  constexpr int KSTEP = TR::KSTEP, MAXSTEPS = TR::MAXSTEPS, REGS = TR::REGS;
-  __shared__ __attribute__((aligned(16))) float part[4][16][64];  // partial tiles of the 4 waves
+  constexpr int KSTEP = TR::KSTEP, REGS = TR::REGS;
+  constexpr int ROUND = TR::MAXSTEPS / (T * T > 1 ? 2 : 1);  // k-steps in flight per round
+  constexpr int HOFF = (REGS == 8 ? 8 : 4);
+  __shared__ __attribute__((aligned(16))) float part[4][T * T][16][64];  // partial tiles of the 4 waves
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = by * 32, n0 = bx * 32;
+  const int m0 = by * (32 * T), n0 = bx * (32 * T);
   const int kbeg = bz * g.k_chunk;
   const int kend = min(g.K, kbeg + g.k_chunk);
   // this wave's quarter, in whole k-steps
@@ -77,77 +83,113 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const NtGroup grp) {
   const int per = (nsteps + 3) / 4;
   const int s0 = wave * per, s1 = min(nsteps, s0 + per);
 
-  const int am = min(m0 + li, g.M - 1), bn = min(n0 + li, g.N - 1);  // clamp: edge rows are discarded
-  const float* ap = g.A + (long long)am * g.lda + kbeg + (REGS == 8 ? 8 : 4) * lh;
-  const float* bp = g.B + (long long)bn * g.ldb + kbeg + (REGS == 8 ? 8 : 4) * lh;
+  const float* ap[T];
+  const float* bp[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {  // clamp: edge rows are loaded twice and discarded at the store
+    ap[t] = g.A + (long long)min(m0 + 32 * t + li, g.M - 1) * g.lda + kbeg + HOFF * lh;
+    bp[t] = g.B + (long long)min(n0 + 32 * t + li, g.N - 1) * g.ldb + kbeg + HOFF * lh;
+  }
+  f32x16 acc[T][T];
+#pragma unroll
+  for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < T; ++tj)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ti][tj][i] = 0.f;
 
-  float va[MAXSTEPS][REGS], vb[MAXSTEPS][REGS];
-  // ---- issue every load of this wave's range (rows are padded: reads stay in bounds)
+  for (int r0 = s0; r0 < s1; r0 += ROUND) {
+    float va[ROUND][T][REGS], vb[ROUND][T][REGS];
+    // ---- issue every load of this round (rows are padded: reads stay in bounds)
 #pragma unroll
-  for (int s = 0; s < MAXSTEPS; ++s) {
-    if (s0 + s < s1) {
-      const int ko = (s0 + s) * KSTEP;
+    for (int s = 0; s < ROUND; ++s) {
+      if (r0 + s < s1) {
+        const int ko = (r0 + s) * KSTEP;
 #pragma unroll
-      for (int q = 0; q < REGS / 4; ++q) {
-        const float4 x = *reinterpret_cast<const float4*>(ap + ko + 4 * q);
-        const float4 y = *reinterpret_cast<const float4*>(bp + ko + 4 * q);
-        va[s][4 * q] = x.x; va[s][4 * q + 1] = x.y; va[s][4 * q + 2] = x.z; va[s][4 * q + 3] = x.w;
-        vb[s][4 * q] = y.x; vb[s][4 * q + 1] = y.y; vb[s][4 * q + 2] = y.z; vb[s][4 * q + 3] = y.w;
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int q = 0; q < REGS / 4; ++q) {
+            const float4 x = *reinterpret_cast<const float4*>(ap[t] + ko + 4 * q);
+            const float4 y = *reinterpret_cast<const float4*>(bp[t] + ko + 4 * q);
+            va[s][t][4 * q] = x.x; va[s][t][4 * q + 1] = x.y; va[s][t][4 * q + 2] = x.z; va[s][t][4 * q + 3] = x.w;
+            vb[s][t][4 * q] = y.x; vb[s][t][4 * q + 1] = y.y; vb[s][t][4 * q + 2] = y.z; vb[s][t][4 * q + 3] = y.w;
+          }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < ROUND; ++s) {
+      if (r0 + s < s1) {
+        // zero the elements past the end of the contraction range (padding may hold anything)
+        const int kk = kbeg + (r0 + s) * KSTEP + HOFF * lh;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int e = 0; e < REGS; ++e)
+            if (kk + e >= kend) { va[s][t][e] = 0.f; vb[s][t][e] = 0.f; }
+        if constexpr (REGS == 4) {
+#pragma unroll
+          for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < T; ++tj)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s][ti][e], vb[s][tj][e], acc[ti][tj], 0, 0, 0);
+        } else {
+          typename P::frag fa[T], fb[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              fa[t][e] = (typename P::elem)va[s][t][e];
+              fb[t][e] = (typename P::elem)vb[s][t][e];
+            }
+#pragma unroll
+          for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < T; ++tj) acc[ti][tj] = P::template mfma<false>(fa[ti], fb[tj], acc[ti][tj]);
+        }
       }
     }
   }
-  f32x16 acc;
+  // ---- meet in LDS; wave w finishes accumulator registers 4w..4w+3 = rows 8w + 4h + {0..3} of each tile
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int ti = 0; ti < T; ++ti)
 #pragma unroll
-  for (int s = 0; s < MAXSTEPS; ++s) {
-    if (s0 + s < s1) {
-      // zero the elements past the end of the contraction range (padding may hold anything)
-      const int kk = kbeg + (s0 + s) * KSTEP + (REGS == 8 ? 8 : 4) * lh;
+    for (int tj = 0; tj < T; ++tj)
 #pragma unroll
-      for (int e = 0; e < REGS; ++e)
-        if (kk + e >= kend) { va[s][e] = 0.f; vb[s][e] = 0.f; }
-      if constexpr (REGS == 4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s][e], vb[s][e], acc, 0, 0, 0);
-      } else {
-        typename P::frag fa, fb;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { fa[e] = (typename P::elem)va[s][e]; fb[e] = (typename P::elem)vb[s][e]; }
-        acc = P::template mfma<false>(fa, fb, acc);
-      }
-    }
-  }
-  // ---- meet in LDS; wave w finishes accumulator registers 4w..4w+3 = rows 8w + 4h + {0..3}
-#pragma unroll
-  for (int i = 0; i < 16; ++i) part[wave][i][lane] = acc[i];
+      for (int i = 0; i < 16; ++i) part[wave][ti * T + tj][i][lane] = acc[ti][tj][i];
   __syncthreads();
-  float r[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-    r[e] = (part[0][4 * wave + e][lane] + part[1][4 * wave + e][lane]) + (part[2][4 * wave + e][lane] + part[3][4 * wave + e][lane]);
-
-  const int n = n0 + li;
-  const int mrow = m0 + 8 * wave + 4 * lh;  // rows mrow .. mrow+3
-  if (n >= g.N) return;
-  float bias = 0.f;
-  if (EP == NT_FWD || EP == NT_FWD_RELU) bias = g.bias[n];
   float* C = g.C + (long long)bz * g.slab_stride;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int m = mrow + e;
-    float v = r[e];
-    if (EP == NT_FWD) v = v + bias;
-    if (EP == NT_FWD_RELU) v = fmaxf(v + bias, 0.f);
-    if (EP == NT_DX_MASK) v = (m < g.M && g.mask[(long long)m * g.ldmask + n] > 0.f) ? v : 0.f;
-    r[e] = v;
-    if (m < g.M) C[(long long)m * g.ldc + n] = v;
-  }
-  if (EP != NT_DW) {
-    if (g.CT) {  // rows of the transposed copy are padded to a multiple of 32: no bound check on m
-      float4 t = make_float4(mrow + 0 < g.M ? r[0] : 0.f, mrow + 1 < g.M ? r[1] : 0.f, mrow + 2 < g.M ? r[2] : 0.f,
-                             mrow + 3 < g.M ? r[3] : 0.f);
-      *reinterpret_cast<float4*>(g.CT + (long long)n * g.ldct + mrow) = t;
+  for (int ti = 0; ti < T; ++ti) {
+#pragma unroll
+    for (int tj = 0; tj < T; ++tj) {
+      float r[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int reg = 4 * wave + e, tt = ti * T + tj;
+        r[e] = (part[0][tt][reg][lane] + part[1][tt][reg][lane]) + (part[2][tt][reg][lane] + part[3][tt][reg][lane]);
+      }
+      const int n = n0 + 32 * tj + li;
+      const int mrow = m0 + 32 * ti + 8 * wave + 4 * lh;  // rows mrow .. mrow+3
+      if (n >= g.N) continue;
+      float bias = 0.f;
+      if (EP == NT_FWD || EP == NT_FWD_RELU) bias = g.bias[n];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = mrow + e;
+        float v = r[e];
+        if (EP == NT_FWD) v = v + bias;
+        if (EP == NT_FWD_RELU) v = fmaxf(v + bias, 0.f);
+        if (EP == NT_DX_MASK) v = (m < g.M && g.mask[(long long)m * g.ldmask + n] > 0.f) ? v : 0.f;
+        r[e] = v;
+        if (m < g.M) C[(long long)m * g.ldc + n] = v;
+      }
+      if (EP != NT_DW && g.CT) {  // rows of the transposed copy are padded past the batch: no bound check on m
+        float4 t4 = make_float4(mrow + 0 < g.M ? r[0] : 0.f, mrow + 1 < g.M ? r[1] : 0.f, mrow + 2 < g.M ? r[2] : 0.f,
+                                mrow + 3 < g.M ? r[3] : 0.f);
+        *reinterpret_cast<float4*>(g.CT + (long long)n * g.ldct + mrow) = t4;
+      }
     }
   }
 }

@@ -753,21 +753,30 @@ static float adam_alpha(const v21_adam& a, long long t) {
 }
 
 static int launch_nt(int prec, NtGroup& grp, hipStream_t st) {
+  // 64x64 workgroup tiles once the problems are large enough to fill the chip with them
+  long long work = 0;
+  for (int i = 0; i < grp.count; ++i) work += (long long)((grp.p[i].M + 63) / 64) * ((grp.p[i].N + 63) / 64) * std::max(1, grp.p[i].nz);
+  const int T = work >= 192 ? 2 : 1;
   int blocks = 0;
   for (int i = 0; i < grp.count; ++i) {
     NtArgs& g = grp.p[i];
-    g.nx = (g.N + 31) / 32; g.ny = (g.M + 31) / 32;
+    g.tile = 32 * T;
+    g.nx = (g.N + g.tile - 1) / g.tile; g.ny = (g.M + g.tile - 1) / g.tile;
     if (g.nz < 1) g.nz = 1;
     if (g.nz == 1) { g.k_chunk = g.K > 0 ? g.K : 1; g.slab_stride = 0; }
     if (g.k_chunk > kNtMaxKPerWg) return fail(V21_ERR_UNSUPPORTED, "contraction range %d > %d per workgroup", g.k_chunk, kNtMaxKPerWg);
     blocks += g.nx * g.ny * g.nz;
   }
   if (blocks <= 0) return V21_OK;
+#define V21_NT(PT) \
+  do { if (T == 2) hipLaunchKernelGGL((gemm_nt_kernel<PT, 2>), dim3(blocks), dim3(256), 0, st, grp); \
+       else hipLaunchKernelGGL((gemm_nt_kernel<PT, 1>), dim3(blocks), dim3(256), 0, st, grp); } while (0)
   switch (prec) {
-    case V21_PREC_F32: hipLaunchKernelGGL(gemm_nt_kernel<PrecF32>, dim3(blocks), dim3(256), 0, st, grp); break;
-    case V21_PREC_F16: hipLaunchKernelGGL(gemm_nt_kernel<PrecF16>, dim3(blocks), dim3(256), 0, st, grp); break;
-    default: hipLaunchKernelGGL(gemm_nt_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, st, grp); break;
+    case V21_PREC_F32: V21_NT(PrecF32); break;
+    case V21_PREC_F16: V21_NT(PrecF16); break;
+    default: V21_NT(PrecBF16); break;
   }
+#undef V21_NT
   HIPCHK(hipGetLastError());
   return V21_OK;
 }

@@ -206,3 +206,35 @@ def test_rccl_single_rank_communicator_is_identity():
     c2.comm_destroy()
     assert res[0][0] == res[1][0]
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_large_batch_step_uses_big_tiles_and_split_k(ctx):
+    """Per-GPU batch 4096 (BASELINE configs[3]): 64x64 workgroup tiles, the batch contraction of
+    the weight gradient split into slabs; same gradient as the oracle."""
+    synth = pkg("synth")
+    dims = [451, 352, 9, 32, 352, 451]
+    act = [1, 0, 1, 1, 0]
+    n = 4096
+    st, tr, Ws, bs = _make(ctx, dims, act=act, seed=12, max_batch=n)
+    sig = synth.make_signals(n, seed=9)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    tr.set_adam(lr=1e-3)
+    tr.set_data(0, y, None, w)
+    loss = tr.run_epoch(None, n)
+    g = tr.get_grad()
+    # float64 oracle gradient of the same stack
+    W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
+    acts = [y.astype(np.float64)]
+    for W_, b_, a in zip(W, b, act):
+        z = acts[-1] @ W_ + b_
+        acts.append(np.maximum(z, 0) if a else z)
+    l, dz = ora.batch_loss_and_grad(acts[-1], y.astype(np.float64), w.astype(np.float64))
+    dWs, dbs = [None] * 5, [None] * 5
+    for li in range(4, -1, -1):
+        dWs[li] = acts[li].T @ dz; dbs[li] = dz.sum(0)
+        dh = dz @ W[li].T
+        dz = dh * (acts[li] > 0) if li > 0 and act[li - 1] else dh
+    ref = ora.flatten_params(dWs, dbs)
+    assert abs(loss - l) / l < 2e-5
+    _close(g, ref, 5e-4, "gradient at batch 4096")
