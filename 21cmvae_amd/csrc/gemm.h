@@ -1,16 +1,10 @@
 // gemm.h -- generic LDS-tiled MFMA GEMM for arbitrary layer shapes (gfx950).
 //
-// Serves (a) the per-layer fallback of Model.predict for stacks that have no fused
-// kernel and (b) every contraction of a training step (Keras fit(), reference call
-// sites emulator.py:369, :739, :756):
-//     forward   Z = H W + b, H' = relu(Z)          (A k-contiguous, B n-contiguous)
-//     backward  dH = dZ W^T  (.) [H > 0]           (A k-contiguous, B k-contiguous)
-//     weights   [dW; db] = [H^T; 1^T] dZ           (A m-contiguous, B n-contiguous)
-// The bias gradient rides along as one extra row of ones appended to H^T, so that the
-// (K+1) x N result is exactly the [kernel | bias] slice of the flat gradient arena.
-// The weight-gradient contraction runs over the batch; it is split over blockIdx.z
-// (SPLIT-K) into per-slice slabs that adam/reduce kernels sum in a fixed order, so the
-// result is bitwise reproducible (no float atomics).
+// The per-layer fallback of Model.predict (emulator.py:402, :753-754) for stacks that
+// have no fused kernel: Z = H W + b, H' = relu(Z), operands as they sit in the Keras-order
+// arena (A k-contiguous, B n-contiguous).  Training does NOT use this kernel any more: a
+// K-loop GEMM pays one global round trip per k-tile, which made a batch-256 step 267 us;
+// see gemm_nt.h.
 //
 // 64x64 output tile per 256-thread workgroup (4 waves as 2x2, one 32x32 MFMA tile
 // each), BK = 64, double-buffered LDS (one barrier per k-tile).  Operands are fp32 in memory; each thread fetches its 8 elements of
@@ -32,15 +26,10 @@ struct GemmArgs {
   const float* B; long long sb_k, sb_n;   // B(k,n) = B[k*sb_k + n*sb_n]
   float* C; long long ldc;                // C(m,n) = C[m*ldc + n]
   int M, N, K;
-  const float* bias;                      // EP_BIAS*: N floats
-  const float* mask; long long ldmask;    // EP_MASK: multiply by [mask(m,n) > 0]
-  int ones_row;                           // A(m == ones_row, k) = 1  (-1: none)
-  float alpha;                            // C = alpha * acc (EP_PLAIN)
-  int k_chunk;                            // split-K: k range of slice z = [z*k_chunk, ...)
-  long long slab_stride;                  // C of slice z = C + z*slab_stride (floats)
+  const float* bias;                      // N floats
 };
 
-enum { EP_PLAIN = 0, EP_BIAS = 1, EP_BIAS_RELU = 2, EP_MASK = 3 };
+enum { EP_BIAS = 1, EP_BIAS_RELU = 2 };
 
 constexpr int kBM = 64, kBN = 64, kBK = 64;
 
@@ -54,8 +43,7 @@ template <> struct GemmTraits<PrecBF16> { using T = __bf16; static constexpr int
 //   RC (row-contiguous): thread -> row t%64, k = 16*(t/64) .. +15            (256-B column segments)
 template <bool KC>
 __device__ __forceinline__ void fetch_tile(float (&v)[16], const float* __restrict__ base, long long s_row,
-                                           long long s_k, int row0, int nrows, int k0, int kend, int tid,
-                                           int ones_row) {
+                                           long long s_k, int row0, int nrows, int k0, int kend, int tid) {
   if constexpr (KC) {
     const int kk = k0 + 4 * (tid & 15);
 #pragma unroll
@@ -64,18 +52,13 @@ __device__ __forceinline__ void fetch_tile(float (&v)[16], const float* __restri
       float* o = v + 4 * half;
       o[0] = o[1] = o[2] = o[3] = 0.f;
       if (row < nrows) {
-        if (row == ones_row) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = (kk + i < kend) ? 1.f : 0.f;
+        const float* p = base + (long long)row * s_row + kk;  // s_k == 1
+        if (kk + 3 < kend && ((reinterpret_cast<unsigned long long>(p) & 15ull) == 0)) {
+          const float4 q = *reinterpret_cast<const float4*>(p);
+          o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
         } else {
-          const float* p = base + (long long)row * s_row + kk;  // s_k == 1
-          if (kk + 3 < kend && ((reinterpret_cast<unsigned long long>(p) & 15ull) == 0)) {
-            const float4 q = *reinterpret_cast<const float4*>(p);
-            o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
-          } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (kk + i < kend) o[i] = p[i];
-          }
+          for (int i = 0; i < 4; ++i) if (kk + i < kend) o[i] = p[i];
         }
       }
     }
@@ -85,7 +68,7 @@ __device__ __forceinline__ void fetch_tile(float (&v)[16], const float* __restri
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float x = 0.f;
-      if (row < nrows && kk + i < kend) x = (row == ones_row) ? 1.f : base[(long long)row * s_row + (long long)(kk + i) * s_k];
+      if (row < nrows && kk + i < kend) x = base[(long long)row * s_row + (long long)(kk + i) * s_k];
       v[i] = x;
     }
   }
@@ -120,8 +103,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
   const int li = lane & 31, lh = lane >> 5;
-  const int kbeg = blockIdx.z * g.k_chunk;
-  const int kend = min(g.K, kbeg + g.k_chunk);
+  const int kbeg = 0, kend = g.K;
 
   f32x16 acc;
 #pragma unroll
@@ -133,8 +115,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   const long long b_srow = BKC ? g.sb_n : 1, b_sk = BKC ? 1 : g.sb_k;
 
   float va[16], vb[16];
-  fetch_tile<AKC>(va, g.A, a_srow, a_sk, m0, g.M, kbeg, kend, tid, g.ones_row);
-  fetch_tile<BKC>(vb, g.B, b_srow, b_sk, n0, g.N, kbeg, kend, tid, -1);
+  fetch_tile<AKC>(va, g.A, a_srow, a_sk, m0, g.M, kbeg, kend, tid);
+  fetch_tile<BKC>(vb, g.B, b_srow, b_sk, n0, g.N, kbeg, kend, tid);
 
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += kBK, buf ^= 1) {
@@ -143,8 +125,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
     store_tile<BKC, T, PITCH>(Bs[buf], vb, tid);
     __syncthreads();
     if (k0 + kBK < kend) {  // next tile's global loads fly while this tile is multiplied
-      fetch_tile<AKC>(va, g.A, a_srow, a_sk, m0, g.M, k0 + kBK, kend, tid, g.ones_row);
-      fetch_tile<BKC>(vb, g.B, b_srow, b_sk, n0, g.N, k0 + kBK, kend, tid, -1);
+      fetch_tile<AKC>(va, g.A, a_srow, a_sk, m0, g.M, k0 + kBK, kend, tid);
+      fetch_tile<BKC>(vb, g.B, b_srow, b_sk, n0, g.N, k0 + kBK, kend, tid);
     }
     const T* ap = As[buf] + (wm * 32 + li) * PITCH;
     const T* bp = Bs[buf] + (wn * 32 + li) * PITCH;
@@ -168,7 +150,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   }
 
   // C/D map of the 32x32 tile: col = lane&31, row = (i&3) + 8(i>>2) + 4(lane>>5)
-  float* C = g.C + (long long)blockIdx.z * g.slab_stride;
+  float* C = g.C;
   const int n = n0 + wn * 32 + li;
   if (n < g.N) {
     float bias = 0.f;
@@ -180,8 +162,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         float v = acc[i];
         if constexpr (EP == EP_BIAS) v = v + bias;
         if constexpr (EP == EP_BIAS_RELU) v = fmaxf(v + bias, 0.f);
-        if constexpr (EP == EP_MASK) v = (g.mask[(long long)m * g.ldmask + n] > 0.f) ? v : 0.f;
-        if constexpr (EP == EP_PLAIN) v = v * g.alpha;
         C[(long long)m * g.ldc + n] = v;
       }
     }

@@ -8,35 +8,6 @@
 
 namespace v21 {
 
-// K5: dst[i, :] = src[idx[i], :]  -- the Keras data adapter's shuffled batch
-// (emulator.py:369-378 [K]).  idx == nullptr -> rows first..first+n-1.
-__global__ void gather_rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                   const int* __restrict__ idx, long long first, int n, int d,
-                                   long long lds_, long long ldd) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= n) return;
-  const long long s = idx ? (long long)idx[first + row] : first + row;
-  const float* sp = src + s * lds_;
-  float* dp = dst + (long long)row * ldd;
-  for (int j = lane; j < d; j += 64) dp[j] = sp[j];
-}
-__global__ void gather_vec_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                  const int* __restrict__ idx, long long first, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[idx ? (long long)idx[first + i] : first + i];
-}
-
-// dst[r][c] (pitch ldd) = src[r][c] (pitch lds_): row-padded copy of a kernel matrix
-__global__ void repitch_kernel(float* __restrict__ dst, long long ldd, const float* __restrict__ src, long long lds_,
-                               int rows, int cols) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)rows * cols) return;
-  const long long r = i / cols;
-  const int c = (int)(i % cols);
-  dst[r * ldd + c] = src[r * lds_ + c];
-}
-
 // K2: loss_i = w_i sum_j (p - y)^2 (relative_mse_loss, emulator.py:68-81, with
 // w_i = 1/(D amp_i^2); plain MSE w_i = 1/D) and dL/dp = scale * w_i * (p - y),
 // scale = 2 / B_global ([K]: batch loss = mean of per-sample losses).
@@ -101,39 +72,8 @@ __global__ void reduce_slabs_kernel(float* __restrict__ g, const float* __restri
   }
 }
 
-// K4: Keras-2.7 Adam (tf.raw_ops.ResourceApplyAdam [K]):
-//   m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);  w -= alpha m / (sqrt(v) + eps)
-// alpha = lr sqrt(1-b2^t)/(1-b1^t) is computed by the host in f32.  One flat arena,
-// float4 per lane; gscale folds 1/nranks-style factors (1.0 here: the loss gradient
-// already carries 1/B_global).
-__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
-                            float* __restrict__ m, float* __restrict__ v, long long n,
-                            float alpha, float omb1, float omb2, float eps) {
-  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i4 + 3 < n) {
-    float4 W = *(float4*)(w + i4), G = *(const float4*)(g + i4), M = *(float4*)(m + i4),
-           V = *(float4*)(v + i4);
-    float* wp = &W.x; const float* gp = &G.x; float* mp = &M.x; float* vp = &V.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      mp[k] = mp[k] + (gp[k] - mp[k]) * omb1;
-      vp[k] = vp[k] + (gp[k] * gp[k] - vp[k]) * omb2;
-      wp[k] = wp[k] - (mp[k] * alpha) / (sqrtf(vp[k]) + eps);
-    }
-    *(float4*)(w + i4) = W; *(float4*)(m + i4) = M; *(float4*)(v + i4) = V;
-  } else {
-    for (long long i = i4; i < n; ++i) {
-      const float gi = g[i];
-      const float mi = m[i] + (gi - m[i]) * omb1;
-      const float vi = v[i] + (gi * gi - v[i]) * omb2;
-      m[i] = mi; v[i] = vi;
-      w[i] = w[i] - (mi * alpha) / (sqrtf(vi) + eps);
-    }
-  }
-}
-
 // ---- kernels of the NT training path (gemm_nt.h) ------------------------------------
-// K5': one wave per batch row: x[idx] -> H0 row and H0^T column, y[idx] -> Y row, w[idx]
+// K5: the Keras data adapter's shuffled batch (emulator.py:369-378 [K]); one wave per batch row: x[idx] -> H0 row and H0^T column, y[idx] -> Y row, w[idx]
 __global__ void gather_batch_kernel(const float* __restrict__ x, int din, float* __restrict__ h0, long long ldh,
                                     float* __restrict__ h0t, long long ldt, const float* __restrict__ y, int dout,
                                     float* __restrict__ yb, long long ldy, const float* __restrict__ w,
@@ -156,7 +96,7 @@ __global__ void gather_batch_kernel(const float* __restrict__ x, int din, float*
   if (lane == 0 && w) wb[row] = w[s];
 }
 
-// K2': like loss_grad_kernel, also writes the transposed gradient dZ^T (dout x batch)
+// K2 (training form): like loss_grad_kernel, also writes the transposed gradient dZ^T (dout x batch)
 __global__ void loss_grad_t_kernel(const float* __restrict__ p, long long ldp, const float* __restrict__ y,
                                    long long ldy, const float* __restrict__ w, float* __restrict__ dz,
                                    long long lddz, float* __restrict__ dzt, long long ldt,
@@ -181,7 +121,10 @@ __global__ void loss_grad_t_kernel(const float* __restrict__ p, long long ldp, c
   if (lane == 0) rowloss[row] = wi * s;
 }
 
-// K4': Adam over the flat arena + refresh of the two GEMM-friendly weight copies:
+// K4: Keras-2.7 Adam (tf.raw_ops.ResourceApplyAdam [K]):
+//   m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);  w -= alpha m / (sqrt(v) + eps)
+// (alpha = lr sqrt(1-b2^t)/(1-b1^t) from the host, f32) over the flat arena, plus the
+// refresh of the two GEMM-friendly weight copies the next step reads:
 // W^T (rows = outputs, padded) for the forward, row-padded W for the backward.
 struct AdamLayer { long long w_off, wt_off, wp_off; int K, N; long long ldwt, ldwp; };
 struct AdamArgs {

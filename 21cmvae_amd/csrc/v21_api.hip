@@ -233,14 +233,10 @@ struct v21_mlp {
   float *d_xs = nullptr, *d_ys = nullptr;
   long long stage_rows = 0;
   int maxdim = 0;
-  // copy of the kernels with rows padded to 16 bytes (backward GEMM operand)
-  float* d_wpad = nullptr;
   unsigned* d_phase = nullptr;  // per-CU arrival counters of the x2 fused variants
-  std::vector<long long> wpad_off;
-  bool wpad_ok = false;
+  bool wpad_ok = false;  // false after the arena was rewritten from outside a trainer (set_weights)
 };
 
-static inline long long ldp(int d) { return (d + 3) & ~3; }  // row pitch of internal buffers: 16-byte rows
 static int fpi_of(int prec) { return prec == V21_PREC_F32 ? 8 : 16; }
 static void stream_geometry(const v21_mlp* m, int prec, int* total, int* padded) {
   int f = 0;
@@ -290,7 +286,6 @@ extern "C" int v21_mlp_destroy(v21_mlp* m) {
   hipFree(m->d_w);
   for (int i = 0; i < 3; ++i) if (m->d_stream[i]) hipFree(m->d_stream[i]);
   if (m->d_mean) hipFree(m->d_mean);
-  if (m->d_wpad) hipFree(m->d_wpad);
   if (m->d_phase) hipFree(m->d_phase);
   for (int i = 0; i < 2; ++i) if (m->d_act[i]) hipFree(m->d_act[i]);
   if (m->d_xs) hipFree(m->d_xs);
@@ -381,30 +376,10 @@ static int ensure_stream(v21_mlp* m, int prec) {
   return V21_OK;
 }
 
-static int ensure_wpad(v21_mlp* m) {
-  if (m->wpad_ok) return V21_OK;
-  if (!m->d_wpad) {
-    long long o = 0;
-    for (int l = 0; l < m->L; ++l) { m->wpad_off.push_back(o); o += (long long)m->dims[l] * ldp(m->dims[l + 1]); }
-    HIPCHK(hipMalloc((void**)&m->d_wpad, (size_t)(o + 4) * sizeof(float)));
-    HIPCHK(hipMemsetAsync(m->d_wpad, 0, (size_t)(o + 4) * sizeof(float), m->ctx->stream));
-  }
-  for (int l = 1; l < m->L; ++l) {  // layer 0 never needs dX
-    const int K = m->dims[l], N = m->dims[l + 1];
-    const long long tot = (long long)K * N;
-    hipLaunchKernelGGL(repitch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, m->ctx->stream,
-                       m->d_wpad + m->wpad_off[l], ldp(N), (const float*)(m->d_w + m->w_off[l]), (long long)N, K, N);
-    HIPCHK(hipGetLastError());
-  }
-  m->wpad_ok = true;
-  return V21_OK;
-}
-
 template <class P, int EP>
-static int launch_gemm(GemmArgs g, hipStream_t st, int nslice = 1) {
+static int launch_gemm(GemmArgs g, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0) return V21_OK;
-  if (nslice <= 1) { nslice = 1; g.k_chunk = g.K > 0 ? g.K : 1; g.slab_stride = 0; }
-  dim3 grid((g.N + kBN - 1) / kBN, (g.M + kBM - 1) / kBM, nslice);
+  dim3 grid((g.N + kBN - 1) / kBN, (g.M + kBM - 1) / kBM);
   const bool akc = g.sa_k == 1, bkc = g.sb_k == 1;
   if (!akc && g.sa_m != 1) return fail(V21_ERR_ARG, "gemm: A must be contiguous along m or k");
   if (!bkc && g.sb_n != 1) return fail(V21_ERR_ARG, "gemm: B must be contiguous along k or n");
@@ -416,11 +391,11 @@ static int launch_gemm(GemmArgs g, hipStream_t st, int nslice = 1) {
   return V21_OK;
 }
 template <int EP>
-static int launch_gemm_prec(int prec, const GemmArgs& g, hipStream_t st, int nslice = 1) {
+static int launch_gemm_prec(int prec, const GemmArgs& g, hipStream_t st) {
   switch (prec) {
-    case V21_PREC_F32: return launch_gemm<PrecF32, EP>(g, st, nslice);
-    case V21_PREC_F16: return launch_gemm<PrecF16, EP>(g, st, nslice);
-    case V21_PREC_BF16: return launch_gemm<PrecBF16, EP>(g, st, nslice);
+    case V21_PREC_F32: return launch_gemm<PrecF32, EP>(g, st);
+    case V21_PREC_F16: return launch_gemm<PrecF16, EP>(g, st);
+    case V21_PREC_BF16: return launch_gemm<PrecBF16, EP>(g, st);
   }
   return fail(V21_ERR_ARG, "precision %d unknown", prec);
 }
@@ -434,7 +409,6 @@ static int dense_forward(v21_mlp* m, int l, const float* in, long long ldin, flo
   g.C = out; g.ldc = ldout;
   g.M = rows; g.N = m->dims[l + 1]; g.K = m->dims[l];
   g.bias = m->d_w + m->b_off[l];
-  g.ones_row = -1; g.alpha = 1.f;
   return m->act[l] == V21_ACT_RELU ? launch_gemm_prec<EP_BIAS_RELU>(prec, g, st) : launch_gemm_prec<EP_BIAS>(prec, g, st);
 }
 
