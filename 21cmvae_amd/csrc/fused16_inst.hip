@@ -1,0 +1,30 @@
+// fused16_inst.hip -- one translation unit per (architecture, precision) of the 16x16x32
+// fused forward kernel; compiled with -DV21_ARCH=S1 -DV21_PREC=F16s16 etc.
+#include "fused_fwd16.h"
+#include "archs.h"
+
+#define V21_CAT3(a, b, c) a##b##c
+#define V21_SYMNAME(a, p) V21_CAT3(launch_fused_, a, _##p)
+#define V21_XCAT(a, b) a##b
+#define V21_ARCH_T(a) V21_XCAT(Arch, a)
+#define V21_PREC_T(p) V21_XCAT(Prec, p)
+#define V21_EXPAND_SYM(a, p) V21_SYMNAME(a, p)
+
+namespace v21 {
+hipError_t V21_EXPAND_SYM(V21_ARCH, V21_PREC)(const FusedArgs& a, int, hipStream_t st) {
+  using A = V21_ARCH_T(V21_ARCH);
+  using P = V21_PREC_T(V21_PREC);
+  auto kern = fused_fwd16<A, P>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds<P>());
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  constexpr int rows = kWaves * P::CB * 16;
+  const long long nwg = (a.n_rows + rows - 1) / rows;
+  if (nwg <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), fused_lds<P>(), st, a);
+  return hipGetLastError();
+}
+}  // namespace v21

@@ -85,6 +85,7 @@ struct FusedArgs {
   v21_affine_in tin;
   unsigned long long* dbg;      // diagnostic builds only (V21_FUSED_STAMP): cycle stamps
   unsigned* phase_ctr;          // x2 variants: per-CU arrival counters (2048 words) for de-phasing
+  int prio_mode;                // x2 variants: 1 = the second workgroup of a CU runs at s_setprio 1 (static)
   int delay_sleeps;             // x2 variants: start delay of the second workgroup of a CU, in s_sleep 127 units
 };
 
@@ -94,7 +95,7 @@ struct FusedArgs {
 // i % EPI of item (16/EPI)*nt + i / EPI of the next layer's operand, and element e of
 // item ku held by lane half h is feature  FPI*ku + 8*(e>>2) + 4*h + (e&3).
 struct PrecF16 {
-  static constexpr int BLK = 24, RING = 4, WPS = 1;  // 96 KiB ring, one wave per SIMD
+  static constexpr int BLK = 24, RING = 4, WPS = 1, DEPTH = 2;  // 96 KiB ring, one wave per SIMD
   using frag = f16x8;
   using elem = _Float16;
   static constexpr int FPI = 16, EPI = 8, CT = 2;
@@ -110,7 +111,7 @@ struct PrecF16 {
   }
 };
 struct PrecBF16 {
-  static constexpr int BLK = 24, RING = 4, WPS = 1;  // 96 KiB ring, one wave per SIMD
+  static constexpr int BLK = 24, RING = 4, WPS = 1, DEPTH = 2;  // 96 KiB ring, one wave per SIMD
   using frag = bf16x8;
   using elem = __bf16;
   static constexpr int FPI = 16, EPI = 8, CT = 2;
@@ -126,7 +127,7 @@ struct PrecBF16 {
 };
 // exact f32: v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain (no reduced precision)
 struct PrecF32 {
-  static constexpr int BLK = 24, RING = 4, WPS = 1;
+  static constexpr int BLK = 24, RING = 4, WPS = 1, DEPTH = 2;
   using frag = f32x4;
   using elem = float;
   static constexpr int FPI = 8, EPI = 4, CT = 1;
@@ -144,8 +145,18 @@ struct PrecF32 {
 // Variant "x2": one column tile per wave (128 signals per workgroup), <= 256 registers,
 // 80 KiB ring -> TWO workgroups per CU, i.e. two waves per SIMD that cover each other's
 // stalls (LDS latency, DMA issue, epilogue VALU, output-layer stores).
+#ifdef V21_FUSED_STAMP  // diagnostic build: one ring slot less makes room for the stamp area at 2 workgroups/CU
+struct PrecF16x2 : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 4, WPS = 2; };
+struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 4, WPS = 2; };
+#else
 struct PrecF16x2 : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
 struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
+#endif
+// tuning variants of the x2 kernel (A/B only: scripts/ab_fused.py, V21_FUSED_TUNE)
+struct PrecF16x2b : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2, DEPTH = 3; };
+struct PrecF16x2c : PrecF16 { static constexpr int CT = 1, BLK = 20, RING = 4, WPS = 2, DEPTH = 2; };
+struct PrecF16x2d : PrecF16 { static constexpr int CT = 1, BLK = 12, RING = 6, WPS = 2, DEPTH = 2; };
+struct PrecF16x2e : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2, DEPTH = 1; };
 
 // ---- compile-time geometry of (architecture, precision) ---------------------------
 // Arch::L layers, Arch::dims[L+1], Arch::act[L] (1 = ReLU).  The last layer is the
@@ -360,7 +371,7 @@ __global__ void __launch_bounds__(256, P::WPS) fused_fwd(const FusedArgs a) {
 #ifndef V21_FUSED_SPREAD
 #define V21_FUSED_SPREAD 0
 #endif
-  constexpr int D = V21_FUSED_D;  // LDS read-ahead, in fragments
+  constexpr int D = P::DEPTH;  // LDS read-ahead, in fragments
   constexpr bool SPREAD = V21_FUSED_SPREAD != 0;
   constexpr int TOTAL = G::total();
   constexpr int NOUT = G::dim(L);
@@ -380,8 +391,9 @@ __global__ void __launch_bounds__(256, P::WPS) fused_fwd(const FusedArgs a) {
   // arrive on a CU (per-CU arrival counter keyed by XCC/SE/SH/CU id; parity, so no reset is
   // needed between launches) sleeps first: its hidden layers then overlap the first one's
   // stores.  Placement only changes speed, never results.
+  unsigned group = 0;  // 0/1: first / second workgroup to arrive on this CU (x2 variants)
   if constexpr (P::WPS == 2) {
-    if (a.phase_ctr != nullptr && a.delay_sleeps > 0) {
+    if (a.phase_ctr != nullptr) {
       if (threadIdx.x == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
@@ -391,6 +403,10 @@ __global__ void __launch_bounds__(256, P::WPS) fused_fwd(const FusedArgs a) {
       __syncthreads();
       const unsigned late = *(volatile unsigned*)smem;
       __syncthreads();
+      group = __builtin_amdgcn_readfirstlane(late);
+      // Rejected: alternating s_setprio per ring block between the two workgroups (needs a
+      // branch inside the unrolled stream; that alone cost 20 %).  Static form only:
+      if (group && a.prio_mode) __builtin_amdgcn_s_setprio(1);
       if (late)
         for (int i = 0; i < a.delay_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     }

@@ -20,6 +20,7 @@
 #include "../../include/v21.h"
 #include "archs.h"
 #include "fused_fwd.h"
+#include "fused_fwd16.h"
 #include "gemm.h"
 #include "gemm_nt.h"
 #include "train_kernels.h"
@@ -193,6 +194,15 @@ V21_ARCH_LIST(V21_DECL)
   hipError_t launch_fused_##a##_BF16x2(const FusedArgs&, int, hipStream_t);
 V21_ARCH_LIST(V21_DECL2)
 #undef V21_DECL2
+#define V21_DECL3(a)                                                        \
+  hipError_t launch_fused_##a##_F16s16(const FusedArgs&, int, hipStream_t); \
+  hipError_t launch_fused_##a##_BF16s16(const FusedArgs&, int, hipStream_t);
+V21_ARCH_LIST(V21_DECL3)
+#undef V21_DECL3
+hipError_t launch_fused_S1_F16x2b(const FusedArgs&, int, hipStream_t);
+hipError_t launch_fused_S1_F16x2c(const FusedArgs&, int, hipStream_t);
+hipError_t launch_fused_S1_F16x2d(const FusedArgs&, int, hipStream_t);
+hipError_t launch_fused_S1_F16x2e(const FusedArgs&, int, hipStream_t);
 }  // namespace v21
 
 typedef hipError_t (*fused_launcher)(const FusedArgs&, int, hipStream_t);
@@ -202,10 +212,12 @@ struct FusedEntry {
   const int* act;
   fused_launcher fn[3];    // one wave per SIMD, two column tiles per wave (f32: one)
   fused_launcher fn_x2[3]; // two workgroups per CU, one column tile per wave (f16/bf16)
+  fused_launcher fn_s16[3]; // same occupancy, 16x16x32 MFMA shape (fused_fwd16.h)
 };
 #define V21_ENTRY(a)                                                                                          \
   {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_##a##_F32, launch_fused_##a##_F16, launch_fused_##a##_BF16}, \
-   {nullptr, launch_fused_##a##_F16x2, launch_fused_##a##_BF16x2}},
+   {nullptr, launch_fused_##a##_F16x2, launch_fused_##a##_BF16x2},                                         \
+   {nullptr, launch_fused_##a##_F16s16, launch_fused_##a##_BF16s16}},
 static const FusedEntry g_fused[] = {V21_ARCH_LIST(V21_ENTRY)};
 #undef V21_ENTRY
 
@@ -222,6 +234,8 @@ struct v21_mlp {
   int fused_id = -1;
   unsigned char* d_stream[3] = {nullptr, nullptr, nullptr};
   bool stream_ok[3] = {false, false, false};
+  unsigned char* d_stream16[3] = {nullptr, nullptr, nullptr};  // 16x16x32-shape fragments
+  bool stream16_ok[3] = {false, false, false};
   bool has_tin = false, has_tout = false;
   v21_affine_in tin{};
   float out_std = 1.f;
@@ -284,7 +298,7 @@ extern "C" int v21_mlp_destroy(v21_mlp* m) {
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
   hipFree(m->d_w);
-  for (int i = 0; i < 3; ++i) if (m->d_stream[i]) hipFree(m->d_stream[i]);
+  for (int i = 0; i < 3; ++i) { if (m->d_stream[i]) hipFree(m->d_stream[i]); if (m->d_stream16[i]) hipFree(m->d_stream16[i]); }
   if (m->d_mean) hipFree(m->d_mean);
   if (m->d_phase) hipFree(m->d_phase);
   for (int i = 0; i < 2; ++i) if (m->d_act[i]) hipFree(m->d_act[i]);
@@ -298,7 +312,10 @@ extern "C" int v21_mlp_num_params(const v21_mlp* m, size_t* n) {
   *n = m->nparams;
   return V21_OK;
 }
-static void invalidate_streams(v21_mlp* m) { m->stream_ok[0] = m->stream_ok[1] = m->stream_ok[2] = false; m->wpad_ok = false; }
+static void invalidate_streams(v21_mlp* m) {
+  for (int i = 0; i < 3; ++i) m->stream_ok[i] = m->stream16_ok[i] = false;
+  m->wpad_ok = false;
+}
 
 extern "C" int v21_mlp_set_weights(v21_mlp* m, const float* flat, size_t n) {
   if (!m || !flat) return fail(V21_ERR_ARG, "null argument");
@@ -345,19 +362,27 @@ extern "C" int v21_mlp_has_fused(const v21_mlp* m, int precision, int* yes) {
   return V21_OK;
 }
 
-static int ensure_stream(v21_mlp* m, int prec) {
-  if (m->stream_ok[prec]) return V21_OK;
+static int ensure_stream(v21_mlp* m, int prec, bool shape16 = false) {
+  if (shape16 ? m->stream16_ok[prec] : m->stream_ok[prec]) return V21_OK;
   int total, padded;
-  stream_geometry(m, prec, &total, &padded);
-  if (!m->d_stream[prec]) HIPCHK(hipMalloc((void**)&m->d_stream[prec], (size_t)padded * 1024));
+  if (shape16) {
+    total = 0;
+    for (int l = 0; l < m->L; ++l) total += ((m->dims[l + 1] + 15) / 16) * ((m->dims[l] + 31) / 32 + 1);
+    padded = (total + 3) / 4 * 4;
+  } else {
+    stream_geometry(m, prec, &total, &padded);
+  }
+  unsigned char*& dst = shape16 ? m->d_stream16[prec] : m->d_stream[prec];
+  if (!dst) HIPCHK(hipMalloc((void**)&dst, (size_t)padded * 1024));
   PackArgs pa{};
   pa.w = m->d_w;
   pa.mean = m->has_tout ? m->d_mean : nullptr;
-  pa.stream = m->d_stream[prec];
+  pa.stream = dst;
   pa.L = m->L;
   pa.total = total;
   pa.padded = padded;
-  pa.fpi = fpi_of(prec);
+  pa.shape16 = shape16 ? 1 : 0;
+  pa.fpi = shape16 ? 32 : fpi_of(prec);
   pa.epi = prec == V21_PREC_F32 ? 4 : 8;
   pa.esize = prec == V21_PREC_F32 ? 4 : 2;
   pa.is_bf16 = prec == V21_PREC_BF16;
@@ -365,14 +390,14 @@ static int ensure_stream(v21_mlp* m, int prec) {
   for (int l = 0; l < m->L; ++l) {
     PackLayer& pl = pa.lt[l];
     pl.K = m->dims[l]; pl.N = m->dims[l + 1];
-    pl.ks = (pl.K + pa.fpi - 1) / pa.fpi; pl.nt = (pl.N + 31) / 32;
+    pl.ks = (pl.K + pa.fpi - 1) / pa.fpi; pl.nt = shape16 ? (pl.N + 15) / 16 : (pl.N + 31) / 32;
     pl.w_off = m->w_off[l]; pl.b_off = m->b_off[l];
     pl.first = f;
     f += pl.nt * (pl.ks + 1);
   }
   hipLaunchKernelGGL(pack_stream_kernel, dim3((padded + 3) / 4), dim3(256), 0, m->ctx->stream, pa);
   HIPCHK(hipGetLastError());
-  m->stream_ok[prec] = true;
+  (shape16 ? m->stream16_ok[prec] : m->stream_ok[prec]) = true;
   return V21_OK;
 }
 
@@ -464,26 +489,43 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
   const bool fused = m->fused_id >= 0 && !(flags & V21_FWD_FORCE_GENERIC) &&
                      (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) && ldy < (1ll << 21);
   if (!fused) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
-  CHK(ensure_stream(m, precision));
+  const int s16 = getenv("V21_FUSED_S16") ? atoi(getenv("V21_FUSED_S16")) : 0;
+  const bool use16 = s16 && g_fused[m->fused_id].fn_s16[precision] != nullptr;
+  CHK(ensure_stream(m, precision, use16));
   FusedArgs a{};
   a.x = d_x; a.ldx = ldx; a.y = d_y; a.ldy = ldy; a.n_rows = n;
-  a.stream = m->d_stream[precision];
+  a.stream = use16 ? m->d_stream16[precision] : m->d_stream[precision];
   const bool tout = (flags & V21_FWD_OUT_TRANSFORM) != 0;
   a.out_std = tout ? m->out_std : 1.0f;
   a.out_mean_scale = tout ? 1.0f : 0.0f;
   a.in_transform = (flags & V21_FWD_IN_TRANSFORM) ? 1 : 0;
   if (a.in_transform) a.tin = m->tin;
   a.dbg = (unsigned long long*)(getenv("V21_FUSED_DBG_PTR") ? strtoull(getenv("V21_FUSED_DBG_PTR"), nullptr, 0) : 0ull);
-  static const int pin = getenv("V21_FUSED_PIN") ? atoi(getenv("V21_FUSED_PIN")) : 0;
-  static const int x2 = getenv("V21_FUSED_X2") ? atoi(getenv("V21_FUSED_X2")) : 1;
+  if (use16) {
+    a.in_transform = (flags & V21_FWD_IN_TRANSFORM) ? 1 : 0;
+  }
+  const int pin = getenv("V21_FUSED_PIN") ? atoi(getenv("V21_FUSED_PIN")) : 0;  // tuning knobs: read per call (A/B in one process)
+  if (use16) {
+    HIPCHK(g_fused[m->fused_id].fn_s16[precision](a, 0, m->ctx->stream));
+    return V21_OK;
+  }
+  const int x2 = getenv("V21_FUSED_X2") ? atoi(getenv("V21_FUSED_X2")) : 1;
   if (x2 && g_fused[m->fused_id].fn_x2[precision]) {  // default for f16/bf16: two 128-signal workgroups per CU
-    static const int delay = getenv("V21_FUSED_DELAY") ? atoi(getenv("V21_FUSED_DELAY")) : 0;
-    if (delay > 0 && !m->d_phase) {
+    const int delay = getenv("V21_FUSED_DELAY") ? atoi(getenv("V21_FUSED_DELAY")) : 0;
+    const int prio = getenv("V21_FUSED_PRIO") ? atoi(getenv("V21_FUSED_PRIO")) : 0;
+    a.prio_mode = prio;
+    if ((delay > 0 || prio) && !m->d_phase) {
       HIPCHK(hipMalloc((void**)&m->d_phase, 2048 * sizeof(unsigned)));
       HIPCHK(hipMemsetAsync(m->d_phase, 0, 2048 * sizeof(unsigned), m->ctx->stream));
     }
     a.phase_ctr = m->d_phase;
     a.delay_sleeps = delay;
+    const char* tune = getenv("V21_FUSED_TUNE");
+    if (tune && m->fused_id == 0 && precision == V21_PREC_F16 && *tune >= 'b' && *tune <= 'e') {
+      fused_launcher tf[] = {launch_fused_S1_F16x2b, launch_fused_S1_F16x2c, launch_fused_S1_F16x2d, launch_fused_S1_F16x2e};
+      HIPCHK(tf[*tune - 'b'](a, pin, m->ctx->stream));
+      return V21_OK;
+    }
     HIPCHK(g_fused[m->fused_id].fn_x2[precision](a, pin, m->ctx->stream));
     return V21_OK;
   }
