@@ -17,7 +17,7 @@ PREC_F32, PREC_F16, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32,
               "f16": PREC_F16, "fp16": PREC_F16, "float16": PREC_F16,
               "bf16": PREC_BF16, "bfloat16": PREC_BF16}
-ACT_LINEAR, ACT_RELU = 0, 1
+ACT_LINEAR, ACT_RELU, ACT_GAUSS = 0, 1, 2
 FWD_IN_TRANSFORM, FWD_OUT_TRANSFORM, FWD_FORCE_GENERIC = 1, 2, 4
 COMM_ID_BYTES = 128
 
@@ -88,6 +88,7 @@ SIGNATURES = {
     "v21_trainer_set_state": (C.c_int, [_P, C.c_int64, _F, _F, C.c_size_t]),
     "v21_trainer_get_grad": (C.c_int, [_P, _F, C.c_size_t]),
     "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
+    "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
     "v21_comm_get_unique_id": (C.c_int, [_P, _P]),
     "v21_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "v21_comm_destroy": (C.c_int, [_P]),
@@ -372,6 +373,10 @@ class Trainer:
         v = None if v is None else np.ascontiguousarray(v, np.float32)
         check(self.lib.v21_trainer_set_state(self.h, int(it), _fptr(m) if m is not None else None,
                                              _fptr(v) if v is not None else None, n))
+
+    def set_vae(self, kl_weight, sample=True, seed=0):
+        """Variational mode of a stack with an ACT_GAUSS layer (include/v21.h: v21_trainer_set_vae)."""
+        check(self.lib.v21_trainer_set_vae(self.h, float(kl_weight), 1 if sample else 0, int(seed) & (2**64 - 1)))
 
     def get_grad(self):
         g = np.empty(self.stack.num_params, np.float32)

@@ -17,7 +17,7 @@ __global__ void loss_grad_kernel(const float* __restrict__ p, long long ldp,
                                  const float* __restrict__ y, long long ldy,
                                  const float* __restrict__ w, float* __restrict__ dz,
                                  long long lddz, float* __restrict__ rowloss, int n, int d,
-                                 float scale) {
+                                 float scale, const float* __restrict__ extra) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
@@ -33,7 +33,7 @@ __global__ void loss_grad_kernel(const float* __restrict__ p, long long ldp,
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) rowloss[row] = wi * s;
+  if (lane == 0) rowloss[row] = wi * s + (extra ? extra[row] : 0.f);  // extra: kl_weight * KL_i (A13)
 }
 
 // deterministic sum of n floats by ONE workgroup -> out[0] (n <= a few 10^5)
@@ -100,7 +100,8 @@ __global__ void gather_batch_kernel(const float* __restrict__ x, int din, float*
 __global__ void loss_grad_t_kernel(const float* __restrict__ p, long long ldp, const float* __restrict__ y,
                                    long long ldy, const float* __restrict__ w, float* __restrict__ dz,
                                    long long lddz, float* __restrict__ dzt, long long ldt,
-                                   float* __restrict__ rowloss, int n, int d, float scale) {
+                                   float* __restrict__ rowloss, int n, int d, float scale,
+                                   const float* __restrict__ extra) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
@@ -118,7 +119,73 @@ __global__ void loss_grad_t_kernel(const float* __restrict__ p, long long ldp, c
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) rowloss[row] = wi * s;
+  if (lane == 0) rowloss[row] = wi * s + (extra ? extra[row] : 0.f);
+}
+
+// ---- A13: the variational latent layer (V21_ACT_GAUSS, include/v21.h) ------------------
+// counter-based standard normal: splitmix64 finaliser of (seed, step, row, d), two 24-bit
+// uniforms, Box-Muller cosine branch (the test checker restates it: gauss_eps).
+__device__ __forceinline__ float gauss_eps(unsigned long long seed, unsigned long long step, unsigned long long row,
+                                           unsigned long long d) {
+  unsigned long long x = seed + step * 0x9E3779B97F4A7C15ull + row * 0xD1B54A32D192ED03ull + d * 0x8CB92BA72F3D8DD7ull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  const float u1 = (float)((x >> 40) + 1ull) * (1.0f / 16777216.0f);         // (0, 1]
+  const float u2 = (float)((x >> 16) & 0xFFFFFFull) * (1.0f / 16777216.0f);  // [0, 1)
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+struct GaussArgs {
+  const float* zs; long long ldz;   // (rows x 2L): [z_mean | z_log_var], output of the Dense before
+  int L, n;
+  float* h; long long ldh;          // forward: z (rows x L) ...
+  float* ht; long long ldt;         // ... and z^T (nullable)
+  float* klrow;                     // forward: kl_weight * KL_i
+  const float* dz; long long lddz;  // backward: dL/dz (rows x L)
+  float* dzs; long long lddzs;      // backward: dL/d[z_mean | z_log_var] ...
+  float* dzst;                      // ... and its transpose (pitch ldt)
+  float beta;                       // forward: kl_weight; backward: kl_weight / B_global
+  int sample;
+  unsigned long long seed, step, row0;
+};
+// one wave per row: z = mu + exp(lv/2) eps;  KL_i = -1/2 sum_d (1 + lv - mu^2 - exp lv)
+__global__ void gauss_sample_kernel(const GaussArgs a) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.n) return;
+  const float* zr = a.zs + (long long)row * a.ldz;
+  float kl = 0.f;
+  for (int d = lane; d < a.L; d += 64) {
+    const float mu = zr[d], lv = zr[a.L + d];
+    const float sd = expf(0.5f * lv);
+    const float e = a.sample ? gauss_eps(a.seed, a.step, a.row0 + row, d) : 0.f;
+    const float z = mu + sd * e;
+    a.h[(long long)row * a.ldh + d] = z;
+    if (a.ht) a.ht[(long long)d * a.ldt + row] = z;
+    kl += -0.5f * (1.0f + lv - mu * mu - sd * sd);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kl += __shfl_xor(kl, o, 64);
+  if (lane == 0) a.klrow[row] = a.beta * kl;
+}
+// d mu = dz + beta mu;  d lv = dz eps exp(lv/2)/2 + beta (exp lv - 1)/2     (beta = kl_weight / B)
+__global__ void gauss_sample_bwd_kernel(const GaussArgs a) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.n) return;
+  const float* zr = a.zs + (long long)row * a.ldz;
+  for (int d = lane; d < a.L; d += 64) {
+    const float mu = zr[d], lv = zr[a.L + d];
+    const float sd = expf(0.5f * lv);
+    const float e = a.sample ? gauss_eps(a.seed, a.step, a.row0 + row, d) : 0.f;
+    const float g = a.dz[(long long)row * a.lddz + d];
+    const float dmu = g + a.beta * mu;
+    const float dlv = g * e * 0.5f * sd + a.beta * 0.5f * (sd * sd - 1.0f);
+    a.dzs[(long long)row * a.lddzs + d] = dmu;
+    a.dzs[(long long)row * a.lddzs + a.L + d] = dlv;
+    a.dzst[(long long)d * a.ldt + row] = dmu;
+    a.dzst[(long long)(a.L + d) * a.ldt + row] = dlv;
+  }
 }
 
 // K4: Keras-2.7 Adam (tf.raw_ops.ResourceApplyAdam [K]):

@@ -249,6 +249,8 @@ struct v21_mlp {
   int maxdim = 0;
   unsigned* d_phase = nullptr;  // per-CU arrival counters of the x2 fused variants
   bool wpad_ok = false;  // false after the arena was rewritten from outside a trainer (set_weights)
+  // width of layer l's Dense output: dims[l+1], or 2*dims[l+1] = [z_mean | z_log_var] for V21_ACT_GAUSS
+  int nw(int l) const { return act[l] == V21_ACT_GAUSS ? 2 * dims[l + 1] : dims[l + 1]; }
 };
 
 static int fpi_of(int prec) { return prec == V21_PREC_F32 ? 8 : 16; }
@@ -266,7 +268,11 @@ extern "C" int v21_mlp_create(v21_ctx* ctx, int n_layers, const int* dims, const
   for (int i = 0; i <= n_layers; ++i)
     if (dims[i] < 1 || dims[i] > 65536) return fail(V21_ERR_ARG, "dims[%d] = %d out of range", i, dims[i]);
   for (int i = 0; i < n_layers; ++i)
-    if (act[i] != V21_ACT_LINEAR && act[i] != V21_ACT_RELU) return fail(V21_ERR_ARG, "act[%d] = %d unknown", i, act[i]);
+    if (act[i] != V21_ACT_LINEAR && act[i] != V21_ACT_RELU && act[i] != V21_ACT_GAUSS)
+      return fail(V21_ERR_ARG, "act[%d] = %d unknown", i, act[i]);
+  int n_gauss = 0;
+  for (int i = 0; i < n_layers; ++i) n_gauss += act[i] == V21_ACT_GAUSS;
+  if (n_gauss > 1) return fail(V21_ERR_UNSUPPORTED, "at most one V21_ACT_GAUSS layer per stack");
   v21_mlp* m = new v21_mlp();
   m->ctx = ctx;
   m->L = n_layers;
@@ -274,8 +280,8 @@ extern "C" int v21_mlp_create(v21_ctx* ctx, int n_layers, const int* dims, const
   m->act.assign(act, act + n_layers);
   long long o = 0;
   for (int l = 0; l < n_layers; ++l) {
-    m->w_off.push_back(o); o += (long long)dims[l] * dims[l + 1];
-    m->b_off.push_back(o); o += dims[l + 1];
+    m->w_off.push_back(o); o += (long long)dims[l] * m->nw(l);
+    m->b_off.push_back(o); o += m->nw(l);
   }
   m->nparams = (size_t)o;
   m->maxdim = *std::max_element(m->dims.begin(), m->dims.end());
@@ -430,7 +436,7 @@ static int dense_forward(v21_mlp* m, int l, const float* in, long long ldin, flo
                          int rows, int prec, hipStream_t st) {
   GemmArgs g{};
   g.A = in; g.sa_m = ldin; g.sa_k = 1;
-  g.B = m->d_w + m->w_off[l]; g.sb_k = m->dims[l + 1]; g.sb_n = 1;
+  g.B = m->d_w + m->w_off[l]; g.sb_k = m->nw(l); g.sb_n = 1;  // V21_ACT_GAUSS: the z_mean columns only (z = z_mean)
   g.C = out; g.ldc = ldout;
   g.M = rows; g.N = m->dims[l + 1]; g.K = m->dims[l];
   g.bias = m->d_w + m->b_off[l];
@@ -649,6 +655,13 @@ struct v21_trainer {
   float* d_evalsum = nullptr;
   float* d_slab = nullptr;  // split-K partial gradients: max_slices x (P + 4)
   int max_slices = 1;
+  // variational latent layer (V21_ACT_GAUSS, A13): gl = its index or -1
+  int gl = -1;
+  float *d_zs = nullptr, *d_dzs = nullptr, *d_dzst = nullptr;  // [z_mean | z_log_var], its gradient, transposed
+  float* d_klrow = nullptr;
+  float kl_weight = 0.f;
+  int sample = 1;
+  unsigned long long seed = 0;
 };
 
 static int zalloc(float** p, size_t nfloat, hipStream_t st) {
@@ -666,6 +679,9 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
   v21_trainer* t = new v21_trainer();
   t->mlp = m; t->ctx = m->ctx; t->prec = precision; t->max_batch = max_batch; t->P = m->nparams;
   const int L = m->L;
+  for (int l = 0; l < L; ++l)
+    if (m->act[l] == V21_ACT_GAUSS) t->gl = l;
+  if (t->gl == L - 1) { delete t; return fail(V21_ERR_UNSUPPORTED, "a V21_ACT_GAUSS layer cannot be the last layer of a trained stack"); }
   CHK(zalloc(&t->d_g, t->P + 4, st));
   CHK(zalloc(&t->d_m, t->P + 4, st));
   CHK(zalloc(&t->d_v, t->P + 4, st));
@@ -688,8 +704,15 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
   HIPCHK(hipStreamSynchronize(st));  // `ones` is a host temporary
   long long ot = 0, op = 0;
   for (int l = 0; l < L; ++l) {
-    t->wt_off.push_back(ot); ot += (long long)(m->dims[l + 1] + 32) * p16(m->dims[l]);
-    t->wp_off.push_back(op); op += (long long)(m->dims[l] + 32) * p16(m->dims[l + 1]);
+    t->wt_off.push_back(ot); ot += (long long)(m->nw(l) + 32) * p16(m->dims[l]);
+    t->wp_off.push_back(op); op += (long long)(m->dims[l] + 32) * p16(m->nw(l));
+  }
+  if (t->gl >= 0) {
+    const int W2 = m->nw(t->gl);
+    CHK(zalloc(&t->d_zs, (size_t)(max_batch + 32) * p16(W2), st));
+    CHK(zalloc(&t->d_dzs, (size_t)(max_batch + 32) * p16(W2), st));
+    CHK(zalloc(&t->d_dzst, (size_t)(W2 + 32) * t->Bp, st));
+    CHK(zalloc(&t->d_klrow, (size_t)max_batch + 32, st));
   }
   CHK(zalloc(&t->d_wt, (size_t)ot + 64, st));
   CHK(zalloc(&t->d_wp, (size_t)op + 64, st));
@@ -719,6 +742,7 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   hipFree(t->d_yb); hipFree(t->d_wb); hipFree(t->d_rowloss); hipFree(t->d_evalsum);
   if (t->d_steploss) hipFree(t->d_steploss);
   if (t->d_slab) hipFree(t->d_slab);
+  if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
   delete t;
   return V21_OK;
 }
@@ -807,7 +831,7 @@ static int adam_and_copies(v21_trainer* t, bool do_adam, float alpha) {
   for (int l = 0; l < m->L; ++l) {
     AdamLayer& al = a.lt[l];
     al.w_off = m->w_off[l]; al.wt_off = t->wt_off[l]; al.wp_off = t->wp_off[l];
-    al.K = m->dims[l]; al.N = m->dims[l + 1]; al.ldwt = p16(al.K); al.ldwp = p16(al.N);
+    al.K = m->dims[l]; al.N = m->nw(l); al.ldwt = p16(al.K); al.ldwp = p16(al.N);
   }
   hipLaunchKernelGGL(adam_repack_kernel, dim3((unsigned)((t->P + 255) / 256)), dim3(256), 0, t->ctx->stream, a);
   HIPCHK(hipGetLastError());
@@ -822,39 +846,63 @@ static int ensure_copies(v21_trainer* t) {
   return V21_OK;
 }
 
-// forward through the stack; h[0] / ht[0] hold the batch
-static int trainer_forward(v21_trainer* t, int rows, bool want_t) {
+static GaussArgs gauss_args(v21_trainer* t, int rows, bool sample, long long row0) {
+  v21_mlp* m = t->mlp;
+  const int l = t->gl;
+  GaussArgs a{};
+  a.zs = t->d_zs; a.ldz = p16(m->nw(l)); a.L = m->dims[l + 1]; a.n = rows;
+  a.h = t->d_h[l + 1]; a.ldh = p16(m->dims[l + 1]); a.ht = nullptr; a.ldt = t->Bp;
+  a.klrow = t->d_klrow;
+  a.dz = t->d_dz[l + 1]; a.lddz = p16(m->dims[l + 1]);
+  a.dzs = t->d_dzs; a.lddzs = p16(m->nw(l)); a.dzst = t->d_dzst;
+  a.beta = t->kl_weight;
+  a.sample = (sample && t->sample) ? 1 : 0;
+  a.seed = t->seed; a.step = (unsigned long long)t->iter; a.row0 = (unsigned long long)row0;
+  return a;
+}
+
+// forward through the stack; h[0] / ht[0] hold the batch.  `sample`: draw eps at the
+// variational layer (training); row0 = position of this rank's first row in the global batch
+static int trainer_forward(v21_trainer* t, int rows, bool want_t, bool sample = false, long long row0 = 0) {
   v21_mlp* m = t->mlp;
   for (int l = 0; l < m->L; ++l) {
+    const bool gauss = m->act[l] == V21_ACT_GAUSS;
     NtGroup grp{};
     grp.count = 1;
     NtArgs& g = grp.p[0];
     g.A = t->d_h[l]; g.lda = p16(m->dims[l]);
     g.B = t->d_wt + t->wt_off[l]; g.ldb = p16(m->dims[l]);
-    g.C = t->d_h[l + 1]; g.ldc = p16(m->dims[l + 1]);
-    g.CT = (want_t && l + 1 < m->L) ? t->d_ht[l + 1] : nullptr; g.ldct = t->Bp;
-    g.M = rows; g.N = m->dims[l + 1]; g.K = m->dims[l];
+    g.C = gauss ? t->d_zs : t->d_h[l + 1]; g.ldc = p16(m->nw(l));
+    g.CT = (want_t && l + 1 < m->L && !gauss) ? t->d_ht[l + 1] : nullptr; g.ldct = t->Bp;
+    g.M = rows; g.N = m->nw(l); g.K = m->dims[l];
     g.bias = m->d_w + m->b_off[l];
     g.ep = m->act[l] == V21_ACT_RELU ? NT_FWD_RELU : NT_FWD;
     g.nz = 1;
     CHK(launch_nt(t->prec, grp, t->ctx->stream));
+    if (gauss) {  // z = z_mean + exp(z_log_var / 2) eps -> h[l+1] (and its transpose), kl_weight * KL_i -> klrow
+      GaussArgs a = gauss_args(t, rows, sample, row0);
+      a.ht = want_t ? t->d_ht[l + 1] : nullptr;
+      hipLaunchKernelGGL(gauss_sample_kernel, dim3((rows + 3) / 4), dim3(256), 0, t->ctx->stream, a);
+      HIPCHK(hipGetLastError());
+    }
   }
   return V21_OK;
 }
 
 // one optimizer step on the batch already gathered into h[0]/ht[0], yb, wb
-static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out) {
+static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out,
+                        long long row0 = 0) {
   v21_mlp* m = t->mlp;
   hipStream_t st = t->ctx->stream;
   const int L = m->L, dout = m->dims[L];
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
     CHK(ensure_copies(t));
-    CHK(trainer_forward(t, rows, true));
+    CHK(trainer_forward(t, rows, true, true, row0));
     const int wpb = 4;  // waves (rows) per block
     hipLaunchKernelGGL(loss_grad_t_kernel, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, st, t->d_h[L], p16(dout), yb,
                        ldy, t->d_wb, t->d_dz[L], p16(dout), t->d_dzt[L], t->Bp, t->d_rowloss, rows, dout,
-                       2.0f / (float)brows);
+                       2.0f / (float)brows, (const float*)t->d_klrow);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_g + t->P, 0);
     HIPCHK(hipGetLastError());
@@ -864,18 +912,25 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
     nslice = (rows + k_chunk - 1) / k_chunk;
     const long long slab_stride = (long long)t->P + 4;
     for (int l = L - 1; l >= 0; --l) {
-      const int K = m->dims[l], N = m->dims[l + 1];
+      const int K = m->dims[l], N = m->nw(l);
+      const bool gauss = l == t->gl;  // gradient w.r.t. this layer's Dense output: dzs / dzst instead of dz[l+1]
+      if (gauss) {  // dz[l+1] = dL/dz  ->  dL/d[z_mean | z_log_var] (+ the KL term's own gradient)
+        GaussArgs a = gauss_args(t, rows, true, row0);
+        a.beta = t->kl_weight / (float)brows;
+        hipLaunchKernelGGL(gauss_sample_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+        HIPCHK(hipGetLastError());
+      }
       NtGroup grp{};
       NtArgs& g = grp.p[0];  // [dW; db] = [H^T; 1^T] dZ
       g.A = t->d_ht[l]; g.lda = t->Bp;
-      g.B = t->d_dzt[l + 1]; g.ldb = t->Bp;
+      g.B = gauss ? t->d_dzst : t->d_dzt[l + 1]; g.ldb = t->Bp;
       g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = N;
       g.M = K + 1; g.N = N; g.K = rows;
       g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
       grp.count = 1;
       if (l > 0) {  // dH = dZ W^T, masked by the ReLU of the layer below -> dz[l], dzt[l]
         NtArgs& d = grp.p[1];
-        d.A = t->d_dz[l + 1]; d.lda = p16(N);
+        d.A = gauss ? t->d_dzs : t->d_dz[l + 1]; d.lda = p16(N);
         d.B = t->d_wp + t->wp_off[l]; d.ldb = p16(N);
         d.C = t->d_dz[l]; d.ldc = p16(K);
         d.CT = t->d_dzt[l]; d.ldct = t->Bp;
@@ -952,7 +1007,7 @@ extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int ba
     if (rows > 0)
       CHK(gather_batch(t, t->d_x[0], din, t->y_is_x[0] ? nullptr : t->d_y[0], dout, t->d_rw[0], d_idx, lo, rows));
     const float* yb = t->y_is_x[0] ? t->d_h[0] : t->d_yb;
-    CHK(trainer_step(t, yb, t->y_is_x[0] ? p16(din) : p16(dout), rows, brows, t->d_steploss + s));
+    CHK(trainer_step(t, yb, t->y_is_x[0] ? p16(din) : p16(dout), rows, brows, t->d_steploss + s, lo - first));
   }
   std::vector<float> h(steps);
   HIPCHK(hipMemcpyAsync(h.data(), t->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -984,7 +1039,7 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
     const int wpb = 4;
     hipLaunchKernelGGL(loss_grad_kernel<false>, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, st, t->d_h[m->L],
                        p16(dout), yb, t->y_is_x[which] ? p16(din) : p16(dout), t->d_wb, (float*)nullptr, 0ll,
-                       t->d_rowloss, rows, dout, 0.f);
+                       t->d_rowloss, rows, dout, 0.f, (const float*)t->d_klrow);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_evalsum, 1);
     HIPCHK(hipGetLastError());
@@ -1007,7 +1062,8 @@ extern "C" int v21_trainer_step_dev(v21_trainer* t, const float* d_x, const floa
   if (!d_y && din != dout) return fail(V21_ERR_ARG, "d_y == NULL (y = x) needs in_dim == out_dim");
   if (n_rows > 0) CHK(gather_batch(t, d_x, din, d_y, dout, d_rw, nullptr, 0, n_rows));
   const float* yb = d_y ? t->d_yb : t->d_h[0];
-  return trainer_step(t, yb, d_y ? p16(dout) : p16(din), n_rows, global_rows, nullptr);
+  return trainer_step(t, yb, d_y ? p16(dout) : p16(din), n_rows, global_rows, nullptr,
+                      (long long)t->ctx->rank * t->max_batch);
 }
 extern "C" int v21_trainer_last_step_loss(v21_trainer* t, double* loss) {
   if (!t || !loss) return fail(V21_ERR_ARG, "null argument");
@@ -1045,6 +1101,13 @@ extern "C" int v21_trainer_get_grad(v21_trainer* t, float* g, size_t n) {
   CHK(use(t->ctx));
   HIPCHK(hipMemcpyAsync(g, t->d_g, n * sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  return V21_OK;
+}
+extern "C" int v21_trainer_set_vae(v21_trainer* t, float kl_weight, int sample, uint64_t seed) {
+  if (!t) return fail(V21_ERR_ARG, "null trainer");
+  if (t->gl < 0) return fail(V21_ERR_STATE, "the stack has no V21_ACT_GAUSS layer");
+  if (!(kl_weight >= 0.f)) return fail(V21_ERR_ARG, "kl_weight must be >= 0");
+  t->kl_weight = kl_weight; t->sample = sample ? 1 : 0; t->seed = (unsigned long long)seed;
   return V21_OK;
 }
 extern "C" int v21_trainer_use_graph(v21_trainer* t, int enable) {

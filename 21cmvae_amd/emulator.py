@@ -13,23 +13,24 @@ import numpy as np
 
 from . import preprocess as pp
 from .callbacks import TqdmCallback
-from .engine import ChainedModel, Dense, Input, Model, Sequential, sequential_from_arrays
+from .engine import ChainedModel, Dense, GaussianLatent, Input, Model, Sequential, sequential_from_arrays
 from .losses import mean_squared_error, relative_mse_loss  # noqa: F401  (public, as in the reference)
 
 PATH = os.path.dirname(os.path.abspath(__file__)) + "/"
 _native = None
 
 
-def _gen_model(in_dim, hidden_dims, out_dim, activation_func, name=None):
+def _gen_model(in_dim, hidden_dims, out_dim, activation_func, name=None, variational=False):
     """Generate a new model: Dense(h, activation) per hidden dim, then a linear
     Dense(out_dim).  ``in_dim`` None defers weight creation until ``build``/first call
-    (a decoder that follows another model)."""
+    (a decoder that follows another model).  ``variational`` (not in the reference
+    snapshot) makes the last layer a ``GaussianLatent`` (z_mean | z_log_var) head."""
     layers = []
     if in_dim is not None:
         layers.append(Input(shape=(in_dim,)))
     for dim in hidden_dims or []:
         layers.append(Dense(dim, activation=activation_func))
-    layers.append(Dense(out_dim))
+    layers.append(GaussianLatent(out_dim, name="z_mean_log_var") if variational else Dense(out_dim))
     return Sequential(layers, name=name)
 
 
@@ -195,13 +196,19 @@ class AutoEncoder(ChainedModel):
     """Encoder + decoder pair of the autoencoder-based emulator; ``call`` reconstructs."""
 
     def __init__(self, signal_train=None, enc_hidden_dims=[], dec_hidden_dims=[], latent_dim=9,
-                 activation_func="relu"):
+                 activation_func="relu", variational=False, kl_weight=0.0):
+        """``variational`` / ``kl_weight`` (build-side): the encoder ends in a
+        (z_mean | z_log_var) head, training samples z and adds kl_weight * KL to each row's
+        loss; ``predict``/``encoder.predict`` use z = z_mean.  variational=False is the
+        reference's deterministic autoencoder (emulator.py:445-518)."""
         if signal_train is None:
             signal_train = _resolve_data(dict(signal_train=None))["signal_train"]
         super().__init__([], name="auto_encoder")
         d = signal_train.shape[-1]
-        self.encoder = _gen_model(d, enc_hidden_dims, latent_dim, activation_func, name="encoder")
+        self.encoder = _gen_model(d, enc_hidden_dims, latent_dim, activation_func, name="encoder",
+                                  variational=variational)
         self.decoder = _gen_model(None, dec_hidden_dims, d, activation_func, name="decoder")
+        self.kl_weight = float(kl_weight)
 
     def _chain(self):  # plain attribute assignment of .encoder/.decoder re-wires the chain
         return [self.encoder, self.decoder]
@@ -225,10 +232,11 @@ class AutoEncoderEmulator(_EmulatorBase):
     def __init__(self, par_train=None, par_val=None, par_test=None, signal_train=None, signal_val=None,
                  signal_test=None, latent_dim=latent_dim, enc_hidden_dims=enc_hidden_dims,
                  dec_hidden_dims=dec_hidden_dims, em_hidden_dims=em_hidden_dims, activation_func="relu",
-                 redshifts=redshifts, frequencies=None, precision="f32"):
+                 redshifts=redshifts, frequencies=None, precision="f32", variational=False, kl_weight=0.0):
         self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test)
         self.redshifts, self.frequencies = _grid(redshifts, frequencies)
-        autoencoder = AutoEncoder(self.signal_train, enc_hidden_dims, dec_hidden_dims, latent_dim, activation_func)
+        autoencoder = AutoEncoder(self.signal_train, enc_hidden_dims, dec_hidden_dims, latent_dim, activation_func,
+                                  variational=variational, kl_weight=kl_weight)
         autoencoder.build((None, self.signal_train.shape[-1]))
         autoencoder.precision = precision
         self.autoencoder = autoencoder

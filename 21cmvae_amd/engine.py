@@ -53,11 +53,39 @@ class Dense:
         self.input_dim = int(input_dim)
         self._version += 1
 
+    @property
+    def _act_code(self):
+        return _native.ACT_RELU if self.activation == "relu" else _native.ACT_LINEAR
+
     def count_params(self):
         return 0 if self.kernel is None else self.kernel.size + self.bias.size
 
     def get_weights(self):
         return [self.kernel.copy(), self.bias.copy()]
+
+
+class GaussianLatent(Dense):
+    """The variational latent layer (build-side: the reference snapshot
+    keeps only its ``z_mean`` layer name).  One Dense(in -> 2*units) whose columns are
+    [z_mean | z_log_var]; the next layer sees z = z_mean + exp(z_log_var/2) * eps while
+    training and z = z_mean in ``predict``.  ``units`` is the latent width."""
+
+    def __init__(self, units, name=None):
+        super().__init__(units, activation=None, name=name)
+        self.activation = "gaussian"
+
+    def build(self, input_dim):
+        if self.kernel is not None and self.input_dim == input_dim:
+            return
+        lim = np.sqrt(6.0 / (input_dim + self.units))  # two Glorot blocks, as two Dense(units) heads would get
+        self.kernel = _rng.uniform(-lim, lim, size=(input_dim, 2 * self.units)).astype(np.float32)
+        self.bias = np.zeros(2 * self.units, np.float32)
+        self.input_dim = int(input_dim)
+        self._version += 1
+
+    @property
+    def _act_code(self):
+        return _native.ACT_GAUSS
 
 
 class Input:
@@ -84,6 +112,9 @@ class Model:
         self._trainer = None
         self._trainer_sig = None
         self._dirty_host = False  # device weights newer than the layers' numpy copies
+        # variational mode (stacks holding a GaussianLatent layer): loss_i = recon_i + kl_weight * KL_i
+        self.kl_weight = 0.0
+        self.sample_latent = True
 
     # -- structure ---------------------------------------------------------------
     def _chain(self):
@@ -148,7 +179,7 @@ class Model:
             sig = self._signature()
             ls = self._dense_layers()
             dims = [ls[0].input_dim] + [l.units for l in ls]
-            act = [_native.ACT_RELU if l.activation == "relu" else _native.ACT_LINEAR for l in ls]
+            act = [l._act_code for l in ls]
             ctx = _native.Context.default()
             self._stack = _native.Stack(ctx, dims, act)
             self._stack.set_weights(self._flat_host())
@@ -166,7 +197,8 @@ class Model:
             for l in self._dense_layers():
                 k = l.kernel.size
                 l.kernel = flat[o:o + k].reshape(l.kernel.shape).copy(); o += k
-                l.bias = flat[o:o + l.units].copy(); o += l.units
+                nb = l.bias.size
+                l.bias = flat[o:o + nb].copy(); o += nb
                 l._version += 1
             self._dirty_host = False
             self._stack_sig = self._signature()  # the device copy IS these weights
@@ -228,6 +260,10 @@ class Model:
             self._trainer.set_state(self.optimizer.iterations)
         o = self.optimizer
         self._trainer.set_adam(float(o.lr), o.beta_1, o.beta_2, o.epsilon)
+        if any(isinstance(l, GaussianLatent) for l in self._dense_layers()):
+            if getattr(self, "_vae_seed", None) is None:
+                self._vae_seed = int(_rng.integers(0, 2**63))
+            self._trainer.set_vae(self.kl_weight, self.sample_latent, self._vae_seed)
         return self._trainer
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=0, callbacks=None,
@@ -261,6 +297,8 @@ class Model:
         for epoch in range(initial_epoch, epochs):
             cbs.on_epoch_begin(epoch)
             tr.set_lr(float(self.optimizer.lr))
+            if getattr(self, "_vae_seed", None) is not None:  # a callback may anneal kl_weight between epochs
+                tr.set_vae(self.kl_weight, self.sample_latent, self._vae_seed)
             perm = _rng.permutation(n).astype(np.int32) if shuffle else None
             logs = {"loss": tr.run_epoch(perm, batch_size)}
             self._dirty_host = True

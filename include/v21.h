@@ -44,7 +44,14 @@ enum {
 
 /* arithmetic of the dense contractions (accumulation is always fp32) */
 enum { V21_PREC_F32 = 0, V21_PREC_F16 = 1, V21_PREC_BF16 = 2 };
-enum { V21_ACT_LINEAR = 0, V21_ACT_RELU = 1 };
+/* V21_ACT_GAUSS: the variational latent layer (the KL/ELBO mode the
+ * north star names; the reference snapshot has only its `z_mean` layer name,
+ * models/autoencoder_based_emulator/encoder.h5).  A layer with this activation is
+ * Dense(dims[l] -> 2*dims[l+1]) whose output is [z_mean | z_log_var]; what the next
+ * layer sees is z = z_mean + exp(z_log_var / 2) * eps (dims[l+1] wide).  forward()
+ * is deterministic (z = z_mean); the trainer samples eps and adds
+ * kl_weight * KL(N(z_mean, exp z_log_var) || N(0, 1)) to every row's loss. */
+enum { V21_ACT_LINEAR = 0, V21_ACT_RELU = 1, V21_ACT_GAUSS = 2 };
 enum { V21_DTYPE_F32 = 0, V21_DTYPE_F64 = 1 };
 
 /* Fused prologue = preprocess.par_transform (preprocess.py:49-110) with the
@@ -153,6 +160,13 @@ int v21_trainer_set_state(v21_trainer* tr, int64_t iter, const float* m, const f
 /* gradient of the last step (after all-reduce), for tests */
 int v21_trainer_get_grad(v21_trainer* tr, float* g, size_t n);
 int v21_trainer_use_graph(v21_trainer* tr, int enable);
+/* Variational mode of a stack with a V21_ACT_GAUSS layer (A13; build-side extension, no
+ * reference arithmetic exists for it): loss_i = recon_i + kl_weight * KL_i,
+ * KL_i = -1/2 sum_d (1 + lv - mu^2 - exp lv).  sample = 0 -> eps = 0 (with kl_weight = 0
+ * this is exactly the deterministic autoencoder of emulator.py:517); otherwise eps is a
+ * counter-based standard normal keyed on (seed, step, row of the global batch, d) --
+ * restated in oracle/ref_numpy.py:gauss_eps.  Evaluation passes use eps = 0. */
+int v21_trainer_set_vae(v21_trainer* tr, float kl_weight, int sample, uint64_t seed);
 
 /* ---- data-parallel communicator (new: the reference is single-process).  RCCL is
  * loaded at run time (librccl.so.1) so a single-GPU user needs no RCCL. --------- */

@@ -23,6 +23,9 @@ Parity status
   i.e. ceil(N/256) = 96 steps per epoch with the partial last batch kept) and by
   finite-difference / torch-autograd cross-checks of the gradients.
 
+* KL/ELBO + reparameterisation (A13): absent from the reference snapshot; the
+  restatement here checks the build-side extension only.  PARITY UNPINNED.
+
 Every function cites the reference lines it follows (paths relative to
 /root/reference).
 """
@@ -287,6 +290,79 @@ def fit(Ws, bs, st, x, y, w_row, epochs, batch=256, seed=0, val=None, dtype=np.f
         if val is not None:
             hist["val_loss"].append(evaluate(Ws, bs, val[0], val[1], val[2], batch, dtype))
     return Ws, bs, hist
+
+
+# --------------------------------------------------------------------------- #
+# A13  variational latent layer: KL / ELBO, reparameterisation
+#      (ABSENT from the reference snapshot -- only the layer name `z_mean` survives in
+#      models/autoencoder_based_emulator/encoder.h5; this is the checker of the BUILD-SIDE
+#      extension include/v21.h:V21_ACT_GAUSS.  PARITY UNPINNED: no reference arithmetic
+#      exists; pinned by finite differences and by "kl_weight = 0, eps = 0 reduces to A7".)
+# --------------------------------------------------------------------------- #
+
+_M64 = (1 << 64) - 1
+
+
+def gauss_eps(seed, step, rows, L, row0=0):
+    """Counter-based standard normals, the same stream as csrc/train_kernels.h:gauss_eps:
+    splitmix64 finaliser of (seed, step, row, d) -> two 24-bit uniforms -> Box-Muller
+    (cosine branch), float32 arithmetic.  Returns (rows, L) float32."""
+    r = (np.arange(rows, dtype=np.uint64) + np.uint64(row0))[:, None]
+    d = np.arange(L, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        x = (np.uint64(seed & _M64) + np.uint64(step) * np.uint64(0x9E3779B97F4A7C15)
+             + r * np.uint64(0xD1B54A32D192ED03) + d * np.uint64(0x8CB92BA72F3D8DD7))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    f = np.float32
+    u1 = ((x >> np.uint64(40)) + np.uint64(1)).astype(f) * f(1.0 / 16777216.0)
+    u2 = ((x >> np.uint64(16)) & np.uint64(0xFFFFFF)).astype(f) * f(1.0 / 16777216.0)
+    return (np.sqrt(f(-2.0) * np.log(u1)) * np.cos(f(6.28318530717958647692) * u2)).astype(f)
+
+
+def vae_forward(Ws, bs, gl, x, eps, dtype=np.float64):
+    """Dense stack whose layer `gl` is the (z_mean | z_log_var) head: W[gl] is (K, 2L);
+    the next layer sees z = mu + exp(lv/2) eps.  ReLU on every other hidden layer, identity
+    on the last.  Returns (acts, mu, lv): acts[l] = input of layer l, acts[-1] = output."""
+    h = np.asarray(x, dtype=dtype)
+    acts, L, mu, lv = [h], len(Ws), None, None
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        z = h @ W.astype(dtype) + b.astype(dtype)
+        if l == gl:
+            nl = W.shape[1] // 2
+            mu, lv = z[:, :nl], z[:, nl:]
+            h = mu + np.exp(0.5 * lv) * eps.astype(dtype)
+        else:
+            h = np.maximum(z, 0) if l < L - 1 else z
+        acts.append(h)
+    return acts, mu, lv
+
+
+def vae_loss_and_grads(Ws, bs, gl, x, y, w_row, eps, kl_weight, dtype=np.float64, denom=None):
+    """loss = mean_i [ w_i sum_j (p - y)^2 + kl_weight * KL_i ],
+    KL_i = -1/2 sum_d (1 + lv - mu^2 - exp lv).  Returns (loss, flat gradient in arena order)."""
+    acts, mu, lv = vae_forward(Ws, bs, gl, x, eps, dtype)
+    B = x.shape[0] if denom is None else denom
+    recon, dz = batch_loss_and_grad(acts[-1], y.astype(dtype), w_row, denom=B)
+    kl = -0.5 * np.sum(1.0 + lv - mu * mu - np.exp(lv), axis=1)
+    loss = recon + float(kl_weight * np.sum(kl.astype(np.float64)) / B)
+    L = len(Ws)
+    dWs, dbs = [None] * L, [None] * L
+    dz = dz.astype(dtype)
+    for l in range(L - 1, -1, -1):
+        dWs[l] = acts[l].T @ dz
+        dbs[l] = dz.sum(axis=0)
+        if l == 0:
+            break
+        dh = dz @ Ws[l].astype(dtype).T
+        if l - 1 == gl:  # through the sampling: d mu = dh + beta mu; d lv = dh eps sd/2 + beta (e^lv - 1)/2
+            sd = np.exp(0.5 * lv)
+            beta = dtype(kl_weight) / B
+            dz = np.concatenate([dh + beta * mu, dh * eps.astype(dtype) * 0.5 * sd + beta * 0.5 * (sd * sd - 1.0)], axis=1)
+        else:
+            dz = dh * (acts[l] > 0)
+    return loss, flatten_params(dWs, dbs)
 
 
 # --------------------------------------------------------------------------- #

@@ -152,3 +152,25 @@ def test_missing_dataset_is_an_error_not_a_download():
         pytest.skip("a dataset file is present")
     with pytest.raises(ValueError, match="not found"):
         emulator.DirectEmulator()
+
+
+def test_variational_autoencoder_mode(data):
+    """A13 (build-side): AutoEncoder(variational=True, kl_weight=...) trains with sampled
+    latents + KL; predict/encoder.predict are deterministic (z = z_mean)."""
+    emulator, optm, eng = pkg("emulator"), pkg("optimizers"), pkg("engine")
+    eng.set_random_seed(2)
+    ae_em = emulator.AutoEncoderEmulator(latent_dim=6, enc_hidden_dims=[32], dec_hidden_dims=[16, 32],
+                                         em_hidden_dims=[32, 32], variational=True, kl_weight=1e-4, **data)
+    ae = ae_em.autoencoder
+    head = ae.encoder.layers[-1]
+    assert isinstance(head, eng.GaussianLatent) and head.kernel.shape == (32, 12) and head.output_shape[-1] == 6
+    ae.compile(optimizer=optm.Adam(0.001), loss=emulator.relative_mse_loss(ae_em.signal_train))
+    ae_em.emulator.compile(optimizer=optm.Adam(0.01), loss=emulator.mean_squared_error)
+    ae_loss, ae_val, em_loss, em_val = ae_em.train(epochs=6, verbose=0)
+    assert ae_loss[-1] < ae_loss[0] and ae_val[-1] < ae_val[0] and em_loss[-1] < em_loss[0]
+    y = pkg("preprocess").preproc(ae_em.signal_test[:7], ae_em.signal_train)
+    z = ae.encoder.predict(y)
+    assert z.shape == (7, 6)
+    np.testing.assert_array_equal(z, ae.encoder.predict(y))  # deterministic
+    np.testing.assert_allclose(ae.predict(y), ae.decoder.predict(z), atol=1e-4, rtol=1e-4)
+    assert ae_em.predict(ae_em.par_test[:3]).shape == (3, 451)

@@ -209,3 +209,66 @@ def test_c_oracle_agrees_with_numpy_oracle(shipped):
         lib.oracle_adam_step(w.ctypes.data_as(fp), g.ctypes.data_as(fp), m.ctypes.data_as(fp), v.ctypes.data_as(fp),
                              100, 1e-2, 0.9, 0.999, 1e-7, t)
     np.testing.assert_allclose(w, ref, rtol=2e-6, atol=1e-7)
+
+
+# ---- A13: variational latent layer (build-side extension; no reference arithmetic) -------
+def test_gauss_eps_is_standard_normal_and_counter_based():
+    e = ora.gauss_eps(seed=42, step=7, rows=4096, L=9)
+    assert e.dtype == np.float32 and e.shape == (4096, 9)
+    assert abs(float(e.mean())) < 0.02 and abs(float(e.std()) - 1.0) < 0.02
+    # counter-based: a row block drawn with row0 equals the same rows of the big draw
+    np.testing.assert_array_equal(ora.gauss_eps(42, 7, 100, 9, row0=1000), e[1000:1100])
+    assert not np.array_equal(ora.gauss_eps(42, 8, 16, 9), e[:16])
+
+
+def _vae_toy(seed=0):
+    rng = np.random.default_rng(seed)
+    shapes = [(12, 8), (8, 6), (3, 8), (8, 12)]  # layer 1 = (z_mean | z_log_var) head, latent 3
+    Ws = [rng.normal(size=s) * 0.3 for s in shapes]
+    bs = [rng.normal(size=s[1]) * 0.1 for s in shapes]
+    x = rng.normal(size=(5, 12))
+    return Ws, bs, x, np.full(5, 1.0 / 12)
+
+
+def test_vae_gradients_match_finite_differences():
+    Ws, bs, x, w = _vae_toy()
+    eps = ora.gauss_eps(1, 0, 5, 3).astype(np.float64)
+    loss, g = ora.vae_loss_and_grads(Ws, bs, 1, x, x, w, eps, 0.3)
+    flat = ora.flatten_params(Ws, bs)
+
+    def f(fl):
+        o, W2, b2 = 0, [], []
+        for W, b in zip(Ws, bs):
+            W2.append(fl[o:o + W.size].reshape(W.shape)); o += W.size
+            b2.append(fl[o:o + b.size]); o += b.size
+        return ora.vae_loss_and_grads(W2, b2, 1, x, x, w, eps, 0.3)[0]
+    idx = np.random.default_rng(1).choice(flat.size, 60, replace=False)
+    for i in idx:
+        d = np.zeros_like(flat); d[i] = 1e-6
+        assert abs((f(flat + d) - f(flat - d)) / 2e-6 - g[i]) < 1e-7
+
+
+def test_vae_without_noise_and_kl_is_the_plain_autoencoder():
+    """kl_weight = 0, eps = 0 must reduce exactly to A7 (emulator.py:517): same loss, same
+    gradients on the z_mean half, zero gradient on the z_log_var half."""
+    Ws, bs, x, w = _vae_toy(3)
+    loss, g = ora.vae_loss_and_grads(Ws, bs, 1, x, x, w, np.zeros((5, 3)), 0.0)
+    Wp = [Ws[0], Ws[1][:, :3], Ws[2], Ws[3]]
+    bp = [bs[0], bs[1][:3], bs[2], bs[3]]
+    acts = [x]
+    for l, (W, b) in enumerate(zip(Wp, bp)):
+        z = acts[-1] @ W + b
+        acts.append(z if l in (1, 3) else np.maximum(z, 0))
+    lo, dz = ora.batch_loss_and_grad(acts[-1], x, w)
+    assert abs(loss - lo) < 1e-14
+    # backward of the plain stack (latent layer linear)
+    dW1 = None
+    for l in range(3, -1, -1):
+        if l == 1:
+            dW1 = acts[1].T @ dz
+        dh = dz @ Wp[l].T
+        dz = dh if l - 1 == 1 else dh * (acts[l] > 0)
+    o = Ws[0].size + bs[0].size
+    gW1 = g[o:o + Ws[1].size].reshape(8, 6)
+    np.testing.assert_allclose(gW1[:, :3], dW1, atol=1e-14)
+    assert np.all(gW1[:, 3:] == 0)

@@ -238,3 +238,112 @@ def test_large_batch_step_uses_big_tiles_and_split_k(ctx):
     ref = ora.flatten_params(dWs, dbs)
     assert abs(loss - l) / l < 2e-5
     _close(g, ref, 5e-4, "gradient at batch 4096")
+
+
+# ---- A13: variational latent layer (V21_ACT_GAUSS) -- build-side extension ----------------
+def _make_vae(ctx, dims, gl, seed=0, max_batch=256, prec="f32"):
+    """dims = widths the NEXT layer sees; layer `gl` is the (z_mean | z_log_var) head, so its
+    kernel is (dims[gl], 2*dims[gl+1])."""
+    native = pkg("_native")
+    rng = np.random.default_rng(seed)
+    L = len(dims) - 1
+    act = [2 if l == gl else (1 if l < L - 1 else 0) for l in range(L)]
+    Ws, bs = [], []
+    for l in range(L):
+        nout = dims[l + 1] * (2 if l == gl else 1)
+        Ws.append(ora.glorot_uniform(rng, dims[l], nout))
+        bs.append(rng.normal(scale=0.05, size=nout).astype(np.float32))
+    st = native.Stack(ctx, dims, act)
+    assert st.num_params == sum(W.size + b.size for W, b in zip(Ws, bs))
+    st.set_weights(ora.flatten_params(Ws, bs))
+    return st, native.Trainer(st, prec, max_batch), Ws, bs
+
+
+def test_vae_step_matches_oracle(ctx):
+    """Sampled step: loss (reconstruction + kl_weight KL) and the full gradient against the
+    float64 oracle fed the same counter-based noise; then Adam moved the weights."""
+    synth = pkg("synth")
+    dims = [451, 64, 9, 32, 451]
+    st, tr, Ws, bs = _make_vae(ctx, dims, gl=1, seed=21, max_batch=160)
+    n = 150
+    sig = synth.make_signals(n, seed=4)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    kl_weight, seed = 2e-3, 0xDEADBEEF12345
+    tr.set_vae(kl_weight, sample=True, seed=seed)
+    tr.set_adam(lr=1e-3)
+    tr.set_state(5)  # the noise stream is keyed on the step counter
+    tr.set_data(0, y, None, w)
+    loss = tr.run_epoch(None, n)
+    eps = ora.gauss_eps(seed, 5, n, 9)
+    W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
+    lo, g = ora.vae_loss_and_grads(W, b, 1, y.astype(np.float64), y.astype(np.float64), w.astype(np.float64), eps, kl_weight)
+    assert abs(loss - lo) / lo < 2e-5, (loss, lo)
+    _close(tr.get_grad(), g, 3e-4, "VAE gradient")
+    assert tr.get_state()[0] == 6
+    # validation pass: eps = 0, KL term included
+    tr.set_data(1, y, None, w)
+    lv = tr.evaluate(1, 64)
+    flat, o, Wn, bn = st.get_weights().astype(np.float64), 0, [], []
+    for W_, b_ in zip(Ws, bs):
+        Wn.append(flat[o:o + W_.size].reshape(W_.shape)); o += W_.size
+        bn.append(flat[o:o + b_.size]); o += b_.size
+    le, _ = ora.vae_loss_and_grads(Wn, bn, 1, y.astype(np.float64), y.astype(np.float64), w.astype(np.float64),
+                                   np.zeros((n, 9)), kl_weight)
+    assert abs(lv - le) / le < 2e-5
+    # deterministic forward (predict): z = z_mean
+    acts, mu, _ = ora.vae_forward(Wn, bn, 1, y[:20].astype(np.float64), np.zeros((20, 9)))
+    np.testing.assert_allclose(st.forward(y[:20], "f32"), acts[-1], atol=2e-4, rtol=1e-4)
+
+
+def test_vae_without_noise_and_kl_equals_plain_autoencoder(ctx):
+    """kl_weight = 0 and eps = 0 must give the deterministic autoencoder of emulator.py:517:
+    same loss and same gradients as the plain stack holding the z_mean columns."""
+    native = pkg("_native")
+    synth = pkg("synth")
+    dims = [451, 48, 9, 16, 451]
+    st, tr, Ws, bs = _make_vae(ctx, dims, gl=1, seed=5, max_batch=128)
+    n = 100
+    sig = synth.make_signals(n, seed=6)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    tr.set_vae(0.0, sample=False, seed=1)
+    tr.set_adam(lr=1e-3); tr.set_data(0, y, None, w)
+    loss = tr.run_epoch(None, n)
+    g = tr.get_grad()
+    Wp = [Ws[0], np.ascontiguousarray(Ws[1][:, :9]), Ws[2], Ws[3]]
+    bp = [bs[0], bs[1][:9].copy(), bs[2], bs[3]]
+    st2 = native.Stack(ctx, dims, [1, 0, 1, 0])
+    st2.set_weights(ora.flatten_params(Wp, bp))
+    tr2 = native.Trainer(st2, "f32", 128)
+    tr2.set_adam(lr=1e-3); tr2.set_data(0, y, None, w)
+    loss2 = tr2.run_epoch(None, n)
+    g2 = tr2.get_grad()
+    assert loss == loss2
+    # split both gradients per layer and compare the shared parts
+    o = o2 = 0
+    for l, (W_, b_) in enumerate(zip(Ws, bs)):
+        gw = g[o:o + W_.size].reshape(W_.shape); o += W_.size
+        gb = g[o:o + b_.size]; o += b_.size
+        gw2 = g2[o2:o2 + Wp[l].size].reshape(Wp[l].shape); o2 += Wp[l].size
+        gb2 = g2[o2:o2 + bp[l].size]; o2 += bp[l].size
+        if l == 1:
+            np.testing.assert_array_equal(gw[:, 9:], 0); np.testing.assert_array_equal(gb[9:], 0)
+            gw, gb = gw[:, :9], gb[:9]
+        np.testing.assert_allclose(gw, gw2, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(gb, gb2, rtol=1e-6, atol=1e-9)
+
+
+def test_vae_trainer_argument_errors(ctx):
+    native = pkg("_native")
+    st = native.Stack(ctx, [8, 4, 8], [1, 0])
+    tr = native.Trainer(st, "f32", 16)
+    with pytest.raises(native.EngineError):
+        tr.set_vae(1.0)  # no variational layer in the stack
+    with pytest.raises(native.EngineError):
+        native.Stack(ctx, [8, 4, 4, 8], [2, 2, 0])  # at most one
+    enc = native.Stack(ctx, [8, 6, 3], [1, 2])  # an encoder alone: forward gives z_mean ...
+    assert enc.num_params == 8 * 6 + 6 + 6 * 6 + 6
+    assert enc.forward(np.zeros((2, 8), np.float32), "f32").shape == (2, 3)
+    with pytest.raises(native.EngineError):
+        native.Trainer(enc, "f32", 16)  # ... but cannot be trained without a decoder
