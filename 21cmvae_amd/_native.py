@@ -89,6 +89,9 @@ SIGNATURES = {
     "v21_trainer_get_grad": (C.c_int, [_P, _F, C.c_size_t]),
     "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
+    "v21_sweep_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),
+    "v21_sweep_destroy": (C.c_int, [_P]),
+    "v21_sweep_run_epoch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
     "v21_comm_get_unique_id": (C.c_int, [_P, _P]),
     "v21_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "v21_comm_destroy": (C.c_int, [_P]),
@@ -382,3 +385,34 @@ class Trainer:
         g = np.empty(self.stack.num_params, np.float32)
         check(self.lib.v21_trainer_get_grad(self.h, _fptr(g), g.size))
         return g
+
+
+class Sweep:
+    """Several Trainers stepped in lock step on one shared batch stream (v21_sweep);
+    trainer 0 holds the training set."""
+
+    def __init__(self, trainers):
+        self.trainers = list(trainers)
+        self.lib, self.ctx = self.trainers[0].lib, self.trainers[0].ctx
+        arr = (_P * len(self.trainers))(*[t.h.value for t in self.trainers])
+        h = _P()
+        check(self.lib.v21_sweep_create(arr, len(self.trainers), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.v21_sweep_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def run_epoch(self, perm, batch):
+        losses = (C.c_double * len(self.trainers))()
+        pp = None
+        if perm is not None:
+            perm = np.ascontiguousarray(perm, dtype=np.int32)
+            pp = perm.ctypes.data_as(C.POINTER(C.c_int32))
+        with self.ctx.lock:
+            check(self.lib.v21_sweep_run_epoch(self.h, pp, int(batch), losses))
+        return [float(v) for v in losses]

@@ -39,12 +39,19 @@ struct NtArgs {
   int nx, ny, nz;                  // tiles along n, m and contraction slices (set by the launcher)
   int tile;                        // 32 or 64: workgroup tile edge (set by the launcher)
 };
-// up to two independent contractions per launch (the backward of one layer: dW and dX
-// both consume dZ of that layer); blocks [0, nx0*ny0*nz0) belong to the first
-struct NtGroup {
-  NtArgs p[2];
+// several independent contractions per launch: the backward of one layer (dW and dX both
+// consume dZ of that layer), and the same layer of every model of a sweep
+// (BASELINE configs[4]).  Blocks are dealt to the problems in order; first[i] = first block
+// of problem i (set by the launcher).
+constexpr int kNtMaxGroup = 16;
+template <int CAP>
+struct NtGroupT {  // CAP = 2 for a single model (small kernel-argument block), 16 for sweeps
+  NtArgs p[CAP];
+  int first[CAP + 1];
   int count;
 };
+using NtGroup = NtGroupT<2>;
+using NtGroupBig = NtGroupT<kNtMaxGroup>;
 enum { NT_FWD = 0, NT_FWD_RELU = 1, NT_DX = 2, NT_DX_MASK = 3, NT_DW = 4 };
 
 constexpr int kNtMaxKPerWg = 512;
@@ -57,14 +64,13 @@ template <> struct NtTraits<PrecBF16> { static constexpr int KSTEP = 16, MAXSTEP
 // T = MFMA tiles per side of the workgroup tile: T = 1 -> 32x32 (latency: small batches),
 // T = 2 -> 64x64 (twice the arithmetic intensity per loaded byte: large batches; the
 // contraction range of a wave is then walked in rounds of <= MAXSTEPS/2 k-steps).
-template <class P, int T>
-__global__ void __launch_bounds__(256) gemm_nt_kernel(const NtGroup grp) {
+template <class P, int T, class GROUP>
+__global__ void __launch_bounds__(256) gemm_nt_kernel(const GROUP grp) {
   using TR = NtTraits<P>;
-  int bid = blockIdx.x;
-  const int n0blocks = grp.p[0].nx * grp.p[0].ny * grp.p[0].nz;
-  const bool second = grp.count > 1 && bid >= n0blocks;
-  if (second) bid -= n0blocks;
-  const NtArgs& g = second ? grp.p[1] : grp.p[0];
+  int pi = 0;
+  while (pi + 1 < grp.count && (int)blockIdx.x >= grp.first[pi + 1]) ++pi;  // uniform: scalar loop
+  const int bid = blockIdx.x - grp.first[pi];
+  const NtArgs& g = grp.p[pi];
   const int bx = bid % g.nx, by = (bid / g.nx) % g.ny, bz = bid / (g.nx * g.ny);
   const int EP = g.ep;
   constexpr int KSTEP = TR::KSTEP, REGS = TR::REGS;

@@ -188,6 +188,60 @@ __global__ void gauss_sample_bwd_kernel(const GaussArgs a) {
   }
 }
 
+// ---- sweep forms (BASELINE configs[4]: many models, one batch): blockIdx.y = model ----------
+constexpr int kSweepMax = 16;
+struct LossGroup {
+  const float* p[kSweepMax]; long long ldp[kSweepMax];
+  float* dz[kSweepMax]; long long lddz[kSweepMax];
+  float* dzt[kSweepMax];
+  float* rowloss[kSweepMax];
+  const float* y; long long ldy;  // the batch's targets and row weights are shared by all models
+  const float* w;
+  long long ldt;
+  int n, d;
+  float scale;
+};
+__global__ void loss_grad_t_group_kernel(const LossGroup a) {
+  const int k = blockIdx.y;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.n) return;
+  const float wi = a.w[row];
+  const float gs = a.scale * wi;
+  const float* pr = a.p[k] + (long long)row * a.ldp[k];
+  const float* yr = a.y + (long long)row * a.ldy;
+  float* dz = a.dz[k] + (long long)row * a.lddz[k];
+  float* dzt = a.dzt[k];
+  float s = 0.f;
+  for (int j = lane; j < a.d; j += 64) {
+    const float df = pr[j] - yr[j];
+    s += df * df;
+    const float gr = gs * df;
+    dz[j] = gr;
+    dzt[(long long)j * a.ldt + row] = gr;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) a.rowloss[k][row] = wi * s;
+}
+struct SumGroup { const float* v[kSweepMax]; float* out[kSweepMax]; float* out2[kSweepMax]; int n; };
+__global__ void sum_group_kernel(const SumGroup a) {  // one workgroup per model, same order as sum_kernel
+  __shared__ double part[16];
+  const float* v = a.v[blockIdx.x];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) s += (double)v[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
+    a.out[blockIdx.x][0] = (float)t;
+    if (a.out2[blockIdx.x]) a.out2[blockIdx.x][0] = (float)t;
+  }
+}
+
 // K4: Keras-2.7 Adam (tf.raw_ops.ResourceApplyAdam [K]):
 //   m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);  w -= alpha m / (sqrt(v) + eps)
 // (alpha = lr sqrt(1-b2^t)/(1-b1^t) from the host, f32) over the flat arena, plus the
@@ -203,16 +257,28 @@ struct AdamArgs {
   int do_adam, L;
   AdamLayer lt[16];
 };
+__device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha);
 __global__ void adam_repack_kernel(const AdamArgs a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
+  adam_repack_element(a, i, a.alpha);
+}
+// sweep form: blockIdx.y = model, argument blocks in device memory (one per model)
+struct AlphaGroup { float a[kSweepMax]; };
+__global__ void adam_repack_group_kernel(const AdamArgs* __restrict__ tab, const AlphaGroup alpha) {
+  const AdamArgs& a = tab[blockIdx.y];
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  adam_repack_element(a, i, alpha.a[blockIdx.y]);
+}
+__device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha) {
   float wi = a.w[i];
   if (a.do_adam) {
     const float gi = a.g[i];
     const float mi = a.m[i] + (gi - a.m[i]) * a.omb1;
     const float vi = a.v[i] + (gi * gi - a.v[i]) * a.omb2;
     a.m[i] = mi; a.v[i] = vi;
-    wi = wi - (mi * a.alpha) / (sqrtf(vi) + a.eps);
+    wi = wi - (mi * alpha) / (sqrtf(vi) + a.eps);
     a.w[i] = wi;
   }
   int l = 0;

@@ -792,7 +792,8 @@ static float adam_alpha(const v21_adam& a, long long t) {
   return a.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
 }
 
-static int launch_nt(int prec, NtGroup& grp, hipStream_t st) {
+template <class GROUP>
+static int launch_nt(int prec, GROUP& grp, hipStream_t st) {
   // 64x64 workgroup tiles once the problems are large enough to fill the chip with them
   long long work = 0;
   for (int i = 0; i < grp.count; ++i) work += (long long)((grp.p[i].M + 63) / 64) * ((grp.p[i].N + 63) / 64) * std::max(1, grp.p[i].nz);
@@ -805,12 +806,14 @@ static int launch_nt(int prec, NtGroup& grp, hipStream_t st) {
     if (g.nz < 1) g.nz = 1;
     if (g.nz == 1) { g.k_chunk = g.K > 0 ? g.K : 1; g.slab_stride = 0; }
     if (g.k_chunk > kNtMaxKPerWg) return fail(V21_ERR_UNSUPPORTED, "contraction range %d > %d per workgroup", g.k_chunk, kNtMaxKPerWg);
+    grp.first[i] = blocks;
     blocks += g.nx * g.ny * g.nz;
   }
+  grp.first[grp.count] = blocks;
   if (blocks <= 0) return V21_OK;
 #define V21_NT(PT) \
-  do { if (T == 2) hipLaunchKernelGGL((gemm_nt_kernel<PT, 2>), dim3(blocks), dim3(256), 0, st, grp); \
-       else hipLaunchKernelGGL((gemm_nt_kernel<PT, 1>), dim3(blocks), dim3(256), 0, st, grp); } while (0)
+  do { if (T == 2) hipLaunchKernelGGL((gemm_nt_kernel<PT, 2, GROUP>), dim3(blocks), dim3(256), 0, st, grp); \
+       else hipLaunchKernelGGL((gemm_nt_kernel<PT, 1, GROUP>), dim3(blocks), dim3(256), 0, st, grp); } while (0)
   switch (prec) {
     case V21_PREC_F32: V21_NT(PrecF32); break;
     case V21_PREC_F16: V21_NT(PrecF16); break;
@@ -822,7 +825,15 @@ static int launch_nt(int prec, NtGroup& grp, hipStream_t st) {
 }
 
 // Adam (do_adam) and/or refresh of the W^T / padded-W copies from the arena
+static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha);
 static int adam_and_copies(v21_trainer* t, bool do_adam, float alpha) {
+  const AdamArgs a = adam_args(t, do_adam, alpha);
+  hipLaunchKernelGGL(adam_repack_kernel, dim3((unsigned)((t->P + 255) / 256)), dim3(256), 0, t->ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  t->copies_ok = true;
+  return V21_OK;
+}
+static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha) {
   v21_mlp* m = t->mlp;
   AdamArgs a{};
   a.w = m->d_w; a.m = t->d_m; a.v = t->d_v; a.g = t->d_g; a.wt = t->d_wt; a.wp = t->d_wp;
@@ -833,10 +844,7 @@ static int adam_and_copies(v21_trainer* t, bool do_adam, float alpha) {
     al.w_off = m->w_off[l]; al.wt_off = t->wt_off[l]; al.wp_off = t->wp_off[l];
     al.K = m->dims[l]; al.N = m->nw(l); al.ldwt = p16(al.K); al.ldwp = p16(al.N);
   }
-  hipLaunchKernelGGL(adam_repack_kernel, dim3((unsigned)((t->P + 255) / 256)), dim3(256), 0, t->ctx->stream, a);
-  HIPCHK(hipGetLastError());
-  t->copies_ok = true;
-  return V21_OK;
+  return a;
 }
 static int ensure_copies(v21_trainer* t) {
   // the arena may have been rewritten behind our back (set_weights): wpad_ok doubles as the dirty flag
@@ -1103,6 +1111,235 @@ extern "C" int v21_trainer_get_grad(v21_trainer* t, float* g, size_t n) {
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
   return V21_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// sweep: G independent models, ONE shared batch stream, one launch per phase for all of them
+// (BASELINE configs[4]: "64 concurrent latent-dim/hidden-width configs packed as batched
+// GEMM", 8 per GPU; no reference code -- the reference trains one model at a time,
+// emulator.py:739-747).  The models share depth, activations and in/out width; hidden and
+// latent widths differ.  Phase k of a step is the same kind of kernel for every model, so it
+// becomes one grouped launch (gemm_nt.h: NtGroup; train_kernels.h: *_group_kernel).
+// ---------------------------------------------------------------------------------
+struct v21_sweep {
+  v21_ctx* ctx = nullptr;
+  std::vector<v21_trainer*> tr;
+  AdamArgs* d_adam = nullptr;
+  std::vector<AdamArgs> h_adam;  // what d_adam holds
+};
+
+extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** out) {
+  if (!trainers || !out) return fail(V21_ERR_ARG, "null argument");
+  if (count < 1 || count > kSweepMax) return fail(V21_ERR_ARG, "count %d not in [1,%d]", count, kSweepMax);
+  v21_trainer* t0 = trainers[0];
+  if (!t0) return fail(V21_ERR_ARG, "null trainer");
+  const v21_mlp* m0 = t0->mlp;
+  for (int k = 0; k < count; ++k) {
+    v21_trainer* t = trainers[k];
+    if (!t) return fail(V21_ERR_ARG, "null trainer");
+    const v21_mlp* m = t->mlp;
+    if (t->ctx != t0->ctx || t->prec != t0->prec || t->max_batch != t0->max_batch)
+      return fail(V21_ERR_ARG, "model %d: context, precision and max_batch must match model 0", k);
+    if (m->L != m0->L || m->act != m0->act || m->dims[0] != m0->dims[0] || m->dims[m->L] != m0->dims[m0->L])
+      return fail(V21_ERR_ARG, "model %d: depth, activations and in/out width must match model 0", k);
+    if (t->gl >= 0) return fail(V21_ERR_UNSUPPORTED, "variational stacks are not swept in this build");
+    for (int j = 0; j < k; ++j)
+      if (trainers[j] == t) return fail(V21_ERR_ARG, "trainer %d listed twice", k);
+  }
+  CHK(use(t0->ctx));
+  v21_sweep* s = new v21_sweep();
+  s->ctx = t0->ctx;
+  s->tr.assign(trainers, trainers + count);
+  HIPCHK(hipMalloc((void**)&s->d_adam, (size_t)count * sizeof(AdamArgs)));
+  for (int k = 0; k < count; ++k) s->h_adam.push_back(adam_args(trainers[k], true, 0.f));
+  HIPCHK(hipMemcpyAsync(s->d_adam, s->h_adam.data(), s->h_adam.size() * sizeof(AdamArgs), hipMemcpyHostToDevice, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  *out = s;
+  return V21_OK;
+}
+extern "C" int v21_sweep_destroy(v21_sweep* s) {
+  if (!s) return V21_OK;
+  hipSetDevice(s->ctx->device);
+  hipStreamSynchronize(s->ctx->stream);
+  hipFree(s->d_adam);
+  delete s;
+  return V21_OK;
+}
+
+// launch `probs` in groups of <= kNtMaxGroup
+static int launch_nt_many(int prec, std::vector<NtArgs>& probs, hipStream_t st) {
+  for (size_t o = 0; o < probs.size(); o += kNtMaxGroup) {
+    NtGroupBig grp{};
+    grp.count = (int)std::min<size_t>(kNtMaxGroup, probs.size() - o);
+    for (int i = 0; i < grp.count; ++i) grp.p[i] = probs[o + i];
+    CHK(launch_nt(prec, grp, st));
+  }
+  return V21_OK;
+}
+
+// one optimizer step of every model on the batch gathered into model 0's h[0]/ht[0]/yb/wb
+static int sweep_step(v21_sweep* s, const float* yb, long long ldy, int rows, int brows, long long step_index) {
+  v21_trainer* t0 = s->tr[0];
+  hipStream_t st = s->ctx->stream;
+  const int G = (int)s->tr.size(), L = t0->mlp->L, dout = t0->mlp->dims[L];
+  if (rows > t0->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t0->max_batch);
+  if (rows > 0) {
+    for (v21_trainer* t : s->tr) CHK(ensure_copies(t));
+    std::vector<NtArgs> probs;
+    for (int l = 0; l < L; ++l) {  // forward, layer l of every model
+      probs.clear();
+      for (v21_trainer* t : s->tr) {
+        v21_mlp* m = t->mlp;
+        NtArgs g{};
+        g.A = l == 0 ? t0->d_h[0] : t->d_h[l]; g.lda = p16(m->dims[l]);
+        g.B = t->d_wt + t->wt_off[l]; g.ldb = p16(m->dims[l]);
+        g.C = t->d_h[l + 1]; g.ldc = p16(m->dims[l + 1]);
+        g.CT = l + 1 < L ? t->d_ht[l + 1] : nullptr; g.ldct = t->Bp;
+        g.M = rows; g.N = m->dims[l + 1]; g.K = m->dims[l];
+        g.bias = m->d_w + m->b_off[l];
+        g.ep = m->act[l] == V21_ACT_RELU ? NT_FWD_RELU : NT_FWD;
+        g.nz = 1;
+        probs.push_back(g);
+      }
+      CHK(launch_nt_many(t0->prec, probs, st));
+    }
+    LossGroup lg{};
+    SumGroup sg{};
+    for (int k = 0; k < G; ++k) {
+      v21_trainer* t = s->tr[k];
+      lg.p[k] = t->d_h[L]; lg.ldp[k] = p16(dout);
+      lg.dz[k] = t->d_dz[L]; lg.lddz[k] = p16(dout);
+      lg.dzt[k] = t->d_dzt[L]; lg.rowloss[k] = t->d_rowloss;
+      sg.v[k] = t->d_rowloss; sg.out[k] = t->d_g + t->P;
+      sg.out2[k] = (s->ctx->nranks == 1 && step_index >= 0) ? t->d_steploss + step_index : nullptr;
+    }
+    lg.y = yb; lg.ldy = ldy; lg.w = t0->d_wb; lg.ldt = t0->Bp; lg.n = rows; lg.d = dout;
+    lg.scale = 2.0f / (float)brows;
+    sg.n = rows;
+    hipLaunchKernelGGL(loss_grad_t_group_kernel, dim3((rows + 3) / 4, G), dim3(256), 0, st, lg);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(sum_group_kernel, dim3(G), dim3(256), 0, st, sg);
+    HIPCHK(hipGetLastError());
+    int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
+    const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
+    nslice = (rows + k_chunk - 1) / k_chunk;
+    for (int l = L - 1; l >= 0; --l) {  // backward, layer l of every model: dW (and dX below the top)
+      probs.clear();
+      for (v21_trainer* t : s->tr) {
+        v21_mlp* m = t->mlp;
+        const int K = m->dims[l], N = m->dims[l + 1];
+        NtArgs g{};
+        g.A = l == 0 ? t0->d_ht[0] : t->d_ht[l]; g.lda = t->Bp;
+        g.B = t->d_dzt[l + 1]; g.ldb = t->Bp;
+        g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = N;
+        g.M = K + 1; g.N = N; g.K = rows;
+        g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = (long long)t->P + 4;
+        probs.push_back(g);
+        if (l > 0) {
+          NtArgs d{};
+          d.A = t->d_dz[l + 1]; d.lda = p16(N);
+          d.B = t->d_wp + t->wp_off[l]; d.ldb = p16(N);
+          d.C = t->d_dz[l]; d.ldc = p16(K);
+          d.CT = t->d_dzt[l]; d.ldct = t->Bp;
+          d.M = rows; d.N = K; d.K = N;
+          d.mask = t->d_h[l]; d.ldmask = p16(K);
+          d.ep = m->act[l - 1] == V21_ACT_RELU ? NT_DX_MASK : NT_DX;
+          d.nz = 1;
+          probs.push_back(d);
+        }
+      }
+      CHK(launch_nt_many(t0->prec, probs, st));
+    }
+    if (nslice > 1)
+      for (v21_trainer* t : s->tr) {
+        const long long n4 = ((long long)t->P + 3) / 4;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
+                           (const float*)t->d_slab, nslice, (long long)t->P + 4, (long long)t->P);
+        HIPCHK(hipGetLastError());
+      }
+  } else {
+    for (v21_trainer* t : s->tr) HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
+  }
+  AlphaGroup al{};
+  size_t maxP = 0;
+  for (int k = 0; k < G; ++k) {
+    v21_trainer* t = s->tr[k];
+    CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
+    if (s->ctx->nranks > 1 && step_index >= 0)
+      HIPCHK(hipMemcpyAsync(t->d_steploss + step_index, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+    t->iter += 1;
+    al.a[k] = adam_alpha(t->adam, t->iter);
+    maxP = std::max(maxP, t->P);
+  }
+  hipLaunchKernelGGL(adam_repack_group_kernel, dim3((unsigned)((maxP + 255) / 256), G), dim3(256), 0, st,
+                     (const AdamArgs*)s->d_adam, al);
+  HIPCHK(hipGetLastError());
+  for (v21_trainer* t : s->tr) {
+    t->copies_ok = true;
+    invalidate_streams(t->mlp);
+    t->mlp->wpad_ok = true;
+  }
+  return V21_OK;
+}
+
+extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch, double* losses) {
+  if (!s || !losses) return fail(V21_ERR_ARG, "null argument");
+  v21_trainer* t0 = s->tr[0];
+  if (t0->n[0] < 1) return fail(V21_ERR_STATE, "model 0 holds the training set of the sweep: none set");
+  CHK(use(s->ctx));
+  hipStream_t st = s->ctx->stream;
+  v21_mlp* m = t0->mlp;
+  const long long n = t0->n[0];
+  const int R = s->ctx->nranks, rk = s->ctx->rank;
+  if (batch < 1) return fail(V21_ERR_ARG, "batch must be >= 1");
+  if ((batch + R - 1) / R > t0->max_batch) return fail(V21_ERR_ARG, "per-rank batch %d exceeds max_batch %d", (batch + R - 1) / R, t0->max_batch);
+  const int* d_idx = nullptr;
+  if (perm) {
+    if (t0->perm_cap < n) {
+      if (t0->d_perm) HIPCHK(hipFree(t0->d_perm));
+      HIPCHK(hipMalloc((void**)&t0->d_perm, (size_t)n * sizeof(int)));
+      t0->perm_cap = n;
+    }
+    HIPCHK(hipMemcpyAsync(t0->d_perm, perm, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    d_idx = t0->d_perm;
+  }
+  const long long steps = (n + batch - 1) / batch;
+  for (v21_trainer* t : s->tr)
+    if (t->steploss_cap < steps) {
+      if (t->d_steploss) HIPCHK(hipFree(t->d_steploss));
+      HIPCHK(hipMalloc((void**)&t->d_steploss, (size_t)steps * sizeof(float)));
+      t->steploss_cap = steps;
+    }
+  // the Adam hyper-parameters may have changed since create (set_adam / set_lr): refresh the device table
+  std::vector<AdamArgs> tab;
+  for (v21_trainer* t : s->tr) tab.push_back(adam_args(t, true, 0.f));
+  if (memcmp(tab.data(), s->h_adam.data(), tab.size() * sizeof(AdamArgs)) != 0) {
+    s->h_adam = tab;
+    HIPCHK(hipMemcpyAsync(s->d_adam, s->h_adam.data(), tab.size() * sizeof(AdamArgs), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  const int din = m->dims[0], dout = m->dims[m->L];
+  for (long long sidx = 0; sidx < steps; ++sidx) {
+    const long long first = sidx * batch;
+    const int brows = (int)std::min<long long>(batch, n - first);
+    const long long lo = first + (long long)brows * rk / R, hi = first + (long long)brows * (rk + 1) / R;
+    const int rows = (int)(hi - lo);
+    if (rows > 0)
+      CHK(gather_batch(t0, t0->d_x[0], din, t0->y_is_x[0] ? nullptr : t0->d_y[0], dout, t0->d_rw[0], d_idx, lo, rows));
+    const float* yb = t0->y_is_x[0] ? t0->d_h[0] : t0->d_yb;
+    CHK(sweep_step(s, yb, t0->y_is_x[0] ? p16(din) : p16(dout), rows, brows, sidx));
+  }
+  std::vector<float> h((size_t)steps * s->tr.size());
+  for (size_t k = 0; k < s->tr.size(); ++k)
+    HIPCHK(hipMemcpyAsync(h.data() + k * steps, s->tr[k]->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (size_t k = 0; k < s->tr.size(); ++k) {
+    double tot = 0.0;
+    for (long long i = 0; i < steps; ++i) tot += (double)h[k * steps + i];
+    losses[k] = tot / (double)n;
+  }
+  return V21_OK;
+}
+
 extern "C" int v21_trainer_set_vae(v21_trainer* t, float kl_weight, int sample, uint64_t seed) {
   if (!t) return fail(V21_ERR_ARG, "null trainer");
   if (t->gl < 0) return fail(V21_ERR_STATE, "the stack has no V21_ACT_GAUSS layer");

@@ -109,6 +109,61 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
             "collective": "RCCL all-reduce of the flat gradient arena (%d floats)" % (st.num_params + 1) if world > 1 else "none"}
 
 
+SWEEP_CONFIGS = [  # (latent, encoder hidden, decoder hidden): widths multiples of 32 in [32, 512] (SURVEY 8d cfg 5)
+    (4, 128, (32, 128)), (8, 256, (32, 256)), (9, 352, (32, 352)), (12, 384, (64, 384)),
+    (16, 448, (64, 448)), (20, 512, (96, 512)), (24, 320, (128, 320)), (32, 480, (160, 480))]
+
+
+def sweep_leg(native, ctx, precision, batch=256, steps_per_epoch=48, epochs=3):
+    """Auxiliary metric (BASELINE configs[4]): 8 autoencoder configs per GPU trained in lock
+    step with grouped launches, against the same 8 trained one after the other.  No
+    collective: ranks hold independent models."""
+    synth = importlib.import_module("21cmvae_amd.synth")
+    pp = importlib.import_module("21cmvae_amd.preprocess")
+    losses = importlib.import_module("21cmvae_amd.losses")
+    n = batch * steps_per_epoch
+    sig = synth.make_signals(n, seed=77)
+    y = pp.preproc(sig, sig)
+    rw = losses.relative_mse_loss(sig)._v21_row_weight(y).astype(np.float32)
+
+    def make():
+        trs = []
+        for i, (lat, he, hd) in enumerate(SWEEP_CONFIGS):
+            dims = [451, he, lat, hd[0], hd[1], 451]
+            st = native.Stack(ctx, dims, AE_ACT)
+            st.set_weights(glorot(dims, seed=50 + i))
+            tr = native.Trainer(st, precision, batch)
+            tr.set_adam(lr=1e-3)
+            trs.append(tr)
+        return trs
+    grouped = make()
+    grouped[0].set_data(0, y, None, rw)
+    sw = native.Sweep(grouped)
+    sw.run_epoch(None, batch)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        lg = sw.run_epoch(None, batch)
+    ctx.sync()
+    tg = time.perf_counter() - t0
+    solo = make()
+    for tr in solo:
+        tr.set_data(0, y, None, rw)
+        tr.run_epoch(None, batch)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        ls = [tr.run_epoch(None, batch) for tr in solo]
+    ctx.sync()
+    ts = time.perf_counter() - t0
+    G, nsteps = len(SWEEP_CONFIGS), epochs * steps_per_epoch
+    return {"models_per_gpu": G, "batch": batch, "precision": precision,
+            "model_steps_per_s_grouped": G * nsteps / tg, "model_steps_per_s_one_by_one": G * nsteps / ts,
+            "speedup": ts / tg, "ms_per_group_step": 1e3 * tg / nsteps,
+            "max_rel_loss_diff_vs_one_by_one": float(max(abs(a - b) / b for a, b in zip(lg, ls))),
+            "configs": "latent/enc/dec widths " + " ".join("%d/%d/%d-%d" % (c[0], c[1], c[2][0], c[2][1]) for c in SWEEP_CONFIGS)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +320,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         xt = pp.par_transform(params.astype(np.float64), par_train).astype(np.float32)
         out["cpu_baseline"] = cpu_baseline(wflat, xt)
+
+    if not args.no_train and not args.no_extras:
+        try:  # before the communicator exists: the models of a sweep are independent per rank
+            out["sweep"] = sweep_leg(native, ctx, args.precision)
+        except Exception as e:
+            out["sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if dist is not None:  # every rank takes part, whether its own leg failed or not
+            t = torch.tensor([out["sweep"].get("model_steps_per_s_grouped", 0.0)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            out["sweep"]["model_steps_per_s_grouped_all_ranks"] = float(t.item())
 
     if not args.no_train:
         try:

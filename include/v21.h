@@ -168,6 +168,21 @@ int v21_trainer_use_graph(v21_trainer* tr, int enable);
  * restated in oracle/ref_numpy.py:gauss_eps.  Evaluation passes use eps = 0. */
 int v21_trainer_set_vae(v21_trainer* tr, float kl_weight, int sample, uint64_t seed);
 
+/* ---- sweep: several models trained in lock step on ONE shared batch stream (BASELINE
+ * configs[4]: "64 concurrent latent-dim/hidden-width configs packed as batched GEMM", 8 per
+ * GPU).  New: the reference trains one model per fit() call (emulator.py:739-747); a sweep
+ * runs the same fit arithmetic for every model, with phase k of the step (layer k forward,
+ * loss, layer k backward, Adam) issued as one grouped launch for all models.  The trainers
+ * must share context, precision, max_batch, depth, activations and in/out width (hidden and
+ * latent widths differ); trainer 0 holds the training set (v21_trainer_set_data).  Each
+ * trainer keeps its own Adam settings, state and weights and can be used on its own
+ * (eval, get_state, ...) between sweep epochs.  count <= 16. */
+typedef struct v21_sweep v21_sweep;
+int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** out);
+int v21_sweep_destroy(v21_sweep* sw); /* the trainers stay alive */
+/* one Keras-style epoch of every model (same shuffle, same batches); losses[count] */
+int v21_sweep_run_epoch(v21_sweep* sw, const int32_t* perm, int batch, double* losses);
+
 /* ---- data-parallel communicator (new: the reference is single-process).  RCCL is
  * loaded at run time (librccl.so.1) so a single-GPU user needs no RCCL. --------- */
 #define V21_COMM_ID_BYTES 128

@@ -1,0 +1,84 @@
+"""Sweep (BASELINE configs[4]): several models trained in lock step with grouped launches must
+give what training each model on its own gives -- the reference trains one model per fit()
+(emulator.py:739-747), so that IS the expected result."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import ref_numpy as ora
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [dict(latent_dim=4, enc_hidden_dims=[32], dec_hidden_dims=[16, 32]),
+           dict(latent_dim=9, enc_hidden_dims=[64], dec_hidden_dims=[32, 96]),
+           dict(latent_dim=12, enc_hidden_dims=[96], dec_hidden_dims=[48, 64])]
+
+
+def _models(sig, seed):
+    emulator, optm, eng = pkg("emulator"), pkg("optimizers"), pkg("engine")
+    eng.set_random_seed(seed)
+    out = []
+    for c in CONFIGS:
+        ae = emulator.AutoEncoder(sig, **c)
+        ae.build((None, 451))
+        ae.compile(optimizer=optm.Adam(1e-3), loss=emulator.relative_mse_loss(sig))
+        out.append(ae)
+    return out
+
+
+@pytest.mark.parametrize("n,batch", [(300, 128), (700, 600)])
+def test_sweep_equals_individual_fits(n, batch):
+    synth, eng, sweep = pkg("synth"), pkg("engine"), pkg("sweep")
+    sig = synth.make_signals(n, seed=3)
+    val = synth.make_signals(60, seed=4)
+    y, yv = ora.preproc(sig, sig), ora.preproc(val, sig)
+    solo = _models(sig, 11)
+    grouped = _models(sig, 11)
+    for a, b in zip(solo, grouped):
+        for wa, wb in zip(a.get_weights(), b.get_weights()):
+            np.testing.assert_array_equal(wa, wb)
+    hs = []
+    for m in solo:
+        eng.set_random_seed(5)  # same shuffle sequence for every run
+        hs.append(m.fit(y, y, batch_size=batch, epochs=3, validation_data=(yv, yv)))
+    eng.set_random_seed(5)
+    hg = sweep.fit_models(grouped, y, y, batch_size=batch, epochs=3, validation_data=(yv, yv))
+    for a, b, ha, hb in zip(solo, grouped, hs, hg):
+        np.testing.assert_allclose(hb.history["loss"], ha.history["loss"], rtol=2e-5)
+        np.testing.assert_allclose(hb.history["val_loss"], ha.history["val_loss"], rtol=2e-5)
+        for wa, wb in zip(a.get_weights(), b.get_weights()):
+            np.testing.assert_allclose(wb, wa, atol=2e-6, rtol=1e-4)
+        assert b.optimizer.iterations == a.optimizer.iterations == 3 * -(-n // batch)
+
+
+def test_sweep_member_stops_early_others_continue():
+    synth, cbm, sweep = pkg("synth"), pkg("callbacks"), pkg("sweep")
+    sig = synth.make_signals(200, seed=8)
+    y = ora.preproc(sig, sig)
+    models = _models(sig, 2)
+
+    class StopAt(cbm.Callback):
+        def __init__(self, at):
+            super().__init__(); self.at = at
+
+        def on_epoch_end(self, epoch, logs=None):
+            if epoch == self.at:
+                self.model.stop_training = True
+    hists = sweep.fit_models(models, y, y, batch_size=64, epochs=4, validation_data=(y, y),
+                             callbacks=[[StopAt(0)], [], [StopAt(2)]])  # model 0 (the data holder) leaves first
+    assert [len(h.history["loss"]) for h in hists] == [1, 4, 3]
+    assert hists[1].history["loss"][-1] < hists[1].history["loss"][0]
+
+
+def test_sweep_argument_errors(ctx):
+    native = pkg("_native")
+    a = native.Trainer(native.Stack(ctx, [8, 6, 8], [1, 0]), "f32", 32)
+    b = native.Trainer(native.Stack(ctx, [8, 5, 4, 8], [1, 1, 0]), "f32", 32)   # other depth
+    c = native.Trainer(native.Stack(ctx, [8, 7, 8], [1, 0]), "f32", 64)         # other max_batch
+    d = native.Trainer(native.Stack(ctx, [8, 7, 8], [1, 0]), "f32", 32)
+    for bad in ([a, b], [a, c], [a, a]):
+        with pytest.raises(native.EngineError):
+            native.Sweep(bad)
+    sw = native.Sweep([a, d])
+    with pytest.raises(native.EngineError):
+        sw.run_epoch(None, 16)  # trainer 0 has no training set
