@@ -38,6 +38,10 @@ struct NtArgs {
   int ep;                          // NT_* epilogue
   int nx, ny, nz;                  // tiles along n, m and contraction slices (set by the launcher)
   int tile;                        // 32 or 64: workgroup tile edge (set by the launcher)
+  // f16/bf16 operand conversion: A*a_scale, B*b_scale, result*out_scale.  Gradients of a large
+  // batch (2 w_i (p-y)/B ~ 1e-7) sit below the f16 normal range: the backward contractions
+  // scale dZ by a power of two on the way into the MFMA and undo it on the way out (exact).
+  float a_scale, b_scale, out_scale;
 };
 // several independent contractions per launch: the backward of one layer (dW and dX both
 // consume dZ of that layer), and the same layer of every model of a sweep
@@ -146,8 +150,8 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GROUP grp) {
           for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              fa[t][e] = (typename P::elem)va[s][t][e];
-              fb[t][e] = (typename P::elem)vb[s][t][e];
+              fa[t][e] = (typename P::elem)(va[s][t][e] * g.a_scale);
+              fb[t][e] = (typename P::elem)(vb[s][t][e] * g.b_scale);
             }
 #pragma unroll
           for (int ti = 0; ti < T; ++ti)
@@ -175,6 +179,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GROUP grp) {
       for (int e = 0; e < 4; ++e) {
         const int reg = 4 * wave + e, tt = ti * T + tj;
         r[e] = (part[0][tt][reg][lane] + part[1][tt][reg][lane]) + (part[2][tt][reg][lane] + part[3][tt][reg][lane]);
+        if constexpr (REGS == 8) r[e] *= g.out_scale;
       }
       const int n = n0 + 32 * tj + li;
       const int mrow = m0 + 32 * ti + 8 * wave + 4 * lh;  // rows mrow .. mrow+3

@@ -786,6 +786,11 @@ extern "C" int v21_trainer_set_data(v21_trainer* t, int which, const float* x, c
   return V21_OK;
 }
 
+// power-of-two scale that lifts dL/dz ~ 2 w_i (p - y) / B, w_i ~ 1/D, into the f16 normal range
+static float grad_opscale(int brows, int dout) {
+  const double s = (double)brows * (double)dout / 16.0;
+  return (float)std::ldexp(1.0, std::max(0, std::min(24, (int)std::lround(std::log2(std::max(1.0, s))))));
+}
 static float adam_alpha(const v21_adam& a, long long t) {
   // [K] alpha_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in float32
   const float b1p = powf(a.beta1, (float)t), b2p = powf(a.beta2, (float)t);
@@ -804,6 +809,9 @@ static int launch_nt(int prec, GROUP& grp, hipStream_t st) {
     g.tile = 32 * T;
     g.nx = (g.N + g.tile - 1) / g.tile; g.ny = (g.M + g.tile - 1) / g.tile;
     if (g.nz < 1) g.nz = 1;
+    if (g.a_scale == 0.f) g.a_scale = 1.f;
+    if (g.b_scale == 0.f) g.b_scale = 1.f;
+    if (g.out_scale == 0.f) g.out_scale = 1.f;
     if (g.nz == 1) { g.k_chunk = g.K > 0 ? g.K : 1; g.slab_stride = 0; }
     if (g.k_chunk > kNtMaxKPerWg) return fail(V21_ERR_UNSUPPORTED, "contraction range %d > %d per workgroup", g.k_chunk, kNtMaxKPerWg);
     grp.first[i] = blocks;
@@ -919,6 +927,7 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
     const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
     nslice = (rows + k_chunk - 1) / k_chunk;
     const long long slab_stride = (long long)t->P + 4;
+    const float gs = grad_opscale(brows, dout);
     for (int l = L - 1; l >= 0; --l) {
       const int K = m->dims[l], N = m->nw(l);
       const bool gauss = l == t->gl;  // gradient w.r.t. this layer's Dense output: dzs / dzst instead of dz[l+1]
@@ -935,6 +944,7 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
       g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = N;
       g.M = K + 1; g.N = N; g.K = rows;
       g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = slab_stride;
+      g.b_scale = gs; g.out_scale = 1.0f / gs;
       grp.count = 1;
       if (l > 0) {  // dH = dZ W^T, masked by the ReLU of the layer below -> dz[l], dzt[l]
         NtArgs& d = grp.p[1];
@@ -946,6 +956,7 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
         d.mask = t->d_h[l]; d.ldmask = p16(K);
         d.ep = m->act[l - 1] == V21_ACT_RELU ? NT_DX_MASK : NT_DX;
         d.nz = 1;
+        d.a_scale = gs; d.out_scale = 1.0f / gs;
         grp.count = 2;
       }
       CHK(launch_nt(t->prec, grp, st));
@@ -1222,6 +1233,7 @@ static int sweep_step(v21_sweep* s, const float* yb, long long ldy, int rows, in
     int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
     const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
     nslice = (rows + k_chunk - 1) / k_chunk;
+    const float gs = grad_opscale(brows, dout);
     for (int l = L - 1; l >= 0; --l) {  // backward, layer l of every model: dW (and dX below the top)
       probs.clear();
       for (v21_trainer* t : s->tr) {
@@ -1233,6 +1245,7 @@ static int sweep_step(v21_sweep* s, const float* yb, long long ldy, int rows, in
         g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = N;
         g.M = K + 1; g.N = N; g.K = rows;
         g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = (long long)t->P + 4;
+        g.b_scale = gs; g.out_scale = 1.0f / gs;
         probs.push_back(g);
         if (l > 0) {
           NtArgs d{};
@@ -1244,6 +1257,7 @@ static int sweep_step(v21_sweep* s, const float* yb, long long ldy, int rows, in
           d.mask = t->d_h[l]; d.ldmask = p16(K);
           d.ep = m->act[l - 1] == V21_ACT_RELU ? NT_DX_MASK : NT_DX;
           d.nz = 1;
+          d.a_scale = gs; d.out_scale = 1.0f / gs;
           probs.push_back(d);
         }
       }
