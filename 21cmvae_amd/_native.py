@@ -89,6 +89,7 @@ SIGNATURES = {
     "v21_trainer_get_grad": (C.c_int, [_P, _F, C.c_size_t]),
     "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
+    "v21_trainer_chain_stamps": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     "v21_sweep_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),
     "v21_sweep_destroy": (C.c_int, [_P]),
     "v21_sweep_run_epoch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
@@ -380,6 +381,11 @@ class Trainer:
     def set_vae(self, kl_weight, sample=True, seed=0):
         """Variational mode of a stack with an ACT_GAUSS layer (include/v21.h: v21_trainer_set_vae)."""
         check(self.lib.v21_trainer_set_vae(self.h, float(kl_weight), 1 if sample else 0, int(seed) & (2**64 - 1)))
+
+    def chain_stamps(self, n=40):
+        out = (C.c_uint64 * n)()
+        check(self.lib.v21_trainer_chain_stamps(self.h, out, n))
+        return np.array(out[:], dtype=np.uint64)
 
     def get_grad(self):
         g = np.empty(self.stack.num_params, np.float32)

@@ -247,7 +247,10 @@ __global__ void sum_group_kernel(const SumGroup a) {  // one workgroup per model
 // (alpha = lr sqrt(1-b2^t)/(1-b1^t) from the host, f32) over the flat arena, plus the
 // refresh of the two GEMM-friendly weight copies the next step reads:
 // W^T (rows = outputs, padded) for the forward, row-padded W for the backward.
-struct AdamLayer { long long w_off, wt_off, wp_off; int K, N; long long ldwt, ldwp; };
+struct AdamLayer {
+  long long w_off, wt_off, wp_off; int K, N; long long ldwt, ldwp;
+  long long fw_off, bw_off; int KS4, NS4;  // train_chain.h streams (element offsets; k-/n-steps padded to 4)
+};
 struct AdamArgs {
   float *w, *m, *v;
   const float* g;
@@ -255,6 +258,8 @@ struct AdamArgs {
   long long n;
   float alpha, omb1, omb2, eps;
   int do_adam, L;
+  void *fw, *bw;  // packed compute-type weight streams of train_chain.h (cprec != 0)
+  int cprec;      // 0: none, 1: f16, 2: bf16
   AdamLayer lt[16];
 };
 __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha);
@@ -289,6 +294,19 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
     const int k = (int)(r / L.N), n = (int)(r % L.N);
     a.wt[L.wt_off + (long long)n * L.ldwt + k] = wi;
     a.wp[L.wp_off + (long long)k * L.ldwp + n] = wi;
+    if (a.cprec) {
+      // forward fragment (tile n/32, k-step k/16): lane = 32*((k%16)/8) + n%32, element k%8
+      const long long pf = L.fw_off + ((((long long)(n >> 5) * L.KS4 + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 3) + (k & 7);
+      // backward fragment (tile k/32, n-step n/16): lane = 32*((n%16)/8) + k%32, element n%8
+      const long long pb = L.bw_off + ((((long long)(k >> 5) * L.NS4 + (n >> 4)) * 64 + ((n >> 3) & 1) * 32 + (k & 31)) << 3) + (n & 7);
+      if (a.cprec == 1) {
+        reinterpret_cast<_Float16*>(a.fw)[pf] = (_Float16)wi;
+        reinterpret_cast<_Float16*>(a.bw)[pb] = (_Float16)wi;
+      } else {
+        reinterpret_cast<__bf16*>(a.fw)[pf] = (__bf16)wi;
+        reinterpret_cast<__bf16*>(a.bw)[pb] = (__bf16)wi;
+      }
+    }
   }
 }
 

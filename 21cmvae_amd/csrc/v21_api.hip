@@ -24,6 +24,7 @@
 #include "gemm.h"
 #include "gemm_nt.h"
 #include "train_kernels.h"
+#include "train_chain.h"
 
 using namespace v21;
 
@@ -662,6 +663,13 @@ struct v21_trainer {
   float kl_weight = 0.f;
   int sample = 1;
   unsigned long long seed = 0;
+  // one-kernel forward + activation-gradient chain (train_chain.h; f16 / bf16 stacks up to 512 wide)
+  bool chain = false;
+  void *d_fw = nullptr, *d_bw = nullptr;
+  std::vector<long long> fw_off, bw_off;  // element offsets per layer
+  float* d_partial = nullptr;
+  unsigned* d_ticket = nullptr;
+  unsigned long long* d_stamps = nullptr;
 };
 
 static int zalloc(float** p, size_t nfloat, hipStream_t st) {
@@ -720,6 +728,29 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
   CHK(zalloc(&t->d_wb, (size_t)max_batch + 32, st));
   CHK(zalloc(&t->d_rowloss, (size_t)max_batch + 32, st));
   CHK(zalloc(&t->d_evalsum, 4, st));
+  {  // eligibility of the chain kernel
+    const char* env = getenv("V21_TRAIN_CHAIN");
+    bool ok = precision != V21_PREC_F32 && t->gl < 0 && !(env && env[0] == '0');
+    int mask_tiles = 0;
+    for (int l = 0; l <= L && ok; ++l) ok = m->dims[l] <= kChainMaxDim;
+    for (int l = 0; l + 1 < L; ++l) mask_tiles += m->act[l] == V21_ACT_RELU ? (m->dims[l + 1] + 31) / 32 : 0;
+    ok = ok && mask_tiles <= kChainMaskTiles;
+    if (ok) {
+      long long of = 0, ob = 0;
+      for (int l = 0; l < L; ++l) {
+        const int K = m->dims[l], N = m->dims[l + 1];
+        const int KS4 = ((K + 15) / 16 + 3) / 4 * 4, NS4 = ((N + 15) / 16 + 3) / 4 * 4;
+        t->fw_off.push_back(of); of += (long long)((N + 31) / 32) * KS4 * 512;
+        t->bw_off.push_back(ob); ob += (long long)((K + 31) / 32) * NS4 * 512;
+      }
+      HIPCHK(hipMalloc(&t->d_fw, (size_t)of * 2 + 64)); HIPCHK(hipMemsetAsync(t->d_fw, 0, (size_t)of * 2 + 64, st));
+      HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 2 + 64)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 2 + 64, st));
+      CHK(zalloc(&t->d_partial, (size_t)(max_batch + 31) / 32 + 4, st));
+      HIPCHK(hipMalloc((void**)&t->d_ticket, 16)); HIPCHK(hipMemsetAsync(t->d_ticket, 0, 16, st));
+      HIPCHK(hipMalloc((void**)&t->d_stamps, 64 * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, 64 * 8, st));
+      t->chain = true;
+    }
+  }
   t->max_slices = std::max(1, (max_batch + kNtMaxKPerWg - 1) / kNtMaxKPerWg);
   CHK(zalloc(&t->d_slab, (size_t)t->max_slices * (t->P + 4), st));
   *out = t;
@@ -743,6 +774,7 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   if (t->d_steploss) hipFree(t->d_steploss);
   if (t->d_slab) hipFree(t->d_slab);
   if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
+  if (t->chain) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_partial); hipFree(t->d_ticket); hipFree(t->d_stamps); }
   delete t;
   return V21_OK;
 }
@@ -851,7 +883,12 @@ static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha) {
     AdamLayer& al = a.lt[l];
     al.w_off = m->w_off[l]; al.wt_off = t->wt_off[l]; al.wp_off = t->wp_off[l];
     al.K = m->dims[l]; al.N = m->nw(l); al.ldwt = p16(al.K); al.ldwp = p16(al.N);
+    if (t->chain) {
+      al.fw_off = t->fw_off[l]; al.bw_off = t->bw_off[l];
+      al.KS4 = ((al.K + 15) / 16 + 3) / 4 * 4; al.NS4 = ((al.N + 15) / 16 + 3) / 4 * 4;
+    }
   }
+  if (t->chain) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->prec == V21_PREC_F16 ? 1 : 2; }
   return a;
 }
 static int ensure_copies(v21_trainer* t) {
@@ -907,7 +944,7 @@ static int trainer_forward(v21_trainer* t, int rows, bool want_t, bool sample = 
 
 // one optimizer step on the batch already gathered into h[0]/ht[0], yb, wb
 static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out,
-                        long long row0 = 0) {
+                        long long row0) {
   v21_mlp* m = t->mlp;
   hipStream_t st = t->ctx->stream;
   const int L = m->L, dout = m->dims[L];
@@ -980,6 +1017,106 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
 }
 
 static int gather_batch(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy_src,
+                        const float* rw, const int* d_idx, long long first, int rows);
+
+// forward + loss + activation gradients of the chain path: ONE launch (train_chain.h)
+static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
+                        const int* d_idx, long long first, int rows, int brows, float* loss_out2) {
+  v21_mlp* m = t->mlp;
+  const int L = m->L;
+  ChainArgs a{};
+  a.L = L;
+  int mt = 0;
+  for (int l = 0; l < L; ++l) {
+    ChainLayer& c = a.lt[l];
+    c.K = m->dims[l]; c.N = m->dims[l + 1];
+    c.KS4 = ((c.K + 15) / 16 + 3) / 4 * 4; c.NT = (c.N + 31) / 32;
+    c.NS4 = ((c.N + 15) / 16 + 3) / 4 * 4; c.KT = (c.K + 31) / 32;
+    c.relu = m->act[l] == V21_ACT_RELU;
+    c.mask_tile = -1;
+    if (c.relu && l + 1 < L) { c.mask_tile = mt; mt += c.NT; }
+    c.fw_off = t->fw_off[l] / 8; c.bw_off = t->bw_off[l] / 8;
+    c.b_off = m->b_off[l];
+    c.ht = t->d_ht[l]; c.dzt = t->d_dzt[l + 1];
+  }
+  a.fw = t->d_fw; a.bw = t->d_bw; a.w = m->d_w;
+  a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.rw = rw; a.idx = d_idx; a.first = first;
+  a.rows = rows; a.Bp = t->Bp;
+  a.scale = 2.0f / (float)brows;
+  a.gs = grad_opscale(brows, m->dims[L]);
+  a.partial = t->d_partial; a.loss_out = t->d_g + t->P; a.loss_out2 = loss_out2; a.ticket = t->d_ticket;
+  a.stamps = t->d_stamps;
+  static bool attr_done[3] = {false, false, false};
+  const dim3 grid((rows + 31) / 32), block(64 * kChainWaves);
+  if (t->prec == V21_PREC_F16) {
+    if (!attr_done[1]) {
+      HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+      attr_done[1] = true;
+    }
+    hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
+  } else {
+    if (!attr_done[2]) {
+      HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+      attr_done[2] = true;
+    }
+    hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+
+static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out,
+                        long long row0);
+// one optimizer step on rows [first, first+rows) (through d_idx when given) of (x, y, rw)
+static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
+                         const int* d_idx, long long first, int rows, int brows, float* loss_out, long long row0) {
+  v21_mlp* m = t->mlp;
+  const int L = m->L, din = m->dims[0], dout = m->dims[L];
+  if (!t->chain) {
+    if (rows > 0) CHK(gather_batch(t, x, ldx, y, ldy, rw, d_idx, first, rows));
+    const float* yb = y ? t->d_yb : t->d_h[0];
+    return trainer_step(t, yb, y ? p16(dout) : p16(din), rows, brows, loss_out, row0);
+  }
+  hipStream_t st = t->ctx->stream;
+  if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
+  if (rows > 0) {
+    CHK(ensure_copies(t));
+    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, nullptr));
+    int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
+    const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
+    nslice = (rows + k_chunk - 1) / k_chunk;
+    const float gs = grad_opscale(brows, dout);
+    NtGroupBig grp{};
+    grp.count = L;
+    for (int l = 0; l < L; ++l) {  // every weight gradient in one launch: [dW; db] = [H^T; 1^T] dZ
+      NtArgs& g = grp.p[l];
+      g.A = t->d_ht[l]; g.lda = t->Bp;
+      g.B = t->d_dzt[l + 1]; g.ldb = t->Bp;
+      g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = m->dims[l + 1];
+      g.M = m->dims[l] + 1; g.N = m->dims[l + 1]; g.K = rows;
+      g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = (long long)t->P + 4;
+      g.b_scale = gs; g.out_scale = 1.0f / gs;
+    }
+    CHK(launch_nt(t->prec, grp, st));
+    if (nslice > 1) {
+      const long long n4 = ((long long)t->P + 3) / 4;
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
+                         (const float*)t->d_slab, nslice, (long long)t->P + 4, (long long)t->P);
+      HIPCHK(hipGetLastError());
+    }
+  } else {
+    HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
+  }
+  CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
+  t->iter += 1;
+  CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter)));
+  if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+  invalidate_streams(m);
+  m->wpad_ok = true;
+  return V21_OK;
+}
+
+static int gather_batch(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy_src,
                         const float* rw, const int* d_idx, long long first, int rows) {
   v21_mlp* m = t->mlp;
   const int din = m->dims[0], dout = m->dims[m->L];
@@ -1023,10 +1160,8 @@ extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int ba
     const int brows = (int)std::min<long long>(batch, n - first);  // rows of the global batch
     const long long lo = first + (long long)brows * rk / R, hi = first + (long long)brows * (rk + 1) / R;
     const int rows = (int)(hi - lo);
-    if (rows > 0)
-      CHK(gather_batch(t, t->d_x[0], din, t->y_is_x[0] ? nullptr : t->d_y[0], dout, t->d_rw[0], d_idx, lo, rows));
-    const float* yb = t->y_is_x[0] ? t->d_h[0] : t->d_yb;
-    CHK(trainer_step(t, yb, t->y_is_x[0] ? p16(din) : p16(dout), rows, brows, t->d_steploss + s, lo - first));
+    CHK(train_on_rows(t, t->d_x[0], din, t->y_is_x[0] ? nullptr : t->d_y[0], dout, t->d_rw[0], d_idx, lo, rows, brows,
+                      t->d_steploss + s, lo - first));
   }
   std::vector<float> h(steps);
   HIPCHK(hipMemcpyAsync(h.data(), t->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1079,10 +1214,8 @@ extern "C" int v21_trainer_step_dev(v21_trainer* t, const float* d_x, const floa
   v21_mlp* m = t->mlp;
   const int din = m->dims[0], dout = m->dims[m->L];
   if (!d_y && din != dout) return fail(V21_ERR_ARG, "d_y == NULL (y = x) needs in_dim == out_dim");
-  if (n_rows > 0) CHK(gather_batch(t, d_x, din, d_y, dout, d_rw, nullptr, 0, n_rows));
-  const float* yb = d_y ? t->d_yb : t->d_h[0];
-  return trainer_step(t, yb, d_y ? p16(dout) : p16(din), n_rows, global_rows, nullptr,
-                      (long long)t->ctx->rank * t->max_batch);
+  return train_on_rows(t, d_x, din, d_y, dout, d_rw, nullptr, 0, n_rows, global_rows, nullptr,
+                       (long long)t->ctx->rank * t->max_batch);
 }
 extern "C" int v21_trainer_last_step_loss(v21_trainer* t, double* loss) {
   if (!t || !loss) return fail(V21_ERR_ARG, "null argument");
@@ -1359,6 +1492,15 @@ extern "C" int v21_trainer_set_vae(v21_trainer* t, float kl_weight, int sample, 
   if (t->gl < 0) return fail(V21_ERR_STATE, "the stack has no V21_ACT_GAUSS layer");
   if (!(kl_weight >= 0.f)) return fail(V21_ERR_ARG, "kl_weight must be >= 0");
   t->kl_weight = kl_weight; t->sample = sample ? 1 : 0; t->seed = (unsigned long long)seed;
+  return V21_OK;
+}
+extern "C" int v21_trainer_chain_stamps(v21_trainer* t, uint64_t* out, int n) {
+  if (!t || !out) return fail(V21_ERR_ARG, "null argument");
+  if (n < 1 || n > 64) return fail(V21_ERR_ARG, "n must be in [1,64]");
+  if (!t->chain) return fail(V21_ERR_STATE, "this trainer does not use the chain kernel");
+  CHK(use(t->ctx));
+  HIPCHK(hipMemcpyAsync(out, t->d_stamps, (size_t)n * 8, hipMemcpyDeviceToHost, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
   return V21_OK;
 }
 extern "C" int v21_trainer_use_graph(v21_trainer* t, int enable) {

@@ -160,6 +160,11 @@ int v21_trainer_set_state(v21_trainer* tr, int64_t iter, const float* m, const f
 /* gradient of the last step (after all-reduce), for tests */
 int v21_trainer_get_grad(v21_trainer* tr, float* g, size_t n);
 int v21_trainer_use_graph(v21_trainer* tr, int enable);
+/* diagnostics: s_memtime stamps of workgroup 0 of the last chain-kernel launch (train_chain.h):
+ * [0] start, [1] batch gathered, [2..L+1] after forward layer l, [L+2] loss reduced,
+ * [L+3..] after each backward layer (top down).  V21_ERR_STATE when the trainer runs the
+ * per-layer path (f32, variational or >512-wide stacks). */
+int v21_trainer_chain_stamps(v21_trainer* tr, uint64_t* out, int n);
 /* Variational mode of a stack with a V21_ACT_GAUSS layer (A13; build-side extension, no
  * reference arithmetic exists for it): loss_i = recon_i + kl_weight * KL_i,
  * KL_i = -1/2 sum_d (1 + lv - mu^2 - exp lv).  sample = 0 -> eps = 0 (with kl_weight = 0

@@ -25,3 +25,9 @@ t1 = time.perf_counter()
 ctx.sync()
 t2 = time.perf_counter()
 print("B=%d %s: host enqueue %.1f us/step, total %.1f us/step" % (B, prec, (t1 - t0) / steps * 1e6, (t2 - t0) / steps * 1e6))
+try:
+    s = tr.chain_stamps(2 + 5 + 1 + 4).astype(np.int64)
+    d = np.diff(s)
+    print("chain stamps (ticks):", d.tolist(), "total", int(s[-1] - s[0]))
+except Exception as e:
+    print("no stamps:", e)

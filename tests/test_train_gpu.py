@@ -347,3 +347,104 @@ def test_vae_trainer_argument_errors(ctx):
     assert enc.forward(np.zeros((2, 8), np.float32), "f32").shape == (2, 3)
     with pytest.raises(native.EngineError):
         native.Trainer(enc, "f32", 16)  # ... but cannot be trained without a decoder
+
+
+# ---- one-kernel forward + activation-gradient chain (csrc/train_chain.h) --------------------
+def _one_step(ctx, dims, act, prec, x, y, w, perm, batch, chain):
+    import os
+    native = pkg("_native")
+    Ws, bs = ora.init_mlp(dims, seed=31)
+    old = os.environ.get("V21_TRAIN_CHAIN")
+    os.environ["V21_TRAIN_CHAIN"] = "1" if chain else "0"
+    try:
+        st = native.Stack(ctx, dims, act)
+        st.set_weights(ora.flatten_params(Ws, bs))
+        tr = native.Trainer(st, prec, batch)  # the path is chosen when the trainer is created
+    finally:
+        if old is None:
+            os.environ.pop("V21_TRAIN_CHAIN")
+        else:
+            os.environ["V21_TRAIN_CHAIN"] = old
+    tr.set_adam(lr=1e-3)
+    tr.set_data(0, x, y, w)
+    loss = tr.run_epoch(perm, batch)
+    return loss, tr.get_grad().astype(np.float64), st.get_weights(), (Ws, bs)
+
+
+def _cos(a, b):
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("case", ["autoencoder_tail", "direct_7_to_451", "batch_4096"])
+def test_chain_kernel_matches_per_layer_path_and_oracle(ctx, prec, case):
+    """The chain kernel (gather + all forward layers + loss + all activation gradients in one
+    launch) against the per-layer NT path in the same precision, and both against the float64
+    oracle.  Cases: a batch that is not a multiple of 32 drawn through a permutation (y = x);
+    separate targets with a 7-wide input; a batch whose weight gradient is split into slabs."""
+    synth = pkg("synth")
+    if case == "direct_7_to_451":
+        dims, act, n = [7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0], 300
+        par = synth.make_params(n, seed=3)
+        x = ora.par_transform(par, par).astype(np.float32)
+        sig = synth.signals_from_params(par)
+        y = ora.preproc(sig, sig)
+        batch = 300
+    else:
+        dims, act = [451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0]
+        n = 4096 if case == "batch_4096" else 200
+        sig = synth.make_signals(n, seed=13)
+        x = ora.preproc(sig, sig); y = None
+        batch = n
+    w = ora.relative_mse_row_weight(x if y is None else y, sig).astype(np.float32)
+    perm = np.random.default_rng(2).permutation(n).astype(np.int32)
+    lc, gc, wc, (Ws, bs) = _one_step(ctx, dims, act, prec, x, y, w, perm, batch, chain=True)
+    ln, gn, wn, _ = _one_step(ctx, dims, act, prec, x, y, w, perm, batch, chain=False)
+    # float64 oracle of the same step
+    W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
+    xs = x[perm].astype(np.float64); ys = xs if y is None else y[perm].astype(np.float64)
+    acts = [xs]
+    for W_, b_, a_ in zip(W, b, act):
+        z = acts[-1] @ W_ + b_
+        acts.append(np.maximum(z, 0) if a_ else z)
+    lo, dz = ora.batch_loss_and_grad(acts[-1], ys, w[perm].astype(np.float64))
+    dWs, dbs = [None] * len(W), [None] * len(W)
+    for li in range(len(W) - 1, -1, -1):
+        dWs[li] = acts[li].T @ dz; dbs[li] = dz.sum(0)
+        dh = dz @ W[li].T
+        dz = dh * (acts[li] > 0) if li > 0 and act[li - 1] else dh
+    go = ora.flatten_params(dWs, dbs)
+    tol = 2e-3 if prec == "f16" else 2e-2
+    assert abs(lc - lo) / lo < tol and abs(lc - ln) / ln < tol, (lc, ln, lo)
+    assert _cos(gc, go) > (0.9995 if prec == "f16" else 0.995), _cos(gc, go)
+    assert _cos(gc, gn) > (0.9995 if prec == "f16" else 0.995), _cos(gc, gn)
+    assert abs(np.linalg.norm(gc) / np.linalg.norm(go) - 1) < (5e-3 if prec == "f16" else 3e-2)
+    # Adam moved the weights the same way (first step: w -= lr * sign-like update; compare the update)
+    uc, un = wc - ora.flatten_params(Ws, bs), wn - ora.flatten_params(Ws, bs)
+    assert _cos(uc.astype(np.float64), un.astype(np.float64)) > 0.98
+
+
+def test_chain_kernel_trains_and_validates(ctx):
+    """Several epochs through the chain path: the loss falls, the validation pass (per-layer
+    forward on the refreshed weight copies) agrees with the training loss level, and predict()
+    sees the trained weights."""
+    synth = pkg("synth")
+    native = pkg("_native")
+    dims, act = [451, 64, 9, 32, 451], [1, 0, 1, 0]
+    Ws, bs = ora.init_mlp(dims, seed=4)
+    st = native.Stack(ctx, dims, act); st.set_weights(ora.flatten_params(Ws, bs))
+    tr = native.Trainer(st, "f16", 256)
+    sig = synth.make_signals(1000, seed=21)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    tr.set_adam(lr=2e-3); tr.set_data(0, y, None, w); tr.set_data(1, y[:300], None, w[:300])
+    losses = [tr.run_epoch(ora.epoch_permutation(1000, 3, ep), 256) for ep in range(12)]
+    assert losses[-1] < 0.5 * losses[0], losses
+    v = tr.evaluate(1, 256)
+    assert 0.3 * losses[-1] < v < 3 * losses[-1]
+    Wt, bt = ora.unflatten_params(st.get_weights().astype(np.float64), dims)
+    p = y[:50].astype(np.float64)
+    for W_, b_, a_ in zip(Wt, bt, act):
+        p = p @ W_ + b_
+        p = np.maximum(p, 0) if a_ else p
+    np.testing.assert_allclose(st.forward(y[:50], "f32"), p, atol=5e-4, rtol=1e-3)
