@@ -50,25 +50,32 @@ struct ChainLayer {
   float* ht;           // input of this layer, transposed (K x Bp), written here
   float* dzt;          // gradient w.r.t. this layer's output, transposed (N x Bp), written here
 };
-struct ChainArgs {
+// what stays the same from step to step: one per model (a sweep keeps a table of them in HBM)
+struct ChainModel {
   int L;
   ChainLayer lt[16];
   const void* fw; const void* bw;  // packed weight streams
   const float* w;                  // arena (biases)
+  long long Bp;                    // pitch of the transposed buffers
+  float* partial;                  // per-workgroup loss
+  float* loss_out;                 // batch loss (sum over rows): the all-reduce slot
+  float* steploss;                 // nullable: per-step losses of the epoch
+  unsigned* ticket;
+  unsigned long long* stamps;      // diagnostics: s_memtime of workgroup 0 at every phase boundary
+};
+// the batch of this step (shared by every model of a sweep)
+struct ChainStep {
   const float* x; long long ldx;   // source rows
-  const float* y; long long ldy;   // targets (y == x for the autoencoder)
+  const float* y; long long ldy;   // targets (nullptr: y == x, the autoencoder)
   const float* rw;                 // row weights w_i
   const int* idx; long long first; // row m of the batch = source row idx[first + m] (or first + m)
   int rows;                        // rows of this rank's batch
-  long long Bp;                    // pitch of the transposed buffers
   float scale;                     // 2 / B_global
   float gs;                        // gradient operand scale (power of two)
-  float* partial;                  // per-workgroup loss
-  float* loss_out; float* loss_out2;
-  unsigned* ticket;
-  unsigned long long* stamps;  // diagnostics: s_memtime of workgroup 0 at every phase boundary
+  long long step_index;            // >= 0: also store the loss at steploss[step_index]
 };
-__device__ __forceinline__ void chain_stamp(const ChainArgs& a, int i) {
+struct ChainArgs : ChainModel, ChainStep {};
+__device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -77,7 +84,22 @@ __device__ __forceinline__ void chain_stamp(const ChainArgs& a, int i) {
 }
 
 template <class P>
+__device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st);
+
+// one model: everything in the kernel-argument block
+template <class P>
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const ChainArgs a) {
+  train_chain_body<P>(a, a);
+}
+// a sweep: blockIdx.y = model, the per-model blocks in device memory
+template <class P>
+__global__ void __launch_bounds__(64 * kChainWaves) train_chain_group_kernel(const ChainModel* __restrict__ tab,
+                                                                             const ChainStep st) {
+  train_chain_body<P>(tab[blockIdx.y], st);
+}
+
+template <class P>
+__device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st) {
   using frag = typename P::frag;
   using elem = typename P::elem;
   constexpr int NW = kChainWaves, PITCH = kChainPitch;
@@ -98,17 +120,17 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const Cha
   // ---- gather: x[idx] -> buf[0] (compute type) and H0^T (fp32)
   if (tid < 32) {
     const int m = m0 + tid;
-    const bool ok = m < a.rows;
-    const long long s = ok ? (a.idx ? (long long)a.idx[a.first + m] : a.first + m) : 0;
+    const bool ok = m < st.rows;
+    const long long s = ok ? (st.idx ? (long long)st.idx[st.first + m] : st.first + m) : 0;
     srow[tid] = s;
-    rwl[tid] = ok ? a.rw[s] : 0.f;
+    rwl[tid] = ok ? st.rw[s] : 0.f;
   }
   __syncthreads();
   {
     const int K0 = a.lt[0].K, K0p = a.lt[0].KS4 * 16;
     const int m = tid & 31;
-    const bool ok = m0 + m < a.rows;
-    const float* xs = a.x + srow[m] * a.ldx;
+    const bool ok = m0 + m < st.rows;
+    const float* xs = st.x + srow[m] * st.ldx;
     float* ht0 = a.lt[0].ht;
     constexpr int KG = (64 * NW) >> 5, NV = kChainMaxDim / KG;
     float v[NV];  // every load first (one memory round trip), then the stores
@@ -162,7 +184,7 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const Cha
     const int nch = ly.KS4 >> 2;
     const float* bias = a.w + ly.b_off;
     float* htn = last ? nullptr : a.lt[l + 1].ht;
-    const float* yrow = (a.y ? a.y : a.x) + srow[li] * (a.y ? a.ldy : a.ldx);
+    const float* yrow = (st.y ? st.y : st.x) + srow[li] * (st.y ? st.ldy : st.ldx);
     const float wi = rwl[li];
     for (int t = wave; t < ly.NT; t += NW) {
       const int n0 = 32 * t;
@@ -199,7 +221,7 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const Cha
             if (n + e < ly.N) htn[(long long)(n + e) * a.Bp + m0 + li] = acc[4 * g + e];
         }
       } else {  // loss_i = w_i sum_j (p - y)^2,  dL/dp = scale w_i (p - y)
-        const float gsc = a.scale * wi;
+        const float gsc = st.scale * wi;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + 8 * g + 4 * lh;
@@ -211,7 +233,7 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const Cha
             d[e] = gsc * df;
             if (n + e < ly.N) ly.dzt[(long long)(n + e) * a.Bp + m0 + li] = d[e];
           }
-          uint2 pk = {P::pack2(d[0] * a.gs, d[1] * a.gs), P::pack2(d[2] * a.gs, d[3] * a.gs)};
+          uint2 pk = {P::pack2(d[0] * st.gs, d[1] * st.gs), P::pack2(d[2] * st.gs, d[3] * st.gs)};
           *reinterpret_cast<uint2*>(out + li * PITCH + n) = pk;
         }
       }
@@ -255,7 +277,7 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const Cha
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (tid == 0) {
       a.loss_out[0] = (float)s;
-      if (a.loss_out2) a.loss_out2[0] = (float)s;
+      if (a.steploss && st.step_index >= 0) a.steploss[st.step_index] = (float)s;
       *a.ticket = 0u;
     }
   }
@@ -268,7 +290,7 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const Cha
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
     const int nch = ly.NS4 >> 2;
-    const float inv = 1.0f / a.gs;
+    const float inv = 1.0f / st.gs;
     for (int t = wave; t < ly.KT; t += NW) {
       const int k0 = 32 * t;
       f32x16 acc;

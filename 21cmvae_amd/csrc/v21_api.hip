@@ -1020,11 +1020,10 @@ static int gather_batch(v21_trainer* t, const float* x, long long ldx, const flo
                         const float* rw, const int* d_idx, long long first, int rows);
 
 // forward + loss + activation gradients of the chain path: ONE launch (train_chain.h)
-static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
-                        const int* d_idx, long long first, int rows, int brows, float* loss_out2) {
+static ChainModel chain_model(v21_trainer* t) {
   v21_mlp* m = t->mlp;
   const int L = m->L;
-  ChainArgs a{};
+  ChainModel a{};
   a.L = L;
   int mt = 0;
   for (int l = 0; l < L; ++l) {
@@ -1040,27 +1039,43 @@ static int launch_chain(v21_trainer* t, const float* x, long long ldx, const flo
     c.ht = t->d_ht[l]; c.dzt = t->d_dzt[l + 1];
   }
   a.fw = t->d_fw; a.bw = t->d_bw; a.w = m->d_w;
-  a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.rw = rw; a.idx = d_idx; a.first = first;
-  a.rows = rows; a.Bp = t->Bp;
-  a.scale = 2.0f / (float)brows;
-  a.gs = grad_opscale(brows, m->dims[L]);
-  a.partial = t->d_partial; a.loss_out = t->d_g + t->P; a.loss_out2 = loss_out2; a.ticket = t->d_ticket;
+  a.Bp = t->Bp;
+  a.partial = t->d_partial; a.loss_out = t->d_g + t->P; a.steploss = t->d_steploss; a.ticket = t->d_ticket;
   a.stamps = t->d_stamps;
-  static bool attr_done[3] = {false, false, false};
-  const dim3 grid((rows + 31) / 32), block(64 * kChainWaves);
-  if (t->prec == V21_PREC_F16) {
-    if (!attr_done[1]) {
-      HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
-      attr_done[1] = true;
-    }
-    hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
+  return a;
+}
+static ChainStep chain_step(const float* x, long long ldx, const float* y, long long ldy, const float* rw,
+                            const int* d_idx, long long first, int rows, int brows, int dout, long long step_index) {
+  ChainStep st{};
+  st.x = x; st.ldx = ldx; st.y = y; st.ldy = ldy; st.rw = rw; st.idx = d_idx; st.first = first;
+  st.rows = rows;
+  st.scale = 2.0f / (float)brows;
+  st.gs = grad_opscale(brows, dout);
+  st.step_index = step_index;
+  return st;
+}
+static int chain_attr(int prec) {
+  static bool done[3] = {false, false, false};
+  if (done[prec]) return V21_OK;
+  if (prec == V21_PREC_F16) {
+    HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
   } else {
-    if (!attr_done[2]) {
-      HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
-      attr_done[2] = true;
-    }
-    hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
+    HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
   }
+  done[prec] = true;
+  return V21_OK;
+}
+static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
+                        const int* d_idx, long long first, int rows, int brows, long long step_index) {
+  ChainArgs a{};
+  static_cast<ChainModel&>(a) = chain_model(t);
+  static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, t->mlp->dims[t->mlp->L], step_index);
+  CHK(chain_attr(t->prec));
+  const dim3 grid((rows + 31) / 32), block(64 * kChainWaves);
+  if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
+  else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
   HIPCHK(hipGetLastError());
   return V21_OK;
 }
@@ -1081,7 +1096,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
     CHK(ensure_copies(t));
-    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, nullptr));
+    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, -1));
     int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
     const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
     nslice = (rows + k_chunk - 1) / k_chunk;
@@ -1269,6 +1284,9 @@ struct v21_sweep {
   std::vector<v21_trainer*> tr;
   AdamArgs* d_adam = nullptr;
   std::vector<AdamArgs> h_adam;  // what d_adam holds
+  bool chain = false;            // every member runs the chain kernel: one grouped launch of it per step
+  ChainModel* d_chain = nullptr;
+  std::vector<ChainModel> h_chain;
 };
 
 extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** out) {
@@ -1296,6 +1314,9 @@ extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** o
   HIPCHK(hipMalloc((void**)&s->d_adam, (size_t)count * sizeof(AdamArgs)));
   for (int k = 0; k < count; ++k) s->h_adam.push_back(adam_args(trainers[k], true, 0.f));
   HIPCHK(hipMemcpyAsync(s->d_adam, s->h_adam.data(), s->h_adam.size() * sizeof(AdamArgs), hipMemcpyHostToDevice, s->ctx->stream));
+  s->chain = true;
+  for (int k = 0; k < count; ++k) s->chain = s->chain && trainers[k]->chain;
+  if (s->chain) HIPCHK(hipMalloc((void**)&s->d_chain, (size_t)count * sizeof(ChainModel)));
   HIPCHK(hipStreamSynchronize(s->ctx->stream));
   *out = s;
   return V21_OK;
@@ -1305,6 +1326,7 @@ extern "C" int v21_sweep_destroy(v21_sweep* s) {
   hipSetDevice(s->ctx->device);
   hipStreamSynchronize(s->ctx->stream);
   hipFree(s->d_adam);
+  if (s->d_chain) hipFree(s->d_chain);
   delete s;
   return V21_OK;
 }
@@ -1428,6 +1450,73 @@ static int sweep_step(v21_sweep* s, const float* yb, long long ldy, int rows, in
   return V21_OK;
 }
 
+// chain form of a sweep step: ONE launch carries every model's rows through forward, loss and the
+// activation-gradient chain (blockIdx.y = model); then all weight gradients, then all Adam updates
+static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows) {
+  v21_trainer* t0 = s->tr[0];
+  hipStream_t st = s->ctx->stream;
+  const int G = (int)s->tr.size(), L = t0->mlp->L, dout = t0->mlp->dims[L], rows = cs.rows;
+  if (rows > t0->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t0->max_batch);
+  if (rows > 0) {
+    for (v21_trainer* t : s->tr) CHK(ensure_copies(t));
+    CHK(chain_attr(t0->prec));
+    const dim3 grid((rows + 31) / 32, G), block(64 * kChainWaves);
+    if (t0->prec == V21_PREC_F16)
+      hipLaunchKernelGGL(train_chain_group_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, cs);
+    else
+      hipLaunchKernelGGL(train_chain_group_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, cs);
+    HIPCHK(hipGetLastError());
+    int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
+    const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
+    nslice = (rows + k_chunk - 1) / k_chunk;
+    const float gs = grad_opscale(brows, dout);
+    std::vector<NtArgs> probs;
+    for (v21_trainer* t : s->tr) {
+      v21_mlp* m = t->mlp;
+      for (int l = 0; l < L; ++l) {
+        NtArgs g{};
+        g.A = t->d_ht[l]; g.lda = t->Bp;
+        g.B = t->d_dzt[l + 1]; g.ldb = t->Bp;
+        g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = m->dims[l + 1];
+        g.M = m->dims[l] + 1; g.N = m->dims[l + 1]; g.K = rows;
+        g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = (long long)t->P + 4;
+        g.b_scale = gs; g.out_scale = 1.0f / gs;
+        probs.push_back(g);
+      }
+    }
+    CHK(launch_nt_many(t0->prec, probs, st));
+    if (nslice > 1)
+      for (v21_trainer* t : s->tr) {
+        const long long n4 = ((long long)t->P + 3) / 4;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
+                           (const float*)t->d_slab, nslice, (long long)t->P + 4, (long long)t->P);
+        HIPCHK(hipGetLastError());
+      }
+  } else {
+    for (v21_trainer* t : s->tr) HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
+  }
+  AlphaGroup al{};
+  size_t maxP = 0;
+  for (int k = 0; k < G; ++k) {
+    v21_trainer* t = s->tr[k];
+    CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
+    if ((s->ctx->nranks > 1 || rows == 0) && cs.step_index >= 0)
+      HIPCHK(hipMemcpyAsync(t->d_steploss + cs.step_index, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+    t->iter += 1;
+    al.a[k] = adam_alpha(t->adam, t->iter);
+    maxP = std::max(maxP, t->P);
+  }
+  hipLaunchKernelGGL(adam_repack_group_kernel, dim3((unsigned)((maxP + 255) / 256), G), dim3(256), 0, st,
+                     (const AdamArgs*)s->d_adam, al);
+  HIPCHK(hipGetLastError());
+  for (v21_trainer* t : s->tr) {
+    t->copies_ok = true;
+    invalidate_streams(t->mlp);
+    t->mlp->wpad_ok = true;
+  }
+  return V21_OK;
+}
+
 extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch, double* losses) {
   if (!s || !losses) return fail(V21_ERR_ARG, "null argument");
   v21_trainer* t0 = s->tr[0];
@@ -1465,11 +1554,25 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
     HIPCHK(hipStreamSynchronize(st));
   }
   const int din = m->dims[0], dout = m->dims[m->L];
+  if (s->chain) {
+    std::vector<ChainModel> tab;
+    for (v21_trainer* t : s->tr) tab.push_back(chain_model(t));
+    if (tab.size() != s->h_chain.size() || memcmp(tab.data(), s->h_chain.data(), tab.size() * sizeof(ChainModel)) != 0) {
+      s->h_chain = tab;
+      HIPCHK(hipMemcpyAsync(s->d_chain, s->h_chain.data(), tab.size() * sizeof(ChainModel), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  }
   for (long long sidx = 0; sidx < steps; ++sidx) {
     const long long first = sidx * batch;
     const int brows = (int)std::min<long long>(batch, n - first);
     const long long lo = first + (long long)brows * rk / R, hi = first + (long long)brows * (rk + 1) / R;
     const int rows = (int)(hi - lo);
+    if (s->chain) {
+      CHK(sweep_step_chain(s, chain_step(t0->d_x[0], din, t0->y_is_x[0] ? nullptr : t0->d_y[0], dout, t0->d_rw[0], d_idx,
+                                         lo, rows, brows, dout, sidx), brows));
+      continue;
+    }
     if (rows > 0)
       CHK(gather_batch(t0, t0->d_x[0], din, t0->y_is_x[0] ? nullptr : t0->d_y[0], dout, t0->d_rw[0], d_idx, lo, rows));
     const float* yb = t0->y_is_x[0] ? t0->d_h[0] : t0->d_yb;

@@ -14,26 +14,30 @@ CONFIGS = [dict(latent_dim=4, enc_hidden_dims=[32], dec_hidden_dims=[16, 32]),
            dict(latent_dim=12, enc_hidden_dims=[96], dec_hidden_dims=[48, 64])]
 
 
-def _models(sig, seed):
+def _models(sig, seed, precision="f32"):
     emulator, optm, eng = pkg("emulator"), pkg("optimizers"), pkg("engine")
     eng.set_random_seed(seed)
     out = []
     for c in CONFIGS:
         ae = emulator.AutoEncoder(sig, **c)
+        ae.precision = precision
         ae.build((None, 451))
         ae.compile(optimizer=optm.Adam(1e-3), loss=emulator.relative_mse_loss(sig))
         out.append(ae)
     return out
 
 
-@pytest.mark.parametrize("n,batch", [(300, 128), (700, 600)])
-def test_sweep_equals_individual_fits(n, batch):
+@pytest.mark.parametrize("n,batch,precision", [(300, 128, "f32"), (700, 600, "f32"), (300, 128, "f16"), (700, 600, "bf16")])
+def test_sweep_equals_individual_fits(n, batch, precision):
     synth, eng, sweep = pkg("synth"), pkg("engine"), pkg("sweep")
     sig = synth.make_signals(n, seed=3)
     val = synth.make_signals(60, seed=4)
     y, yv = ora.preproc(sig, sig), ora.preproc(val, sig)
-    solo = _models(sig, 11)
-    grouped = _models(sig, 11)
+    solo = _models(sig, 11, precision)
+    grouped = _models(sig, 11, precision)
+    # f32: same kernels, same order.  f16/bf16 (chain kernel): the grouped weight-gradient launch may pick
+    # another tile size than a single model's, i.e. another summation order of rounded products
+    ltol, wtol = (2e-5, 2e-6) if precision == "f32" else (2e-3, 2e-3)
     for a, b in zip(solo, grouped):
         for wa, wb in zip(a.get_weights(), b.get_weights()):
             np.testing.assert_array_equal(wa, wb)
@@ -44,10 +48,10 @@ def test_sweep_equals_individual_fits(n, batch):
     eng.set_random_seed(5)
     hg = sweep.fit_models(grouped, y, y, batch_size=batch, epochs=3, validation_data=(yv, yv))
     for a, b, ha, hb in zip(solo, grouped, hs, hg):
-        np.testing.assert_allclose(hb.history["loss"], ha.history["loss"], rtol=2e-5)
-        np.testing.assert_allclose(hb.history["val_loss"], ha.history["val_loss"], rtol=2e-5)
+        np.testing.assert_allclose(hb.history["loss"], ha.history["loss"], rtol=ltol)
+        np.testing.assert_allclose(hb.history["val_loss"], ha.history["val_loss"], rtol=ltol)
         for wa, wb in zip(a.get_weights(), b.get_weights()):
-            np.testing.assert_allclose(wb, wa, atol=2e-6, rtol=1e-4)
+            np.testing.assert_allclose(wb, wa, atol=wtol, rtol=1e-4)
         assert b.optimizer.iterations == a.optimizer.iterations == 3 * -(-n // batch)
 
 
