@@ -260,6 +260,7 @@ struct AdamArgs {
   int do_adam, L;
   void *fw, *bw;  // packed compute-type weight streams of train_chain.h (cprec != 0)
   int cprec;      // 0: none, 1: f16, 2: bf16
+  int skip_nt;    // leave the fp32 W^T / padded-W copies alone (chain steps do not read them)
   AdamLayer lt[16];
 };
 __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha);
@@ -292,8 +293,10 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
   const long long r = i - L.w_off;
   if (r < (long long)L.K * L.N) {  // a kernel element (biases have no copies)
     const int k = (int)(r / L.N), n = (int)(r % L.N);
-    a.wt[L.wt_off + (long long)n * L.ldwt + k] = wi;
-    a.wp[L.wp_off + (long long)k * L.ldwp + n] = wi;
+    if (!a.skip_nt) {
+      a.wt[L.wt_off + (long long)n * L.ldwt + k] = wi;
+      a.wp[L.wp_off + (long long)k * L.ldwp + n] = wi;
+    }
     if (a.cprec) {
       // forward fragment (tile n/32, k-step k/16): lane = 32*((k%16)/8) + n%32, element k%8
       const long long pf = L.fw_off + ((((long long)(n >> 5) * L.KS4 + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 3) + (k & 7);

@@ -648,6 +648,7 @@ struct v21_trainer {
   float *d_wt = nullptr, *d_wp = nullptr;
   std::vector<long long> wt_off, wp_off;
   bool copies_ok = false;
+  bool nt_ok = false;  // the fp32 W^T / padded-W copies of the per-layer path are fresh (chain steps skip them)
   float* d_yb = nullptr;
   float* d_wb = nullptr;
   float* d_rowloss = nullptr;
@@ -865,15 +866,16 @@ static int launch_nt(int prec, GROUP& grp, hipStream_t st) {
 }
 
 // Adam (do_adam) and/or refresh of the W^T / padded-W copies from the arena
-static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha);
-static int adam_and_copies(v21_trainer* t, bool do_adam, float alpha) {
-  const AdamArgs a = adam_args(t, do_adam, alpha);
+static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_nt = false);
+static int adam_and_copies(v21_trainer* t, bool do_adam, float alpha, bool skip_nt = false) {
+  const AdamArgs a = adam_args(t, do_adam, alpha, skip_nt);
   hipLaunchKernelGGL(adam_repack_kernel, dim3((unsigned)((t->P + 255) / 256)), dim3(256), 0, t->ctx->stream, a);
   HIPCHK(hipGetLastError());
   t->copies_ok = true;
+  t->nt_ok = !skip_nt;
   return V21_OK;
 }
-static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha) {
+static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_nt) {
   v21_mlp* m = t->mlp;
   AdamArgs a{};
   a.w = m->d_w; a.m = t->d_m; a.v = t->d_v; a.g = t->d_g; a.wt = t->d_wt; a.wp = t->d_wp;
@@ -889,11 +891,13 @@ static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha) {
     }
   }
   if (t->chain) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->prec == V21_PREC_F16 ? 1 : 2; }
+  a.skip_nt = (skip_nt && t->chain) ? 1 : 0;
   return a;
 }
-static int ensure_copies(v21_trainer* t) {
+// need_nt: the caller reads the fp32 copies (per-layer forward/backward); chain steps do not
+static int ensure_copies(v21_trainer* t, bool need_nt = true) {
   // the arena may have been rewritten behind our back (set_weights): wpad_ok doubles as the dirty flag
-  if (t->copies_ok && t->mlp->wpad_ok) return V21_OK;
+  if (t->copies_ok && t->mlp->wpad_ok && (t->nt_ok || !need_nt)) return V21_OK;
   CHK(adam_and_copies(t, false, 0.f));
   t->mlp->wpad_ok = true;
   return V21_OK;
@@ -1095,7 +1099,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   hipStream_t st = t->ctx->stream;
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
-    CHK(ensure_copies(t));
+    CHK(ensure_copies(t, false));
     CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, -1));
     int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
     const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
@@ -1124,7 +1128,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   }
   CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
   t->iter += 1;
-  CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter)));
+  CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter), true));
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
   invalidate_streams(m);
   m->wpad_ok = true;
@@ -1312,10 +1316,10 @@ extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** o
   s->ctx = t0->ctx;
   s->tr.assign(trainers, trainers + count);
   HIPCHK(hipMalloc((void**)&s->d_adam, (size_t)count * sizeof(AdamArgs)));
-  for (int k = 0; k < count; ++k) s->h_adam.push_back(adam_args(trainers[k], true, 0.f));
-  HIPCHK(hipMemcpyAsync(s->d_adam, s->h_adam.data(), s->h_adam.size() * sizeof(AdamArgs), hipMemcpyHostToDevice, s->ctx->stream));
   s->chain = true;
   for (int k = 0; k < count; ++k) s->chain = s->chain && trainers[k]->chain;
+  for (int k = 0; k < count; ++k) s->h_adam.push_back(adam_args(trainers[k], true, 0.f, s->chain));
+  HIPCHK(hipMemcpyAsync(s->d_adam, s->h_adam.data(), s->h_adam.size() * sizeof(AdamArgs), hipMemcpyHostToDevice, s->ctx->stream));
   if (s->chain) HIPCHK(hipMalloc((void**)&s->d_chain, (size_t)count * sizeof(ChainModel)));
   HIPCHK(hipStreamSynchronize(s->ctx->stream));
   *out = s;
@@ -1443,7 +1447,7 @@ static int sweep_step(v21_sweep* s, const float* yb, long long ldy, int rows, in
                      (const AdamArgs*)s->d_adam, al);
   HIPCHK(hipGetLastError());
   for (v21_trainer* t : s->tr) {
-    t->copies_ok = true;
+    t->copies_ok = true; t->nt_ok = true;
     invalidate_streams(t->mlp);
     t->mlp->wpad_ok = true;
   }
@@ -1458,7 +1462,7 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows) {
   const int G = (int)s->tr.size(), L = t0->mlp->L, dout = t0->mlp->dims[L], rows = cs.rows;
   if (rows > t0->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t0->max_batch);
   if (rows > 0) {
-    for (v21_trainer* t : s->tr) CHK(ensure_copies(t));
+    for (v21_trainer* t : s->tr) CHK(ensure_copies(t, false));
     CHK(chain_attr(t0->prec));
     const dim3 grid((rows + 31) / 32, G), block(64 * kChainWaves);
     if (t0->prec == V21_PREC_F16)
@@ -1510,7 +1514,7 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows) {
                      (const AdamArgs*)s->d_adam, al);
   HIPCHK(hipGetLastError());
   for (v21_trainer* t : s->tr) {
-    t->copies_ok = true;
+    t->copies_ok = true; t->nt_ok = false;
     invalidate_streams(t->mlp);
     t->mlp->wpad_ok = true;
   }
@@ -1547,7 +1551,7 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
     }
   // the Adam hyper-parameters may have changed since create (set_adam / set_lr): refresh the device table
   std::vector<AdamArgs> tab;
-  for (v21_trainer* t : s->tr) tab.push_back(adam_args(t, true, 0.f));
+  for (v21_trainer* t : s->tr) tab.push_back(adam_args(t, true, 0.f, s->chain));
   if (memcmp(tab.data(), s->h_adam.data(), tab.size() * sizeof(AdamArgs)) != 0) {
     s->h_adam = tab;
     HIPCHK(hipMemcpyAsync(s->d_adam, s->h_adam.data(), tab.size() * sizeof(AdamArgs), hipMemcpyHostToDevice, st));
