@@ -47,8 +47,10 @@ struct ChainLayer {
   int mask_tile;       // first tile of this layer's output mask in LDS (-1: none)
   long long fw_off, bw_off;  // fragment offsets (units of 8 elements) into the packed streams
   long long b_off;     // bias offset in the arena
-  float* ht;           // input of this layer, transposed (K x Bp), written here
-  float* dzt;          // gradient w.r.t. this layer's output, transposed (N x Bp), written here
+  // operands of the weight gradient (gemm_dw16_kernel below), written here in MFMA-fragment order:
+  // element (feature f, batch row b) at ((f/32 * BS + b/16) * 64 + 32*((b%16)/8) + f%32) * 8 + b%8
+  void* ht16;          // input of this layer (K features; feature K is a constant row of ones)
+  void* dzt16;         // gs * gradient w.r.t. this layer's output (N features)
 };
 // what stays the same from step to step: one per model (a sweep keeps a table of them in HBM)
 struct ChainModel {
@@ -56,7 +58,7 @@ struct ChainModel {
   ChainLayer lt[16];
   const void* fw; const void* bw;  // packed weight streams
   const float* w;                  // arena (biases)
-  long long Bp;                    // pitch of the transposed buffers
+  long long BS;                    // batch steps of 16 per feature tile of the transposed buffers
   float* partial;                  // per-workgroup loss
   float* loss_out;                 // batch loss (sum over rows): the all-reduce slot
   float* steploss;                 // nullable: per-step losses of the epoch
@@ -131,7 +133,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const int m = tid & 31;
     const bool ok = m0 + m < st.rows;
     const float* xs = st.x + srow[m] * st.ldx;
-    float* ht0 = a.lt[0].ht;
     constexpr int KG = (64 * NW) >> 5, NV = kChainMaxDim / KG;
     float v[NV];  // every load first (one memory round trip), then the stores
 #pragma unroll
@@ -143,7 +144,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     for (int i = 0; i < NV; ++i) {
       const int k = (tid >> 5) + KG * i;
       if (k < K0p) buf[0][m * PITCH + k] = (elem)v[i];
-      if (k < K0) ht0[(long long)k * a.Bp + m0 + m] = v[i];
     }
   }
   __syncthreads();
@@ -153,6 +153,21 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   const frag* bw = reinterpret_cast<const frag*>(a.bw);
   float lsum = 0.f;  // this lane's share of the row losses
   int cur = 0;
+
+  // the 32 rows x F features in `act` -> fragment-ordered transposed copy (16 bytes per store: 8 batch
+  // rows of one feature); rows past the end of the batch are written as zeros
+  auto flush_t = [&](const elem* act, int F, void* dst) {
+    const int F32 = (F + 31) & ~31;
+    frag* d = reinterpret_cast<frag*>(dst);
+    for (int i = tid; i < 4 * F32; i += 64 * NW) {
+      const int q = i / F32, f = i % F32;
+      if (f >= F) continue;
+      frag v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (m0 + 8 * q + j < st.rows) ? act[(8 * q + j) * PITCH + f] : (elem)0.f;
+      d[((long long)(f >> 5) * a.BS + (m0 >> 4) + (q >> 1)) * 64 + (q & 1) * 32 + (f & 31)] = v;
+    }
+  };
 
   // one 32-wide tile: acc(rows = features of the tile, col = batch row li) over `nch` chunks of 4 k-steps
   auto contract = [&](const frag* wsrc, const elem* act, int nch, f32x16& acc) {
@@ -183,7 +198,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     elem* out = buf[cur ^ 1];
     const int nch = ly.KS4 >> 2;
     const float* bias = a.w + ly.b_off;
-    float* htn = last ? nullptr : a.lt[l + 1].ht;
+    flush_t(act, ly.K, ly.ht16);  // this layer's input -> operand of its weight gradient
     const float* yrow = (st.y ? st.y : st.x) + srow[li] * (st.y ? st.ldy : st.ldx);
     const float wi = rwl[li];
     for (int t = wave; t < ly.NT; t += NW) {
@@ -216,9 +231,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
           const int n = n0 + 8 * g + 4 * lh;
           uint2 pk = {P::pack2(acc[4 * g], acc[4 * g + 1]), P::pack2(acc[4 * g + 2], acc[4 * g + 3])};
           *reinterpret_cast<uint2*>(out + li * PITCH + n) = pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < ly.N) htn[(long long)(n + e) * a.Bp + m0 + li] = acc[4 * g + e];
         }
       } else {  // loss_i = w_i sum_j (p - y)^2,  dL/dp = scale w_i (p - y)
         const float gsc = st.scale * wi;
@@ -231,7 +243,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
             const float df = n + e < ly.N ? acc[4 * g + e] - yv[4 * g + e] : 0.f;
             lsum += df * df;
             d[e] = gsc * df;
-            if (n + e < ly.N) ly.dzt[(long long)(n + e) * a.Bp + m0 + li] = d[e];
           }
           uint2 pk = {P::pack2(d[0] * st.gs, d[1] * st.gs), P::pack2(d[2] * st.gs, d[3] * st.gs)};
           *reinterpret_cast<uint2*>(out + li * PITCH + n) = pk;
@@ -290,7 +301,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
     const int nch = ly.NS4 >> 2;
-    const float inv = 1.0f / st.gs;
+    flush_t(act, ly.N, ly.dzt16);  // gs * dZ of this layer's output -> operand of its weight gradient
     for (int t = wave; t < ly.KT; t += NW) {
       const int k0 = 32 * t;
       f32x16 acc;
@@ -307,9 +318,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
         const int k = k0 + 8 * g + 4 * lh;
         uint2 pk = {P::pack2(acc[4 * g], acc[4 * g + 1]), P::pack2(acc[4 * g + 2], acc[4 * g + 3])};
         *reinterpret_cast<uint2*>(out + li * PITCH + k) = pk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + e < ly.K) below.dzt[(long long)(k + e) * a.Bp + m0 + li] = acc[4 * g + e] * inv;
       }
     }
     {
@@ -323,6 +331,98 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     cur ^= 1;
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
+  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16);
+}
+
+// ---- weight gradients from the fragment-ordered operands: [dW; db](k, n) = sum_b HT(k, b) dZT(n, b).
+// 64x64 output tile per 256-thread workgroup; the four waves split the batch range of the slice,
+// every fragment is one 1-KiB wave load straight into MFMA operand registers (no conversion, no
+// masking: rows past the batch are zeros); partial tiles meet in LDS; slices -> slabs (fixed order).
+struct Dw16Args {
+  const void* A; const void* B;  // ht16 (M = K+1 features), dzt16 (N features)
+  float* C; long long ldc;       // slab z at C + z*slab_stride
+  int M, N;
+  int nx, ny, nz;                // 64-tiles along N, along M; batch slices
+  int steps, steps_per_slice;    // batch steps of 16 in all / per slice
+  long long BS;
+  long long slab_stride;
+  float out_scale;
+};
+struct Dw16Group {
+  Dw16Args p[kNtMaxGroup];
+  int first[kNtMaxGroup + 1];
+  int count;
+};
+template <class P>
+__global__ void __launch_bounds__(256) gemm_dw16_kernel(const Dw16Group grp) {
+  using frag = typename P::frag;
+  int pi = 0;
+  while (pi + 1 < grp.count && (int)blockIdx.x >= grp.first[pi + 1]) ++pi;
+  const Dw16Args& g = grp.p[pi];
+  const int bid = blockIdx.x - grp.first[pi];
+  const int bx = bid % g.nx, by = (bid / g.nx) % g.ny, bz = bid / (g.nx * g.ny);
+  __shared__ __attribute__((aligned(16))) float part[4][4][16][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int sbeg = bz * g.steps_per_slice, send = min(g.steps, sbeg + g.steps_per_slice);
+  const int per = (send - sbeg + 3) / 4;
+  const int s0 = sbeg + wave * per, s1 = min(send, s0 + per);
+  const frag* A = reinterpret_cast<const frag*>(g.A);
+  const frag* B = reinterpret_cast<const frag*>(g.B);
+  const frag* ap[2] = {A + ((long long)(2 * by) * g.BS) * 64 + lane, A + ((long long)(2 * by + 1) * g.BS) * 64 + lane};
+  const frag* bp[2] = {B + ((long long)(2 * bx) * g.BS) * 64 + lane, B + ((long long)(2 * bx + 1) * g.BS) * 64 + lane};
+  // feature tiles past the end of the operand (odd tile counts) are clamped: their rows are never stored
+  const int mt = (g.M + 31) / 32, nt = (g.N + 31) / 32;
+  if (2 * by + 1 >= mt) ap[1] = ap[0];
+  if (2 * bx + 1 >= nt) bp[1] = bp[0];
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  constexpr int MAXS = kNtMaxKPerWg / 16 / 4;  // 8 batch steps per wave
+  frag fa[MAXS][2], fb[MAXS][2];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s0 + s < s1) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[s][t] = ap[t][(long long)(s0 + s) * 64];
+        fb[s][t] = bp[t][(long long)(s0 + s) * 64];
+      }
+    }
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s0 + s < s1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = P::template mfma<false>(fa[s][i], fb[s][j], acc[i][j]);
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wave][2 * i + j][r][lane] = acc[i][j][r];
+  __syncthreads();
+  float* C = g.C + (long long)bz * g.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = 64 * bx + 32 * j + li;
+      const int mrow = 64 * by + 32 * i + 8 * wave + 4 * lh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int reg = 4 * wave + e, tt = 2 * i + j;
+        const float v = ((part[0][tt][reg][lane] + part[1][tt][reg][lane]) + (part[2][tt][reg][lane] + part[3][tt][reg][lane])) * g.out_scale;
+        if (n < g.N && mrow + e < g.M) C[(long long)(mrow + e) * g.ldc + n] = v;
+      }
+    }
 }
 
 }  // namespace v21

@@ -670,6 +670,8 @@ struct v21_trainer {
   std::vector<long long> fw_off, bw_off;  // element offsets per layer
   float* d_partial = nullptr;
   unsigned* d_ticket = nullptr;
+  std::vector<void*> d_ht16, d_dzt16;  // fragment-ordered weight-gradient operands (train_chain.h)
+  long long BS = 0;                    // batch steps of 16 per feature tile
   unsigned long long* d_stamps = nullptr;
 };
 
@@ -749,6 +751,22 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
       CHK(zalloc(&t->d_partial, (size_t)(max_batch + 31) / 32 + 4, st));
       HIPCHK(hipMalloc((void**)&t->d_ticket, 16)); HIPCHK(hipMemsetAsync(t->d_ticket, 0, 16, st));
       HIPCHK(hipMalloc((void**)&t->d_stamps, 64 * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, 64 * 8, st));
+      t->BS = ((long long)max_batch + 31) / 32 * 2 + 2;
+      t->d_ht16.assign(L + 1, nullptr); t->d_dzt16.assign(L + 1, nullptr);
+      const unsigned short one = precision == V21_PREC_F16 ? 0x3C00 : 0x3F80;
+      for (int l = 0; l < L; ++l) {
+        const int K = m->dims[l], N = m->dims[l + 1];
+        const size_t na = (size_t)((K + 1 + 31) / 32) * t->BS * 512, nb = (size_t)((N + 31) / 32) * t->BS * 512;
+        HIPCHK(hipMalloc(&t->d_ht16[l], na * 2)); HIPCHK(hipMemsetAsync(t->d_ht16[l], 0, na * 2, st));
+        HIPCHK(hipMalloc(&t->d_dzt16[l + 1], nb * 2)); HIPCHK(hipMemsetAsync(t->d_dzt16[l + 1], 0, nb * 2, st));
+        // feature K of the input operand: the constant row of ones that turns [dW; db] into one contraction
+        std::vector<unsigned short> tile((size_t)t->BS * 512, 0);
+        for (long long b = 0; b < t->BS * 16; ++b)
+          tile[(size_t)((b >> 4) * 64 + ((b >> 3) & 1) * 32 + (K & 31)) * 8 + (b & 7)] = one;
+        // (only element f%32 == K%32 of the last feature tile is set; the chain kernel writes features < K only)
+        HIPCHK(hipMemcpyAsync((char*)t->d_ht16[l] + (size_t)(K >> 5) * t->BS * 1024, tile.data(), tile.size() * 2, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+      }
       t->chain = true;
     }
   }
@@ -775,7 +793,9 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   if (t->d_steploss) hipFree(t->d_steploss);
   if (t->d_slab) hipFree(t->d_slab);
   if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
-  if (t->chain) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_partial); hipFree(t->d_ticket); hipFree(t->d_stamps); }
+  if (t->chain) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_partial); hipFree(t->d_ticket); hipFree(t->d_stamps);
+    for (void* p : t->d_ht16) if (p) hipFree(p);
+    for (void* p : t->d_dzt16) if (p) hipFree(p); }
   delete t;
   return V21_OK;
 }
@@ -1040,10 +1060,10 @@ static ChainModel chain_model(v21_trainer* t) {
     if (c.relu && l + 1 < L) { c.mask_tile = mt; mt += c.NT; }
     c.fw_off = t->fw_off[l] / 8; c.bw_off = t->bw_off[l] / 8;
     c.b_off = m->b_off[l];
-    c.ht = t->d_ht[l]; c.dzt = t->d_dzt[l + 1];
+    c.ht16 = t->d_ht16[l]; c.dzt16 = t->d_dzt16[l + 1];
   }
   a.fw = t->d_fw; a.bw = t->d_bw; a.w = m->d_w;
-  a.Bp = t->Bp;
+  a.BS = t->BS;
   a.partial = t->d_partial; a.loss_out = t->d_g + t->P; a.steploss = t->d_steploss; a.ticket = t->d_ticket;
   a.stamps = t->d_stamps;
   return a;
@@ -1084,6 +1104,47 @@ static int launch_chain(v21_trainer* t, const float* x, long long ldx, const flo
   return V21_OK;
 }
 
+// weight gradients of chain-mode trainers: problems in groups of <= 16 per launch
+static void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, std::vector<Dw16Args>& probs) {
+  v21_mlp* m = t->mlp;
+  const int L = m->L;
+  const int steps = (rows + 15) / 16;
+  int nslice = (steps + 31) / 32;
+  const int sps = (steps + nslice - 1) / nslice;
+  nslice = (steps + sps - 1) / sps;
+  const float gs = grad_opscale(brows, m->dims[L]);
+  for (int l = 0; l < L; ++l) {
+    Dw16Args g{};
+    g.A = t->d_ht16[l]; g.B = t->d_dzt16[l + 1];
+    g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = m->dims[l + 1];
+    g.M = m->dims[l] + 1; g.N = m->dims[l + 1];
+    g.nx = (g.N + 63) / 64; g.ny = (g.M + 63) / 64; g.nz = nslice;
+    g.steps = steps; g.steps_per_slice = sps; g.BS = t->BS;
+    g.slab_stride = (long long)t->P + 4;
+    g.out_scale = 1.0f / gs;
+    probs.push_back(g);
+  }
+  *nslice_out = nslice;
+}
+static int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t st) {
+  for (size_t o = 0; o < probs.size(); o += kNtMaxGroup) {
+    Dw16Group grp{};
+    grp.count = (int)std::min<size_t>(kNtMaxGroup, probs.size() - o);
+    int blocks = 0;
+    for (int i = 0; i < grp.count; ++i) {
+      grp.p[i] = probs[o + i];
+      grp.first[i] = blocks;
+      blocks += grp.p[i].nx * grp.p[i].ny * grp.p[i].nz;
+    }
+    grp.first[grp.count] = blocks;
+    if (blocks <= 0) continue;
+    if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_kernel<PrecF16>, dim3(blocks), dim3(256), 0, st, grp);
+    else hipLaunchKernelGGL(gemm_dw16_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, st, grp);
+    HIPCHK(hipGetLastError());
+  }
+  return V21_OK;
+}
+
 static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out,
                         long long row0);
 // one optimizer step on rows [first, first+rows) (through d_idx when given) of (x, y, rw)
@@ -1101,22 +1162,10 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   if (rows > 0) {
     CHK(ensure_copies(t, false));
     CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, -1));
-    int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
-    const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
-    nslice = (rows + k_chunk - 1) / k_chunk;
-    const float gs = grad_opscale(brows, dout);
-    NtGroupBig grp{};
-    grp.count = L;
-    for (int l = 0; l < L; ++l) {  // every weight gradient in one launch: [dW; db] = [H^T; 1^T] dZ
-      NtArgs& g = grp.p[l];
-      g.A = t->d_ht[l]; g.lda = t->Bp;
-      g.B = t->d_dzt[l + 1]; g.ldb = t->Bp;
-      g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = m->dims[l + 1];
-      g.M = m->dims[l] + 1; g.N = m->dims[l + 1]; g.K = rows;
-      g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = (long long)t->P + 4;
-      g.b_scale = gs; g.out_scale = 1.0f / gs;
-    }
-    CHK(launch_nt(t->prec, grp, st));
+    int nslice = 1;
+    std::vector<Dw16Args> probs;
+    dw16_problems(t, rows, brows, &nslice, probs);  // every weight gradient in one launch: [dW; db] = [H^T; 1^T] dZ
+    CHK(launch_dw16(t->prec, probs, st));
     if (nslice > 1) {
       const long long n4 = ((long long)t->P + 3) / 4;
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
@@ -1470,25 +1519,10 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows) {
     else
       hipLaunchKernelGGL(train_chain_group_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, cs);
     HIPCHK(hipGetLastError());
-    int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
-    const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
-    nslice = (rows + k_chunk - 1) / k_chunk;
-    const float gs = grad_opscale(brows, dout);
-    std::vector<NtArgs> probs;
-    for (v21_trainer* t : s->tr) {
-      v21_mlp* m = t->mlp;
-      for (int l = 0; l < L; ++l) {
-        NtArgs g{};
-        g.A = t->d_ht[l]; g.lda = t->Bp;
-        g.B = t->d_dzt[l + 1]; g.ldb = t->Bp;
-        g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = m->dims[l + 1];
-        g.M = m->dims[l] + 1; g.N = m->dims[l + 1]; g.K = rows;
-        g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = (long long)t->P + 4;
-        g.b_scale = gs; g.out_scale = 1.0f / gs;
-        probs.push_back(g);
-      }
-    }
-    CHK(launch_nt_many(t0->prec, probs, st));
+    int nslice = 1;
+    std::vector<Dw16Args> probs;
+    for (v21_trainer* t : s->tr) dw16_problems(t, rows, brows, &nslice, probs);
+    CHK(launch_dw16(t0->prec, probs, st));
     if (nslice > 1)
       for (v21_trainer* t : s->tr) {
         const long long n4 = ((long long)t->P + 3) / 4;
