@@ -37,7 +37,9 @@ constexpr int kChainWaves = 8;
 constexpr int kChainMaskTiles = 112;
 constexpr int kChainBufBytes = 2 * 32 * kChainPitch * 2;
 constexpr int kChainMaskBytes = kChainMaskTiles * 64 * 2;
-constexpr int kChainLdsBytes = kChainBufBytes + kChainMaskBytes + kChainWaves * 32 * 4 + 32 * 4 + 32 * 8 + 16;
+constexpr int kChainYPitch = kChainMaxDim + 4;  // floats; 2064 B = 16 B mod 128 B
+constexpr int kChainSmallBytes = kChainWaves * 32 * 4 + 32 * 4 + 32 * 8 + 16;
+constexpr int kChainLdsBytes = kChainBufBytes + kChainMaskBytes + kChainSmallBytes + 32 * kChainYPitch * 4;
 
 struct ChainLayer {
   int K, N;            // Dense input / output width
@@ -59,10 +61,9 @@ struct ChainModel {
   const void* fw; const void* bw;  // packed weight streams
   const float* w;                  // arena (biases)
   long long BS;                    // batch steps of 16 per feature tile of the transposed buffers
-  float* partial;                  // per-workgroup loss
-  float* loss_out;                 // batch loss (sum over rows): the all-reduce slot
-  float* steploss;                 // nullable: per-step losses of the epoch
-  unsigned* ticket;
+  // batch loss: every workgroup adds its rows' losses as 2^-32 fixed point (an integer sum does not
+  // depend on the order of arrival); gemm_dw16_kernel turns it into the float slot and clears it
+  unsigned long long* loss_acc;
   unsigned long long* stamps;      // diagnostics: s_memtime of workgroup 0 at every phase boundary
 };
 // the batch of this step (shared by every model of a sweep)
@@ -74,7 +75,6 @@ struct ChainStep {
   int rows;                        // rows of this rank's batch
   float scale;                     // 2 / B_global
   float gs;                        // gradient operand scale (power of two)
-  long long step_index;            // >= 0: also store the loss at steploss[step_index]
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
@@ -111,7 +111,8 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   float(*red)[32] = reinterpret_cast<float(*)[32]>(chain_smem + kChainBufBytes + kChainMaskBytes);
   float* rwl = reinterpret_cast<float*>(chain_smem + kChainBufBytes + kChainMaskBytes + NW * 32 * 4);
   long long* srow = reinterpret_cast<long long*>(rwl + 32);
-  int& is_last = *reinterpret_cast<int*>(srow + 32);
+  float* ystg = reinterpret_cast<float*>(chain_smem + kChainBufBytes + kChainMaskBytes + kChainSmallBytes);
+  constexpr int YP = kChainYPitch;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,22 +129,31 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     rwl[tid] = ok ? st.rw[s] : 0.f;
   }
   __syncthreads();
-  {
-    const int K0 = a.lt[0].K, K0p = a.lt[0].KS4 * 16;
-    const int m = tid & 31;
-    const bool ok = m0 + m < st.rows;
-    const float* xs = st.x + srow[m] * st.ldx;
-    constexpr int KG = (64 * NW) >> 5, NV = kChainMaxDim / KG;
-    float v[NV];  // every load first (one memory round trip), then the stores
+  {  // wave w moves rows 4w..4w+3, lanes run along the row (256-byte segments); targets stay in LDS as fp32
+    const int K0 = a.lt[0].K, K0p = a.lt[0].KS4 * 16, DO = a.lt[a.L - 1].N;
+    float v[4][8], yv[4][8];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int k = (tid >> 5) + KG * i;
-      v[i] = (ok && k < K0) ? xs[k] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * wave + r;
+      const bool ok = m0 + m < st.rows;
+      const float* xs = st.x + srow[m] * st.ldx;
+      const float* ys = st.y ? st.y + srow[m] * st.ldy : xs;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = lane + 64 * i;
+        v[r][i] = (ok && k < K0) ? xs[k] : 0.f;
+        if (st.y) yv[r][i] = (ok && k < DO) ? ys[k] : 0.f;
+      }
     }
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int k = (tid >> 5) + KG * i;
-      if (k < K0p) buf[0][m * PITCH + k] = (elem)v[i];
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * wave + r;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = lane + 64 * i;
+        if (k < K0p) buf[0][m * PITCH + k] = (elem)v[r][i];
+        ystg[m * YP + k] = st.y ? yv[r][i] : v[r][i];
+      }
     }
   }
   __syncthreads();
@@ -199,7 +209,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const int nch = ly.KS4 >> 2;
     const float* bias = a.w + ly.b_off;
     flush_t(act, ly.K, ly.ht16);  // this layer's input -> operand of its weight gradient
-    const float* yrow = (st.y ? st.y : st.x) + srow[li] * (st.y ? st.ldy : st.ldx);
     const float wi = rwl[li];
     for (int t = wave; t < ly.NT; t += NW) {
       const int n0 = 32 * t;
@@ -208,14 +217,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         acc[r] = n < ly.N ? bias[n] : 0.f;
-      }
-      float yv[16];
-      if (last) {  // targets of this tile: in flight together with the weights
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = n0 + 8 * (r >> 2) + 4 * lh + (r & 3);
-          yv[r] = n < ly.N ? yrow[n] : 0.f;
-        }
       }
       contract(fw + ly.fw_off + ((long long)t * ly.KS4) * 64 + lane, act, nch, acc);
       if (!last) {
@@ -237,10 +238,11 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + 8 * g + 4 * lh;
+          const f32x4 yq = *reinterpret_cast<const f32x4*>(ystg + li * YP + n);
           float d[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float df = n + e < ly.N ? acc[4 * g + e] - yv[4 * g + e] : 0.f;
+            const float df = n + e < ly.N ? acc[4 * g + e] - yq[e] : 0.f;
             lsum += df * df;
             d[e] = gsc * df;
           }
@@ -262,7 +264,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     chain_stamp(a, 2 + l);
   }
 
-  // ---- loss: lanes -> rows -> workgroup, fixed order
+  // ---- loss: lanes -> rows -> workgroup (fixed order) -> one fixed-point atomic per workgroup
   lsum += __shfl_xor(lsum, 32, 64);
   if (lh == 0) red[wave][li] = lsum * rwl[li];
   __syncthreads();
@@ -272,25 +274,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     for (int w = 0; w < NW; ++w) s += red[w][tid];
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (tid == 0) {
-      a.partial[blockIdx.x] = s;
-      __threadfence();
-      const unsigned tk = atomicAdd(a.ticket, 1u);
-      is_last = tk == gridDim.x - 1;
-    }
-  }
-  __syncthreads();
-  if (is_last && tid < 64) {  // the last workgroup to get here adds the partials in block order
-    __threadfence();
-    double s = 0.0;
-    for (int i = tid; i < (int)gridDim.x; i += 64) s += (double)a.partial[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (tid == 0) {
-      a.loss_out[0] = (float)s;
-      if (a.steploss && st.step_index >= 0) a.steploss[st.step_index] = (float)s;
-      *a.ticket = 0u;
-    }
+    if (tid == 0) atomicAdd(a.loss_acc, (unsigned long long)(long long)llrint((double)s * 4294967296.0));
   }
 
   chain_stamp(a, 2 + a.L);
@@ -347,6 +331,8 @@ struct Dw16Args {
   long long BS;
   long long slab_stride;
   float out_scale;
+  // on the first problem of a model: fixed-point batch loss -> float slot(s), accumulator cleared
+  unsigned long long* loss_acc; float* loss_out; float* loss_out2;
 };
 struct Dw16Group {
   Dw16Args p[kNtMaxGroup];
@@ -361,6 +347,12 @@ __global__ void __launch_bounds__(256) gemm_dw16_kernel(const Dw16Group grp) {
   const Dw16Args& g = grp.p[pi];
   const int bid = blockIdx.x - grp.first[pi];
   const int bx = bid % g.nx, by = (bid / g.nx) % g.ny, bz = bid / (g.nx * g.ny);
+  if (g.loss_acc && bid == 0 && threadIdx.x == 0) {
+    const float f = (float)((double)(long long)*g.loss_acc * (1.0 / 4294967296.0));
+    *g.loss_out = f;
+    if (g.loss_out2) *g.loss_out2 = f;
+    *g.loss_acc = 0ull;
+  }
   __shared__ __attribute__((aligned(16))) float part[4][4][16][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

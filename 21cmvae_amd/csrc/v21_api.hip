@@ -1064,18 +1064,17 @@ static ChainModel chain_model(v21_trainer* t) {
   }
   a.fw = t->d_fw; a.bw = t->d_bw; a.w = m->d_w;
   a.BS = t->BS;
-  a.partial = t->d_partial; a.loss_out = t->d_g + t->P; a.steploss = t->d_steploss; a.ticket = t->d_ticket;
+  a.loss_acc = (unsigned long long*)t->d_ticket;
   a.stamps = t->d_stamps;
   return a;
 }
 static ChainStep chain_step(const float* x, long long ldx, const float* y, long long ldy, const float* rw,
-                            const int* d_idx, long long first, int rows, int brows, int dout, long long step_index) {
+                            const int* d_idx, long long first, int rows, int brows, int dout) {
   ChainStep st{};
   st.x = x; st.ldx = ldx; st.y = y; st.ldy = ldy; st.rw = rw; st.idx = d_idx; st.first = first;
   st.rows = rows;
   st.scale = 2.0f / (float)brows;
   st.gs = grad_opscale(brows, dout);
-  st.step_index = step_index;
   return st;
 }
 static int chain_attr(int prec) {
@@ -1092,10 +1091,10 @@ static int chain_attr(int prec) {
   return V21_OK;
 }
 static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
-                        const int* d_idx, long long first, int rows, int brows, long long step_index) {
+                        const int* d_idx, long long first, int rows, int brows) {
   ChainArgs a{};
   static_cast<ChainModel&>(a) = chain_model(t);
-  static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, t->mlp->dims[t->mlp->L], step_index);
+  static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, t->mlp->dims[t->mlp->L]);
   CHK(chain_attr(t->prec));
   const dim3 grid((rows + 31) / 32), block(64 * kChainWaves);
   if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
@@ -1105,7 +1104,8 @@ static int launch_chain(v21_trainer* t, const float* x, long long ldx, const flo
 }
 
 // weight gradients of chain-mode trainers: problems in groups of <= 16 per launch
-static void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, std::vector<Dw16Args>& probs) {
+static void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, std::vector<Dw16Args>& probs,
+                          float* loss_out2 = nullptr) {
   v21_mlp* m = t->mlp;
   const int L = m->L;
   const int steps = (rows + 15) / 16;
@@ -1122,6 +1122,7 @@ static void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, 
     g.steps = steps; g.steps_per_slice = sps; g.BS = t->BS;
     g.slab_stride = (long long)t->P + 4;
     g.out_scale = 1.0f / gs;
+    if (l == 0) { g.loss_acc = (unsigned long long*)t->d_ticket; g.loss_out = t->d_g + t->P; g.loss_out2 = loss_out2; }
     probs.push_back(g);
   }
   *nslice_out = nslice;
@@ -1161,7 +1162,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
     CHK(ensure_copies(t, false));
-    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, -1));
+    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows));
     int nslice = 1;
     std::vector<Dw16Args> probs;
     dw16_problems(t, rows, brows, &nslice, probs);  // every weight gradient in one launch: [dW; db] = [H^T; 1^T] dZ
@@ -1505,7 +1506,7 @@ static int sweep_step(v21_sweep* s, const float* yb, long long ldy, int rows, in
 
 // chain form of a sweep step: ONE launch carries every model's rows through forward, loss and the
 // activation-gradient chain (blockIdx.y = model); then all weight gradients, then all Adam updates
-static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows) {
+static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long long step_index) {
   v21_trainer* t0 = s->tr[0];
   hipStream_t st = s->ctx->stream;
   const int G = (int)s->tr.size(), L = t0->mlp->L, dout = t0->mlp->dims[L], rows = cs.rows;
@@ -1521,7 +1522,9 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows) {
     HIPCHK(hipGetLastError());
     int nslice = 1;
     std::vector<Dw16Args> probs;
-    for (v21_trainer* t : s->tr) dw16_problems(t, rows, brows, &nslice, probs);
+    for (v21_trainer* t : s->tr)
+      dw16_problems(t, rows, brows, &nslice, probs,
+                    (s->ctx->nranks == 1 && step_index >= 0) ? t->d_steploss + step_index : nullptr);
     CHK(launch_dw16(t0->prec, probs, st));
     if (nslice > 1)
       for (v21_trainer* t : s->tr) {
@@ -1538,8 +1541,8 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows) {
   for (int k = 0; k < G; ++k) {
     v21_trainer* t = s->tr[k];
     CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
-    if ((s->ctx->nranks > 1 || rows == 0) && cs.step_index >= 0)
-      HIPCHK(hipMemcpyAsync(t->d_steploss + cs.step_index, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((s->ctx->nranks > 1 || rows == 0) && step_index >= 0)
+      HIPCHK(hipMemcpyAsync(t->d_steploss + step_index, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
     t->iter += 1;
     al.a[k] = adam_alpha(t->adam, t->iter);
     maxP = std::max(maxP, t->P);
@@ -1608,7 +1611,7 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
     const int rows = (int)(hi - lo);
     if (s->chain) {
       CHK(sweep_step_chain(s, chain_step(t0->d_x[0], din, t0->y_is_x[0] ? nullptr : t0->d_y[0], dout, t0->d_rw[0], d_idx,
-                                         lo, rows, brows, dout, sidx), brows));
+                                         lo, rows, brows, dout), brows, sidx));
       continue;
     }
     if (rows > 0)
