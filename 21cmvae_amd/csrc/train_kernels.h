@@ -261,6 +261,9 @@ struct AdamArgs {
   void *fw, *bw;  // packed compute-type weight streams of train_chain.h (cprec != 0)
   int cprec;      // 0: none, 1: f16, 2: bf16
   int skip_nt;    // leave the fp32 W^T / padded-W copies alone (chain steps do not read them)
+  // split-K slabs of the weight gradient still to be summed (single rank: the separate
+  // reduce_slabs launch is folded in here; g is rewritten with the sum, same fixed order)
+  float* gw; const float* slab; int nslab; long long slab_stride;
   AdamLayer lt[16];
 };
 __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha);
@@ -280,7 +283,14 @@ __global__ void adam_repack_group_kernel(const AdamArgs* __restrict__ tab, const
 __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha) {
   float wi = a.w[i];
   if (a.do_adam) {
-    const float gi = a.g[i];
+    float gi;
+    if (a.nslab > 1) {
+      gi = a.slab[i];
+      for (int k = 1; k < a.nslab; ++k) gi += a.slab[k * a.slab_stride + i];
+      a.gw[i] = gi;
+    } else {
+      gi = a.g[i];
+    }
     const float mi = a.m[i] + (gi - a.m[i]) * a.omb1;
     const float vi = a.v[i] + (gi * gi - a.v[i]) * a.omb2;
     a.m[i] = mi; a.v[i] = vi;

@@ -887,8 +887,9 @@ static int launch_nt(int prec, GROUP& grp, hipStream_t st) {
 
 // Adam (do_adam) and/or refresh of the W^T / padded-W copies from the arena
 static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_nt = false);
-static int adam_and_copies(v21_trainer* t, bool do_adam, float alpha, bool skip_nt = false) {
-  const AdamArgs a = adam_args(t, do_adam, alpha, skip_nt);
+static int adam_and_copies(v21_trainer* t, bool do_adam, float alpha, bool skip_nt = false, int nslab = 1) {
+  AdamArgs a = adam_args(t, do_adam, alpha, skip_nt);
+  if (nslab > 1) { a.gw = t->d_g; a.slab = t->d_slab; a.nslab = nslab; a.slab_stride = (long long)t->P + 4; }
   hipLaunchKernelGGL(adam_repack_kernel, dim3((unsigned)((t->P + 255) / 256)), dim3(256), 0, t->ctx->stream, a);
   HIPCHK(hipGetLastError());
   t->copies_ok = true;
@@ -1159,6 +1160,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     return trainer_step(t, yb, y ? p16(dout) : p16(din), rows, brows, loss_out, row0);
   }
   hipStream_t st = t->ctx->stream;
+  int fold = 1;
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
     CHK(ensure_copies(t, false));
@@ -1167,7 +1169,8 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     std::vector<Dw16Args> probs;
     dw16_problems(t, rows, brows, &nslice, probs);  // every weight gradient in one launch: [dW; db] = [H^T; 1^T] dZ
     CHK(launch_dw16(t->prec, probs, st));
-    if (nslice > 1) {
+    fold = nslice > 1 && t->ctx->nranks == 1 ? nslice : 1;  // single rank: Adam sums the slabs itself
+    if (nslice > 1 && fold == 1) {
       const long long n4 = ((long long)t->P + 3) / 4;
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
                          (const float*)t->d_slab, nslice, (long long)t->P + 4, (long long)t->P);
@@ -1178,7 +1181,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   }
   CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
   t->iter += 1;
-  CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter), true));
+  CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter), true, fold));
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
   invalidate_streams(m);
   m->wpad_ok = true;
