@@ -23,6 +23,15 @@ import time
 
 import numpy as np
 
+# numpy's BLAS pool (one spinning thread per host core after every matmul of the data
+# set-up) competes with the thread that enqueues kernels: the GPU legs run with the pool limited
+# to one thread; cpu_baseline (run last) lifts the limit.
+try:
+    from threadpoolctl import threadpool_limits
+    _BLAS_LIMIT = threadpool_limits(limits=1)
+except Exception:
+    _BLAS_LIMIT = None
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -49,6 +58,8 @@ def cpu_baseline(weights_flat, x_f32, budget_s=12.0):
     """The CPU oracle (numpy fp32 restatement, oracle/ref_numpy.py) on a bounded sample of
     the same workload: 8,192 of the 65,536 rows per pass, repeated for ~budget_s."""
     from oracle import ref_numpy as ora
+    if _BLAS_LIMIT is not None:
+        _BLAS_LIMIT.restore_original_limits()  # the baseline gets every host core
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
@@ -317,10 +328,6 @@ def main():
             stack.forward(params, args.precision, flags)
         out["host_roundtrip_signals_per_s"] = B * reps / (time.perf_counter() - t0)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        xt = pp.par_transform(params.astype(np.float64), par_train).astype(np.float32)
-        out["cpu_baseline"] = cpu_baseline(wflat, xt)
-
     if not args.no_train and not args.no_extras:
         try:  # before the communicator exists: the models of a sweep are independent per rank
             out["sweep"] = sweep_leg(native, ctx, args.precision)
@@ -343,6 +350,10 @@ def main():
                                                           sync_all, 256, "f32", 200, 10)
         except Exception as e:  # the headline metric must survive a failure of the auxiliary leg
             out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # last: see _BLAS_LIMIT
+        xt = pp.par_transform(params.astype(np.float64), par_train).astype(np.float32)
+        out["cpu_baseline"] = cpu_baseline(wflat, xt)
 
     barrier()
     if rank == 0:
