@@ -448,3 +448,51 @@ def test_chain_kernel_trains_and_validates(ctx):
         p = p @ W_ + b_
         p = np.maximum(p, 0) if a_ else p
     np.testing.assert_allclose(st.forward(y[:50], "f32"), p, atol=5e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dims,act,n", [
+    ([451, 451], [0], 70),                         # one layer: the loss epilogue is also the first layer
+    ([33, 500, 512, 17], [1, 1, 0], 45),           # widths that are not multiples of 16/32, the 512 limit
+    ([7, 64, 3], [1, 0], 1),                       # a single row
+    ([20, 40, 8, 40, 20], [1, 0, 1, 0], 257),      # linear layer inside, batch one past a block boundary
+])
+def test_chain_kernel_odd_shapes(ctx, dims, act, n):
+    """Edge shapes of the chain path against the float64 oracle: gradient direction and norm, loss."""
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(n, dims[0])).astype(np.float32)
+    y = None if dims[0] == dims[-1] and len(dims) > 2 else rng.normal(size=(n, dims[-1])).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, size=n).astype(np.float32) / dims[-1]
+    perm = rng.permutation(n).astype(np.int32)
+    lc, gc, _, (Ws, bs) = _one_step(ctx, dims, act, "f16", x, y, w, perm, max(n, 2), chain=True)
+    W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
+    xs = x[perm].astype(np.float64); ys = xs if y is None else y[perm].astype(np.float64)
+    acts = [xs]
+    for W_, b_, a_ in zip(W, b, act):
+        z = acts[-1] @ W_ + b_
+        acts.append(np.maximum(z, 0) if a_ else z)
+    lo, dz = ora.batch_loss_and_grad(acts[-1], ys, w[perm].astype(np.float64))
+    dWs, dbs = [None] * len(W), [None] * len(W)
+    for li in range(len(W) - 1, -1, -1):
+        dWs[li] = acts[li].T @ dz; dbs[li] = dz.sum(0)
+        dh = dz @ W[li].T
+        dz = dh * (acts[li] > 0) if li > 0 and act[li - 1] else dh
+    go = ora.flatten_params(dWs, dbs)
+    assert abs(lc - lo) / lo < 3e-3, (lc, lo)
+    assert _cos(gc, go) > 0.9995, _cos(gc, go)
+    assert abs(np.linalg.norm(gc) / np.linalg.norm(go) - 1) < 5e-3
+
+
+def test_chain_path_is_actually_used(ctx):
+    """f16/bf16 trainers of stacks up to 512 wide run the chain kernel (its stamps exist); f32, wide
+    and variational stacks take the per-layer path."""
+    native = pkg("_native")
+    st = native.Stack(ctx, [16, 32, 16], [1, 0])
+    x = np.zeros((8, 16), np.float32); w = np.ones(8, np.float32)
+    tr = native.Trainer(st, "f16", 8); tr.set_data(0, x, None, w); tr.run_epoch(None, 8)
+    s = tr.chain_stamps(6)
+    assert s[0] > 0 and np.all(np.diff(s.astype(np.int64)[:5]) > 0)
+    for stack, prec in ((st, "f32"), (native.Stack(ctx, [16, 600, 16], [1, 0]), "f16"),
+                        (native.Stack(ctx, [16, 8, 16], [2, 0]), "bf16")):
+        t2 = native.Trainer(stack, prec, 8)
+        with pytest.raises(native.EngineError):
+            t2.chain_stamps(4)
