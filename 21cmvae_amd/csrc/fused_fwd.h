@@ -152,11 +152,8 @@ struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 4, 
 struct PrecF16x2 : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
 struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
 #endif
-// tuning variants of the x2 kernel (A/B only: scripts/ab_fused.py, V21_FUSED_TUNE)
-struct PrecF16x2b : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2, DEPTH = 3; };
-struct PrecF16x2c : PrecF16 { static constexpr int CT = 1, BLK = 20, RING = 4, WPS = 2, DEPTH = 2; };
-struct PrecF16x2d : PrecF16 { static constexpr int CT = 1, BLK = 12, RING = 6, WPS = 2, DEPTH = 2; };
-struct PrecF16x2e : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2, DEPTH = 1; };
+// (A/B-tested and dropped in round 1: read-ahead depth 1/3 and ring geometries 20x4 / 12x6 -- all within
+// 0.5 % of the 16x5, depth-2 configuration above)
 
 // ---- compile-time geometry of (architecture, precision) ---------------------------
 // Arch::L layers, Arch::dims[L+1], Arch::act[L] (1 = ReLU).  The last layer is the

@@ -200,10 +200,6 @@ V21_ARCH_LIST(V21_DECL2)
   hipError_t launch_fused_##a##_BF16s16(const FusedArgs&, int, hipStream_t);
 V21_ARCH_LIST(V21_DECL3)
 #undef V21_DECL3
-hipError_t launch_fused_S1_F16x2b(const FusedArgs&, int, hipStream_t);
-hipError_t launch_fused_S1_F16x2c(const FusedArgs&, int, hipStream_t);
-hipError_t launch_fused_S1_F16x2d(const FusedArgs&, int, hipStream_t);
-hipError_t launch_fused_S1_F16x2e(const FusedArgs&, int, hipStream_t);
 }  // namespace v21
 
 typedef hipError_t (*fused_launcher)(const FusedArgs&, int, hipStream_t);
@@ -527,12 +523,6 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
     }
     a.phase_ctr = m->d_phase;
     a.delay_sleeps = delay;
-    const char* tune = getenv("V21_FUSED_TUNE");
-    if (tune && m->fused_id == 0 && precision == V21_PREC_F16 && *tune >= 'b' && *tune <= 'e') {
-      fused_launcher tf[] = {launch_fused_S1_F16x2b, launch_fused_S1_F16x2c, launch_fused_S1_F16x2d, launch_fused_S1_F16x2e};
-      HIPCHK(tf[*tune - 'b'](a, pin, m->ctx->stream));
-      return V21_OK;
-    }
     HIPCHK(g_fused[m->fused_id].fn_x2[precision](a, pin, m->ctx->stream));
     return V21_OK;
   }
