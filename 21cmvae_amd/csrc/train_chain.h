@@ -110,7 +110,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   unsigned short(*masks)[64] = reinterpret_cast<unsigned short(*)[64]>(chain_smem + kChainBufBytes);
   float(*red)[32] = reinterpret_cast<float(*)[32]>(chain_smem + kChainBufBytes + kChainMaskBytes);
   float* rwl = reinterpret_cast<float*>(chain_smem + kChainBufBytes + kChainMaskBytes + NW * 32 * 4);
-  long long* srow = reinterpret_cast<long long*>(rwl + 32);
   float* ystg = reinterpret_cast<float*>(chain_smem + kChainBufBytes + kChainMaskBytes + kChainSmallBytes);
   constexpr int YP = kChainYPitch;
 
@@ -121,28 +120,29 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
 
   chain_stamp(a, 0);
   // ---- gather: x[idx] -> buf[0] (compute type) and H0^T (fp32)
-  if (tid < 32) {
-    const int m = m0 + tid;
-    const bool ok = m < st.rows;
-    const long long s = ok ? (st.idx ? (long long)st.idx[st.first + m] : st.first + m) : 0;
-    srow[tid] = s;
-    rwl[tid] = ok ? st.rw[s] : 0.f;
-  }
-  __syncthreads();
-  {  // wave w moves rows 4w..4w+3, lanes run along the row (256-byte segments); targets stay in LDS as fp32
+  {  // wave w moves rows 4w..4w+3, lanes run along the row (256-byte segments); targets stay in LDS as fp32.
+     // Two dependent round trips: the wave's four row indices, then rows + row weights together.
     const int K0 = a.lt[0].K, K0p = a.lt[0].KS4 * 16, DO = a.lt[a.L - 1].N;
-    float v[4][8], yv[4][8];
+    long long sr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = 4 * wave + r;
-      const bool ok = m0 + m < st.rows;
-      const float* xs = st.x + srow[m] * st.ldx;
-      const float* ys = st.y ? st.y + srow[m] * st.ldy : xs;
+      const int m = m0 + 4 * wave + r;  // wave-uniform: scalar loads
+      sr[r] = m < st.rows ? (st.idx ? (long long)st.idx[st.first + m] : st.first + m) : 0;
+    }
+    if (lane < 4) {
+      const int m = 4 * wave + lane;
+      const long long s = lane == 0 ? sr[0] : lane == 1 ? sr[1] : lane == 2 ? sr[2] : sr[3];
+      rwl[m] = m0 + m < st.rows ? st.rw[s] : 0.f;
+    }
+    float v[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = m0 + 4 * wave + r < st.rows;
+      const float* xs = st.x + sr[r] * st.ldx;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = lane + 64 * i;
         v[r][i] = (ok && k < K0) ? xs[k] : 0.f;
-        if (st.y) yv[r][i] = (ok && k < DO) ? ys[k] : 0.f;
       }
     }
 #pragma unroll
@@ -152,8 +152,24 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       for (int i = 0; i < 8; ++i) {
         const int k = lane + 64 * i;
         if (k < K0p) buf[0][m * PITCH + k] = (elem)v[r][i];
-        ystg[m * YP + k] = st.y ? yv[r][i] : v[r][i];
+        if (!st.y) ystg[m * YP + k] = v[r][i];
       }
+    }
+    if (st.y) {  // separate targets: a second pass through the same registers
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = m0 + 4 * wave + r < st.rows;
+        const float* ys = st.y + sr[r] * st.ldy;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = lane + 64 * i;
+          v[r][i] = (ok && k < DO) ? ys[k] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ystg[(4 * wave + r) * YP + lane + 64 * i] = v[r][i];
     }
   }
   __syncthreads();
@@ -166,10 +182,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
 
   // the 32 rows x F features in `act` -> fragment-ordered transposed copy (16 bytes per store: 8 batch
   // rows of one feature); rows past the end of the batch are written as zeros
-  auto flush_t = [&](const elem* act, int F, void* dst) {
+  // `tiles`: tile count of the contraction that follows -- the waves that get one tile fewer do the flush
+  auto flush_t = [&](const elem* act, int F, void* dst, int tiles) {
     const int F32 = (F + 31) & ~31;
     frag* d = reinterpret_cast<frag*>(dst);
-    for (int i = tid; i < 4 * F32; i += 64 * NW) {
+    const int w0 = tiles % NW;  // waves [0, w0) carry the extra tile (w0 == 0: all alike)
+    if (wave < w0) return;
+    for (int i = tid - 64 * w0; i < 4 * F32; i += 64 * (NW - w0)) {
       const int q = i / F32, f = i % F32;
       if (f >= F) continue;
       frag v;
@@ -189,14 +208,20 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
         for (int j = 0; j < 4; ++j) wv[4 * c + j] = wsrc[(4 * c + j) * 64];
       }
     const elem* ap = act + li * PITCH + 8 * lh;
+    frag bc[4], bn[4];  // activation fragments of chunk c+1 are read from LDS under the MFMAs of chunk c
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bc[j] = *reinterpret_cast<const frag*>(ap + j * 16);
 #pragma unroll
     for (int c = 0; c < 8; ++c)
       if (c < nch) {
+        if (c + 1 < nch) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const frag bv = *reinterpret_cast<const frag*>(ap + (4 * c + j) * 16);
-          acc = P::template mfma<false>(wv[4 * c + j], bv, acc);
+          for (int j = 0; j < 4; ++j) bn[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 1) + j) * 16);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = P::template mfma<false>(wv[4 * c + j], bc[j], acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bc[j] = bn[j];
       }
   };
 
@@ -208,7 +233,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     elem* out = buf[cur ^ 1];
     const int nch = ly.KS4 >> 2;
     const float* bias = a.w + ly.b_off;
-    flush_t(act, ly.K, ly.ht16);  // this layer's input -> operand of its weight gradient
+    flush_t(act, ly.K, ly.ht16, ly.NT);  // this layer's input -> operand of its weight gradient
     const float wi = rwl[li];
     for (int t = wave; t < ly.NT; t += NW) {
       const int n0 = 32 * t;
@@ -285,7 +310,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
     const int nch = ly.NS4 >> 2;
-    flush_t(act, ly.N, ly.dzt16);  // gs * dZ of this layer's output -> operand of its weight gradient
+    flush_t(act, ly.N, ly.dzt16, ly.KT);  // gs * dZ of this layer's output -> operand of its weight gradient
     for (int t = wave; t < ly.KT; t += NW) {
       const int k0 = 32 * t;
       f32x16 acc;
@@ -315,7 +340,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     cur ^= 1;
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
-  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16);
+  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
 }
 
 // ---- weight gradients from the fragment-ordered operands: [dW; db](k, n) = sum_b HT(k, b) dZT(n, b).

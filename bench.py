@@ -339,17 +339,32 @@ def main():
             out["sweep"]["model_steps_per_s_grouped_all_ranks"] = float(t.item())
 
     if not args.no_train:
-        try:
-            if world > 1:
-                importlib.import_module("21cmvae_amd.parallel").init_engine_comm(ctx)
-            tl = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
-                           args.train_batch, args.precision, args.train_steps, 5)
-            out["train"] = tl
-            if world == 1 and not args.no_extras:
-                out["train_ref_batch256_f32"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
-                                                          sync_all, 256, "f32", 200, 10)
-        except Exception as e:  # the headline metric must survive a failure of the auxiliary leg
-            out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        def run_train():
+            try:
+                if world > 1:
+                    importlib.import_module("21cmvae_amd.parallel").init_engine_comm(ctx)
+                tl = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
+                               args.train_batch, args.precision, args.train_steps, 5)
+                out["train"] = tl
+                if world == 1 and not args.no_extras:
+                    out["train_ref_batch256_f32"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
+                                                              sync_all, 256, "f32", 200, 10)
+            except Exception as e:  # the headline metric must survive a failure of the auxiliary leg
+                out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world > 1:
+            # a communicator that never comes up must not take the headline number with it: the leg runs
+            # in a thread, and a rank that is still waiting after the limit reports and leaves
+            import threading
+            th = threading.Thread(target=run_train, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("V21_BENCH_TRAIN_TIMEOUT", "150")))
+            if th.is_alive():
+                out["train"] = {"error": "timeout: the data-parallel training leg did not finish"}
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        else:
+            run_train()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # last: see _BLAS_LIMIT
         xt = pp.par_transform(params.astype(np.float64), par_train).astype(np.float32)
