@@ -95,7 +95,7 @@ struct FusedArgs {
 // i % EPI of item (16/EPI)*nt + i / EPI of the next layer's operand, and element e of
 // item ku held by lane half h is feature  FPI*ku + 8*(e>>2) + 4*h + (e&3).
 struct PrecF16 {
-  static constexpr int BLK = 24, RING = 4, WPS = 1, DEPTH = 2;  // 96 KiB ring, one wave per SIMD
+  static constexpr int BLK = 24, RING = 4, WPS = 1, DEPTH = 2, WAVES = 4;  // 96 KiB ring, one wave per SIMD
   using frag = f16x8;
   using elem = _Float16;
   static constexpr int FPI = 16, EPI = 8, CT = 2;
@@ -111,7 +111,7 @@ struct PrecF16 {
   }
 };
 struct PrecBF16 {
-  static constexpr int BLK = 24, RING = 4, WPS = 1, DEPTH = 2;  // 96 KiB ring, one wave per SIMD
+  static constexpr int BLK = 24, RING = 4, WPS = 1, DEPTH = 2, WAVES = 4;  // 96 KiB ring, one wave per SIMD
   using frag = bf16x8;
   using elem = __bf16;
   static constexpr int FPI = 16, EPI = 8, CT = 2;
@@ -127,7 +127,7 @@ struct PrecBF16 {
 };
 // exact f32: v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain (no reduced precision)
 struct PrecF32 {
-  static constexpr int BLK = 24, RING = 4, WPS = 1, DEPTH = 2;
+  static constexpr int BLK = 24, RING = 4, WPS = 1, DEPTH = 2, WAVES = 4;
   using frag = f32x4;
   using elem = float;
   static constexpr int FPI = 8, EPI = 4, CT = 1;
@@ -152,6 +152,11 @@ struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 4, 
 struct PrecF16x2 : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
 struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
 #endif
+// Variant "w8": the two waves of a SIMD belong to ONE 512-thread workgroup and share one ring, so every
+// weight fragment is pulled into the CU once for 256 signals instead of once per 128 (half the L2->LDS
+// stream per CU; ring up to 144 KiB since a single workgroup owns the CU's LDS).
+struct PrecF16w8 : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 9, WPS = 1, WAVES = 8; };
+struct PrecBF16w8 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 9, WPS = 1, WAVES = 8; };
 // (A/B-tested and dropped in round 1: read-ahead depth 1/3 and ring geometries 20x4 / 12x6 -- all within
 // 0.5 % of the 16x5, depth-2 configuration above)
 
@@ -161,7 +166,7 @@ struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 5, 
 template <class Arch, class P> struct Geo {
   static constexpr int L = Arch::L;
   static constexpr int FPI = P::FPI;
-  static constexpr int BLK = P::BLK, RING = P::RING;
+  static constexpr int BLK = P::BLK, RING = P::RING, WAVES = P::WAVES;
   static constexpr int IPT = 16 / P::EPI;  // operand items produced per 32-wide tile
   static constexpr int dim(int i) { return Arch::dims[i]; }
   static constexpr int act(int l) { return Arch::act[l]; }
@@ -174,12 +179,12 @@ template <class Arch, class P> struct Geo {
     return f + nt * (ks_of(l) + 1);
   }
   static constexpr int total() { return tile_base(L, 0); }
-  static constexpr int padded() { return (total() + 3) / 4 * 4; }
+  static constexpr int padded() { return (total() + 7) / 8 * 8; }
   static constexpr int n_blocks() { return (padded() + BLK - 1) / BLK; }
   static constexpr int blk_glds(int b) {  // LDS-DMA instructions per wave in block b
     if (b < 0 || b >= n_blocks()) return 0;
     const int rem = padded() - b * BLK;
-    return (rem < BLK ? rem : BLK) / kWaves;
+    return (rem < BLK ? rem : BLK) / WAVES;
   }
   static constexpr int ks_max() {
     int m = 0;
@@ -279,7 +284,7 @@ __device__ __forceinline__ void issue_block(const unsigned char* gstream, unsign
     const unsigned s = lds_addr(smem) + (B % G::RING) * G::BLK * kFragBytes + wave * kFragBytes;
     static_for<NG>([&](auto i) __attribute__((always_inline)) {
       constexpr int I = decltype(i)::value;
-      glds16(g + I * kWaves * kFragBytes, voff, s + I * kWaves * kFragBytes);
+      glds16(g + I * G::WAVES * kFragBytes, voff, s + I * G::WAVES * kFragBytes);
     });
   }
 }
@@ -294,10 +299,10 @@ __device__ __forceinline__ void issue_piece(const unsigned char* gstream, unsign
                                             int wave, int lane) {
   if constexpr (B >= 0 && B < G::n_blocks()) {
     if constexpr (I < G::blk_glds(B)) {
-      const unsigned char* g = gstream + (size_t)B * G::BLK * kFragBytes + I * kWaves * kFragBytes;
+      const unsigned char* g = gstream + (size_t)B * G::BLK * kFragBytes + I * G::WAVES * kFragBytes;
       const unsigned voff = wave * kFragBytes + lane * 16;
       const unsigned s = lds_addr(smem) + (B % G::RING) * G::BLK * kFragBytes + wave * kFragBytes +
-                         I * kWaves * kFragBytes;
+                         I * G::WAVES * kFragBytes;
       glds16(g, voff, s);
     }
   }
@@ -350,9 +355,10 @@ template <class G, int F> __device__ __forceinline__ const unsigned char* frag_p
 __device__ __forceinline__ unsigned to_areg(unsigned v) { return v; }
 
 // ---- the kernel -------------------------------------------------------------------
-// grid.x = ceil(n_rows / (kWaves*CT*32)); block = 256 threads; dynamic LDS fused_lds<P>().
+// grid.x = ceil(n_rows / (WAVES*CT*32)); block = 64*WAVES threads; dynamic LDS fused_lds<P>().
 template <class Arch, class P, bool PIN>
-__global__ void __launch_bounds__(256, P::WPS) fused_fwd(const FusedArgs a) {
+__global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedArgs a) {
+  constexpr int kWaves = P::WAVES;
   constexpr int kBlkFrags = P::BLK, kRing = P::RING, kFusedLds = fused_lds<P>();
   (void)kFusedLds;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

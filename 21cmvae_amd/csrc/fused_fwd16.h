@@ -44,7 +44,7 @@ struct PrecBF16s16 {
 // ---- compile-time geometry: n-tiles of 16 outputs, k-steps of 32 features ---------------
 template <class Arch, class P> struct Geo16 {
   static constexpr int L = Arch::L;
-  static constexpr int BLK = P::BLK, RING = P::RING, CB = P::CB;
+  static constexpr int BLK = P::BLK, RING = P::RING, CB = P::CB, WAVES = kWaves;
   static constexpr int NCH = CB * 2;  // epilogue chunks per tile: (column block, register pair)
   static constexpr int dim(int i) { return Arch::dims[i]; }
   static constexpr int act(int l) { return Arch::act[l]; }

@@ -23,10 +23,10 @@ static hipError_t launch_one(const FusedArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  constexpr int rows = kWaves * P::CT * 32;
+  constexpr int rows = P::WAVES * P::CT * 32;
   const long long nwg = (a.n_rows + rows - 1) / rows;
   if (nwg <= 0) return hipSuccess;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), fused_lds_alloc<P>(), st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * P::WAVES), fused_lds_alloc<P>(), st, a);
   return hipGetLastError();
 }
 

@@ -200,6 +200,11 @@ V21_ARCH_LIST(V21_DECL2)
   hipError_t launch_fused_##a##_BF16s16(const FusedArgs&, int, hipStream_t);
 V21_ARCH_LIST(V21_DECL3)
 #undef V21_DECL3
+#define V21_DECL4(a)                                                       \
+  hipError_t launch_fused_##a##_F16w8(const FusedArgs&, int, hipStream_t); \
+  hipError_t launch_fused_##a##_BF16w8(const FusedArgs&, int, hipStream_t);
+V21_ARCH_LIST(V21_DECL4)
+#undef V21_DECL4
 }  // namespace v21
 
 typedef hipError_t (*fused_launcher)(const FusedArgs&, int, hipStream_t);
@@ -210,11 +215,13 @@ struct FusedEntry {
   fused_launcher fn[3];    // one wave per SIMD, two column tiles per wave (f32: one)
   fused_launcher fn_x2[3]; // two workgroups per CU, one column tile per wave (f16/bf16)
   fused_launcher fn_s16[3]; // same occupancy, 16x16x32 MFMA shape (fused_fwd16.h)
+  fused_launcher fn_w8[3];  // one 8-wave workgroup per CU: the two waves of a SIMD share the weight ring
 };
 #define V21_ENTRY(a)                                                                                          \
   {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_##a##_F32, launch_fused_##a##_F16, launch_fused_##a##_BF16}, \
    {nullptr, launch_fused_##a##_F16x2, launch_fused_##a##_BF16x2},                                         \
-   {nullptr, launch_fused_##a##_F16s16, launch_fused_##a##_BF16s16}},
+   {nullptr, launch_fused_##a##_F16s16, launch_fused_##a##_BF16s16},                                       \
+   {nullptr, launch_fused_##a##_F16w8, launch_fused_##a##_BF16w8}},
 static const FusedEntry g_fused[] = {V21_ARCH_LIST(V21_ENTRY)};
 #undef V21_ENTRY
 
@@ -255,7 +262,7 @@ static void stream_geometry(const v21_mlp* m, int prec, int* total, int* padded)
   int f = 0;
   for (int l = 0; l < m->L; ++l) f += ((m->dims[l + 1] + 31) / 32) * ((m->dims[l] + fpi_of(prec) - 1) / fpi_of(prec) + 1);
   *total = f;
-  *padded = (f + 3) / 4 * 4;
+  *padded = (f + 7) / 8 * 8;  // whole DMA rounds of the 4- and 8-wave kernels (fused_fwd.h: Geo::padded)
 }
 
 extern "C" int v21_mlp_create(v21_ctx* ctx, int n_layers, const int* dims, const int* act, v21_mlp** out) {
@@ -513,6 +520,13 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
     return V21_OK;
   }
   const int x2 = getenv("V21_FUSED_X2") ? atoi(getenv("V21_FUSED_X2")) : 1;
+  {
+    const char* w8 = getenv("V21_FUSED_W8");
+    if (w8 && w8[0] == '1' && g_fused[m->fused_id].fn_w8[precision]) {
+      HIPCHK(g_fused[m->fused_id].fn_w8[precision](a, 0, m->ctx->stream));
+      return V21_OK;
+    }
+  }
   if (x2 && g_fused[m->fused_id].fn_x2[precision]) {  // default for f16/bf16: two 128-signal workgroups per CU
     const int delay = getenv("V21_FUSED_DELAY") ? atoi(getenv("V21_FUSED_DELAY")) : 0;
     const int prio = getenv("V21_FUSED_PRIO") ? atoi(getenv("V21_FUSED_PRIO")) : 0;
