@@ -175,6 +175,28 @@ def sweep_leg(native, ctx, precision, batch=256, steps_per_epoch=48, epochs=3):
             "configs": "latent/enc/dec widths " + " ".join("%d/%d/%d-%d" % (c[0], c[1], c[2][0], c[2][1]) for c in SWEEP_CONFIGS)}
 
 
+def fit_leg(precision, epochs=12):
+    """Auxiliary metric (BASELINE configs[2]): the reference's whole training recipe through the class
+    surface -- AutoEncoderEmulator.train(): autoencoder fit x -> x, encode, latent emulator fit, each
+    with a validation pass per epoch -- on a synthetic data set of the reference's size (24,562 / 2,730
+    rows, batch 256).  Wall clock of the call, Python and callbacks included."""
+    synth = importlib.import_module("21cmvae_amd.synth")
+    emu = importlib.import_module("21cmvae_amd.emulator")
+    optm = importlib.import_module("21cmvae_amd.optimizers")
+    data = synth.make_dataset()
+    ae = emu.AutoEncoderEmulator(precision=precision, **data)
+    ae.autoencoder.compile(optimizer=optm.Adam(1e-3), loss=emu.relative_mse_loss(ae.signal_train))
+    ae.emulator.compile(optimizer=optm.Adam(1e-3), loss=emu.mean_squared_error)
+    ae.train(epochs=1, verbose=0)  # allocations, data upload
+    t0 = time.perf_counter()
+    out = ae.train(epochs=epochs, verbose=0)
+    dt = time.perf_counter() - t0
+    steps = 2 * epochs * -(-data["par_train"].shape[0] // 256)
+    return {"precision": precision, "epochs": epochs, "rows": int(data["par_train"].shape[0]), "batch": 256,
+            "optimizer_steps_per_s": steps / dt, "s_per_epoch_both_models": dt / epochs,
+            "final_ae_loss": out[0][-1], "final_emulator_loss": out[2][-1]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -365,6 +387,12 @@ def main():
                 os._exit(0)
         else:
             run_train()
+
+    if rank == 0 and world == 1 and not args.no_train and not args.no_extras:
+        try:
+            out["fit_reference_recipe"] = [fit_leg("f32"), fit_leg("f16")]
+        except Exception as e:
+            out["fit_reference_recipe"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # last: see _BLAS_LIMIT
         xt = pp.par_transform(params.astype(np.float64), par_train).astype(np.float32)
