@@ -174,3 +174,31 @@ def test_variational_autoencoder_mode(data):
     np.testing.assert_array_equal(z, ae.encoder.predict(y))  # deterministic
     np.testing.assert_allclose(ae.predict(y), ae.decoder.predict(z), atol=1e-4, rtol=1e-4)
     assert ae_em.predict(ae_em.par_test[:3]).shape == (3, 451)
+
+
+def test_f16_training_early_stop_restores_best_weights(data):
+    """The chain-kernel path behind the Keras callbacks: EarlyStopping stops a run whose validation loss
+    rises (learning rate far too high), restores the best epoch's weights into the device stack (packed
+    streams included), and a second fit() continues from them."""
+    emulator, cbm, optm, eng = pkg("emulator"), pkg("callbacks"), pkg("optimizers"), pkg("engine")
+    eng.set_random_seed(3)
+    direm = emulator.DirectEmulator(hidden_dims=[64, 64], precision="f16", **data)
+    direm.emulator.compile(optimizer=optm.Adam(0.003), loss=emulator.relative_mse_loss(direm.signal_train))
+    l0, v0 = direm.train(epochs=4, verbose=0)
+    good = [w.copy() for w in direm.emulator.get_weights()]
+    # now wreck it: a huge learning rate makes the validation loss jump; patience 1 stops at once
+    direm.emulator.optimizer.lr = 0.5
+    es = cbm.EarlyStopping(monitor="val_loss", patience=1, restore_best_weights=True)
+    l1, v1 = direm.train(epochs=8, callbacks=[es], verbose=0)
+    assert len(l1) < 8 and es.stopped_epoch > 0
+    best = int(np.argmin(v1))
+    X = pkg("preprocess").par_transform(direm.par_val, direm.par_train)
+    Y = pkg("preprocess").preproc(direm.signal_val, direm.signal_train)
+    # the restored weights reproduce the best validation loss (f32 evaluation of f16-trained weights)
+    got = direm.emulator.evaluate(X, Y, batch_size=256)
+    assert abs(got - v1[best]) / v1[best] < 2e-2, (got, v1)
+    # and training goes on from there at a sane rate
+    direm.emulator.optimizer.lr = 0.001
+    l2, v2 = direm.train(epochs=3, verbose=0)
+    assert v2[-1] < 1.5 * v1[best]
+    assert len(good) == len(direm.emulator.get_weights())
