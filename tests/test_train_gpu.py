@@ -496,3 +496,37 @@ def test_chain_path_is_actually_used(ctx):
         t2 = native.Trainer(stack, prec, 8)
         with pytest.raises(native.EngineError):
             t2.chain_stamps(4)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_data_parallel_arithmetic_without_a_communicator(ctx, prec):
+    """What two ranks would feed the all-reduce: each takes its slice of the global batch with
+    global_rows = B in the loss scale; the SUM of the two gradient arenas (and of the two loss slots)
+    must be the single-process full-batch gradient (per-layer path in f32, chain kernel in f16)."""
+    native = pkg("_native")
+    synth = pkg("synth")
+    dims, act = [451, 96, 9, 32, 451], [1, 0, 1, 0]
+    n, cut = 200, 77  # uneven split, neither part a multiple of 32
+    sig = synth.make_signals(n, seed=17)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    Ws, bs = ora.init_mlp(dims, seed=2)
+    flat = ora.flatten_params(Ws, bs)
+
+    def grad_of(rows, global_rows):
+        st = native.Stack(ctx, dims, act); st.set_weights(flat)
+        tr = native.Trainer(st, prec, 256)
+        tr.set_adam(lr=0.0)
+        d_x, d_w = ctx.malloc(y[rows].nbytes), ctx.malloc(w[rows].nbytes)
+        ctx.h2d(d_x, np.ascontiguousarray(y[rows])); ctx.h2d(d_w, np.ascontiguousarray(w[rows]))
+        tr.step_dev(d_x, None, d_w, len(y[rows]), global_rows)
+        g, l = tr.get_grad().astype(np.float64), tr.last_step_loss()
+        ctx.free(d_x); ctx.free(d_w)
+        return g, l
+    g_all, l_all = grad_of(slice(0, n), n)
+    g_a, l_a = grad_of(slice(0, cut), n)
+    g_b, l_b = grad_of(slice(cut, n), n)
+    tol = 1e-5 if prec == "f32" else 2e-3
+    assert abs((l_a + l_b) - l_all) / l_all < tol
+    err = np.abs(g_a + g_b - g_all).max() / np.abs(g_all).max()
+    assert err < tol, err
