@@ -323,6 +323,29 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
   }
 }
 
+// fp32 W^T copies (rows = outputs, pitch p16(K)) of the small-batch forward path: one thread per arena element
+__global__ void wt_pack_kernel(const AdamArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  int l = 0;
+  while (l + 1 < a.L && i >= a.lt[l + 1].w_off) ++l;
+  const AdamLayer L = a.lt[l];
+  const long long r = i - L.w_off;
+  if (r < (long long)L.K * L.N) {
+    const int k = (int)(r / L.N), n = (int)(r % L.N);
+    a.wt[L.wt_off + (long long)n * L.ldwt + k] = a.w[i];
+  }
+}
+// rows of x -> zero-padded rows of pitch ldd (the latency GEMM reads whole 16-float groups)
+__global__ void copy_pad_kernel(float* __restrict__ dst, long long ldd, const float* __restrict__ src, long long lds_,
+                                long long n, int d) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * ldd) return;
+  const long long row = i / ldd;
+  const int j = (int)(i % ldd);
+  dst[i] = j < d ? src[row * lds_ + j] : 0.f;
+}
+
 // generic-path prologue / epilogue (the fused kernel does these in registers)
 __global__ void affine_in_kernel(float* __restrict__ dst, long long ldd, const float* __restrict__ src,
                                  long long lds_, long long n, const v21_affine_in t) {

@@ -253,6 +253,11 @@ struct v21_mlp {
   int maxdim = 0;
   unsigned* d_phase = nullptr;  // per-CU arrival counters of the x2 fused variants
   bool wpad_ok = false;  // false after the arena was rewritten from outside a trainer (set_weights)
+  // small-batch latency path: fp32 W^T copies + two padded activation images
+  float* d_wt = nullptr;
+  std::vector<long long> wt_off;
+  bool wt_ok = false;
+  float* d_small[2] = {nullptr, nullptr};
   // width of layer l's Dense output: dims[l+1], or 2*dims[l+1] = [z_mean | z_log_var] for V21_ACT_GAUSS
   int nw(int l) const { return act[l] == V21_ACT_GAUSS ? 2 * dims[l + 1] : dims[l + 1]; }
 };
@@ -312,6 +317,8 @@ extern "C" int v21_mlp_destroy(v21_mlp* m) {
   if (m->d_mean) hipFree(m->d_mean);
   if (m->d_phase) hipFree(m->d_phase);
   for (int i = 0; i < 2; ++i) if (m->d_act[i]) hipFree(m->d_act[i]);
+  for (int i = 0; i < 2; ++i) if (m->d_small[i]) hipFree(m->d_small[i]);
+  if (m->d_wt) hipFree(m->d_wt);
   if (m->d_xs) hipFree(m->d_xs);
   if (m->d_ys) hipFree(m->d_ys);
   delete m;
@@ -325,6 +332,7 @@ extern "C" int v21_mlp_num_params(const v21_mlp* m, size_t* n) {
 static void invalidate_streams(v21_mlp* m) {
   for (int i = 0; i < 3; ++i) m->stream_ok[i] = m->stream16_ok[i] = false;
   m->wpad_ok = false;
+  m->wt_ok = false;
 }
 
 extern "C" int v21_mlp_set_weights(v21_mlp* m, const float* flat, size_t n) {
@@ -487,6 +495,9 @@ static int forward_generic(v21_mlp* m, const float* d_x, long long ldx, long lon
   return V21_OK;
 }
 
+static int forward_small(v21_mlp* m, const float* d_x, long long ldx, long long n, float* d_y, long long ldy, int prec,
+                         int flags);
+
 extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, int64_t n, float* d_y, int64_t ldy,
                                    int precision, int flags) {
   if (!m || !d_x || !d_y) return fail(V21_ERR_ARG, "null argument");
@@ -498,6 +509,12 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
   if ((flags & V21_FWD_OUT_TRANSFORM) && !m->has_tout) return fail(V21_ERR_STATE, "output transform requested but not set");
   const bool fused = m->fused_id >= 0 && !(flags & V21_FWD_FORCE_GENERIC) &&
                      (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) && ldy < (1ll << 21);
+  // few rows: one latency-oriented launch per layer beats one wave walking the whole stack in f32
+  // (and the K-loop GEMM of the generic path in any precision)
+  if (n <= V21_SMALL_BATCH_ROWS && !(flags & (V21_FWD_NO_SMALL | V21_FWD_FORCE_GENERIC)) &&
+      (precision == V21_PREC_F32 || !fused) && (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) &&
+      m->maxdim <= kNtMaxKPerWg)
+    return forward_small(m, d_x, ldx, n, d_y, ldy, precision, flags);
   if (!fused) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
   const int s16 = getenv("V21_FUSED_S16") ? atoi(getenv("V21_FUSED_S16")) : 0;
   const bool use16 = s16 && g_fused[m->fused_id].fn_s16[precision] != nullptr;
@@ -886,6 +903,70 @@ static int launch_nt(int prec, GROUP& grp, hipStream_t st) {
   }
 #undef V21_NT
   HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+
+// Model.predict on a few rows (emulator.py:402 called from a sampler): one gemm_nt launch per layer
+static int forward_small(v21_mlp* m, const float* d_x, long long ldx, long long n, float* d_y, long long ldy, int prec,
+                         int flags) {
+  hipStream_t st = m->ctx->stream;
+  const int L = m->L, rows = (int)n;
+  if (!m->d_wt) {
+    long long ot = 0;
+    for (int l = 0; l < L; ++l) { m->wt_off.push_back(ot); ot += (long long)(m->nw(l) + 32) * p16(m->dims[l]); }
+    HIPCHK(hipMalloc((void**)&m->d_wt, (size_t)(ot + 64) * sizeof(float)));
+    HIPCHK(hipMemsetAsync(m->d_wt, 0, (size_t)(ot + 64) * sizeof(float), st));
+    for (int i = 0; i < 2; ++i) {
+      const size_t nb = (size_t)(V21_SMALL_BATCH_ROWS + 32) * p16(m->maxdim) * sizeof(float);
+      HIPCHK(hipMalloc((void**)&m->d_small[i], nb));
+      HIPCHK(hipMemsetAsync(m->d_small[i], 0, nb, st));
+    }
+  }
+  if (!m->wt_ok) {
+    AdamArgs a{};
+    a.w = m->d_w; a.wt = m->d_wt; a.n = (long long)m->nparams; a.L = L;
+    for (int l = 0; l < L; ++l) {
+      AdamLayer& al = a.lt[l];
+      al.w_off = m->w_off[l]; al.wt_off = m->wt_off[l]; al.K = m->dims[l]; al.N = m->nw(l); al.ldwt = p16(al.K);
+    }
+    hipLaunchKernelGGL(wt_pack_kernel, dim3((unsigned)((m->nparams + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    m->wt_ok = true;
+  }
+  const long long ld0 = p16(m->dims[0]);
+  if ((flags & V21_FWD_IN_TRANSFORM) && m->has_tin) {
+    const long long tot = (long long)rows * m->dims[0];
+    hipLaunchKernelGGL(affine_in_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->d_small[0], ld0, d_x,
+                       ldx, (long long)rows, m->tin);
+  } else {
+    const long long tot = (long long)rows * ld0;
+    hipLaunchKernelGGL(copy_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->d_small[0], ld0, d_x,
+                       ldx, (long long)rows, m->dims[0]);
+  }
+  HIPCHK(hipGetLastError());
+  int cur = 0;
+  for (int l = 0; l < L; ++l) {
+    const bool last = l == L - 1;
+    NtGroup grp{};
+    grp.count = 1;
+    NtArgs& g = grp.p[0];
+    g.A = m->d_small[cur]; g.lda = p16(m->dims[l]);
+    g.B = m->d_wt + m->wt_off[l]; g.ldb = p16(m->dims[l]);
+    g.C = last ? d_y : m->d_small[cur ^ 1]; g.ldc = last ? ldy : p16(m->dims[l + 1]);
+    g.CT = nullptr;
+    g.M = rows; g.N = m->dims[l + 1]; g.K = m->dims[l];  // V21_ACT_GAUSS: the z_mean rows of W^T only
+    g.bias = m->d_w + m->b_off[l];
+    g.ep = m->act[l] == V21_ACT_RELU ? NT_FWD_RELU : NT_FWD;
+    g.nz = 1;
+    CHK(launch_nt(prec, grp, st));
+    cur ^= 1;
+  }
+  if ((flags & V21_FWD_OUT_TRANSFORM) && m->has_tout) {
+    const long long tot = (long long)rows * m->dims[L];
+    hipLaunchKernelGGL(affine_out_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_y, ldy, (long long)rows,
+                       m->dims[L], m->out_std, m->d_mean);
+    HIPCHK(hipGetLastError());
+  }
   return V21_OK;
 }
 

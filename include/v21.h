@@ -115,7 +115,14 @@ int v21_mlp_has_fused(const v21_mlp* mlp, int precision, int* yes);
 
 /* Model.predict (emulator.py:402, :753-754, :789-790) and Model.__call__ (:517, :827):
  * host (n, in_dim) f32/f64 -> host (n, out_dim) f32.  flags: bit0 = apply input
- * transform, bit1 = apply output transform, bit2 = force the generic per-layer path. */
+ * transform, bit1 = apply output transform, bit2 = force the generic per-layer path,
+ * bit3 = never take the small-batch latency path.
+ * Path selection (results agree within fp32 rounding of the summation order): the fused
+ * one-launch kernel for the shipped stack shapes; for up to V21_SMALL_BATCH_ROWS rows in
+ * f32 (and for any stack without a fused kernel) one latency-oriented launch per layer
+ * that spreads a layer's output tiles over the chip -- a sampler that calls
+ * predict() row by row (the reference's use case: README "40 ms" per call) waits for one
+ * memory round trip per layer instead of for one wave walking the whole stack. */
 int v21_mlp_forward(v21_mlp* mlp, const void* x, int x_dtype, int64_t n, float* y,
                     int precision, int flags);
 /* Same, device-resident, asynchronous on the context stream.  ldx/ldy = row pitch
@@ -125,6 +132,8 @@ int v21_mlp_forward_dev(v21_mlp* mlp, const float* d_x, int64_t ldx, int64_t n,
 #define V21_FWD_IN_TRANSFORM 1
 #define V21_FWD_OUT_TRANSFORM 2
 #define V21_FWD_FORCE_GENERIC 4
+#define V21_FWD_NO_SMALL 8
+#define V21_SMALL_BATCH_ROWS 4096
 
 /* ---- trainer: replaces Model.compile + Model.fit (emulator.py:369-378, :739-747,
  * :756-764; optimizer/loss from notebooks/Training.ipynb cells 4 and 10). ------- */

@@ -56,11 +56,17 @@ def test_fused_f32_matches_oracle(ctx, dims, n):
     x = rng.uniform(-1, 1, size=(n, 7)).astype(np.float32)
     st = _stack(ctx, Ws, bs)
     assert st.has_fused("f32")
-    y = st.forward(x, "f32")
+    native = pkg("_native")
     ref = ora.mlp_forward(Ws, bs, x)
+    # the fused one-launch kernel (what large batches run) ...
+    y = st.forward(x, "f32", flags=native.FWD_NO_SMALL)
     np.testing.assert_allclose(y, ref, atol=F32_ATOL, rtol=F32_RTOL)
-    # the generic per-layer path must agree too
-    yg = st.forward(x, "f32", flags=pkg("_native").FWD_FORCE_GENERIC)
+    # ... the small-batch latency path that f32 calls of <= 4096 rows take by default ...
+    ys = st.forward(x, "f32")
+    np.testing.assert_allclose(ys, ref, atol=F32_ATOL, rtol=F32_RTOL)
+    np.testing.assert_allclose(ys, y, atol=5e-6, rtol=1e-5)  # paths differ by summation order only
+    # ... and the generic per-layer K-loop path must agree too
+    yg = st.forward(x, "f32", flags=native.FWD_FORCE_GENERIC)
     np.testing.assert_allclose(yg, ref, atol=F32_ATOL, rtol=F32_RTOL)
 
 
@@ -77,8 +83,11 @@ def test_fused_full_size_ragged_and_row_independent(ctx):
         y = st.forward(x, prec)
         assert y.shape == (n, 451) and np.isfinite(y).all()
         idx = np.r_[0:5, 255:258, 32767:32770, n - 20:n]
-        ysub = st.forward(x[idx], prec)
-        np.testing.assert_array_equal(y[idx], ysub)  # bit-identical: rows are independent
+        ysub = st.forward(x[idx], prec, flags=pkg("_native").FWD_NO_SMALL)
+        np.testing.assert_array_equal(y[idx], ysub)  # same kernel: bit-identical, rows are independent
+        # the default route of a few f32 rows is the small-batch path (another summation order); the
+        # reference's own batched-vs-single tolerance is atol 5e-5 (tests/test_emulator.py:68)
+        np.testing.assert_allclose(st.forward(x[idx], prec), y[idx], atol=5e-6, rtol=1e-5)
     y32 = st.forward(x, "f32")
     pick = rng.choice(n, size=300, replace=False)
     np.testing.assert_allclose(y32[pick], ora.mlp_forward(Ws, bs, x[pick]), atol=F32_ATOL, rtol=F32_RTOL)
@@ -158,8 +167,9 @@ def test_generic_path_odd_shapes(ctx):
         x = rng.normal(size=(77, dims[0])).astype(np.float32)
         st = _stack(ctx, Ws, bs)
         for prec, tol in (("f32", 3e-5), ("f16", 3e-2), ("bf16", 2e-1)):
-            y = st.forward(x, prec)
-            np.testing.assert_allclose(y, ora.mlp_forward(Ws, bs, x), atol=tol, rtol=tol)
+            for flags in (0, pkg("_native").FWD_NO_SMALL):  # latency path (default at this size) and K-loop path
+                y = st.forward(x, prec, flags=flags)
+                np.testing.assert_allclose(y, ora.mlp_forward(Ws, bs, x), atol=tol, rtol=tol)
 
 
 def test_argument_errors_are_reported(ctx):
@@ -174,3 +184,31 @@ def test_argument_errors_are_reported(ctx):
     with pytest.raises(native.EngineError):  # transform requested but never set
         st.forward(np.zeros((4, 7), np.float32), flags=native.FWD_OUT_TRANSFORM)
     assert st.forward(np.zeros((0, 7), np.float32)).shape == (0, 3)
+
+
+def test_small_batch_path_with_transforms_and_edges(ctx):
+    """The latency path with the fused-in preprocess transforms (what DirectEmulator.predict sends for
+    one parameter vector), at the row counts around its limit, and a stack wider than it supports."""
+    native = pkg("_native")
+    pp, synth = pkg("preprocess"), pkg("synth")
+    Ws, bs = ora.init_mlp(S1, seed=9)
+    st = _stack(ctx, Ws, bs)
+    par_train = synth.make_params(2000, seed=1, corners=True)
+    sig = synth.make_signals(500, seed=2)
+    ps, ss = pp.ParamStats.of(par_train), pp.SignalStats.of(sig)
+    st.set_input_transform(ps.log_mask, ps.zero_floor, ps.lo, ps.hi)
+    st.set_output_transform(ss.std, ss.mean)
+    flags = native.FWD_IN_TRANSFORM | native.FWD_OUT_TRANSFORM
+    for n in (1, 2, 4096, 4097):  # 4097 rows: back on the fused kernel
+        par = synth.make_params(n, seed=3, dtype=np.float32)
+        par[0, 2] = 0.0  # the fx == 0 -> 1e-6 rule (preprocess.py:76)
+        ref = ora.unpreproc(ora.mlp_forward(Ws, bs, ora.par_transform(par.astype(np.float64), par_train)), sig)
+        y = st.forward(par, "f32", flags=flags)
+        np.testing.assert_allclose(y, ref, atol=2e-3, rtol=2e-5)  # mK units (std ~ 40)
+        y2 = st.forward(par, "f32", flags=flags | native.FWD_NO_SMALL)
+        np.testing.assert_allclose(y, y2, atol=2e-3, rtol=2e-5)
+    wide = [7, 600, 5]
+    Ww, bw = ora.init_mlp(wide, seed=1)
+    sw = _stack(ctx, Ww, bw)
+    x = np.random.default_rng(0).normal(size=(3, 7)).astype(np.float32)
+    np.testing.assert_allclose(sw.forward(x, "f32"), ora.mlp_forward(Ww, bw, x), atol=3e-5, rtol=3e-5)
