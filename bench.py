@@ -175,6 +175,30 @@ def sweep_leg(native, ctx, precision, batch=256, steps_per_epoch=48, epochs=3):
             "configs": "latent/enc/dec widths " + " ".join("%d/%d/%d-%d" % (c[0], c[1], c[2][0], c[2][1]) for c in SWEEP_CONFIGS)}
 
 
+def latency_leg():
+    """Auxiliary metric: what a sampler sees -- DirectEmulator.predict() on ONE parameter vector through
+    the class surface (numpy in, numpy out; host transform, PCIe both ways, synchronisation included).
+    The reference quotes 40 ms per call (README.rst:11)."""
+    synth = importlib.import_module("21cmvae_amd.synth")
+    emu = importlib.import_module("21cmvae_amd.emulator")
+    data = synth.make_dataset(4000, 400, 400)
+    res = {}
+    for prec in ("f32", "f16"):
+        em = emu.DirectEmulator(hidden_dims=DIMS[1:-1], precision=prec, **data)
+        p1 = data["par_test"][0]
+        for _ in range(20):
+            em.predict(p1)
+        lat = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(200):
+                em.predict(p1)
+            lat.append((time.perf_counter() - t0) / 200 * 1e6)
+        res[prec] = {"us_per_call_median": float(np.median(lat)), "us_per_call_min": float(min(lat))}
+    res["note"] = "f32 (default): small-batch path, one launch per layer; f16: fused one-launch kernel"
+    return res
+
+
 def fit_leg(precision, epochs=12):
     """Auxiliary metric (BASELINE configs[2]): the reference's whole training recipe through the class
     surface -- AutoEncoderEmulator.train(): autoencoder fit x -> x, encode, latent emulator fit, each
@@ -393,6 +417,10 @@ def main():
             out["fit_reference_recipe"] = [fit_leg("f32"), fit_leg("f16")]
         except Exception as e:
             out["fit_reference_recipe"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            out["single_call_latency"] = latency_leg()
+        except Exception as e:
+            out["single_call_latency"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # last: see _BLAS_LIMIT
         xt = pp.par_transform(params.astype(np.float64), par_train).astype(np.float32)
