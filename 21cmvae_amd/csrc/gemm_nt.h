@@ -42,6 +42,7 @@ struct NtArgs {
   // batch (2 w_i (p-y)/B ~ 1e-7) sit below the f16 normal range: the backward contractions
   // scale dZ by a power of two on the way into the MFMA and undo it on the way out (exact).
   float a_scale, b_scale, out_scale;
+  const float* aff_mean; float aff_std;  // NT_FWD_UNPRE
 };
 // several independent contractions per launch: the backward of one layer (dW and dX both
 // consume dZ of that layer), and the same layer of every model of a sweep
@@ -56,7 +57,8 @@ struct NtGroupT {  // CAP = 2 for a single model (small kernel-argument block), 
 };
 using NtGroup = NtGroupT<2>;
 using NtGroupBig = NtGroupT<kNtMaxGroup>;
-enum { NT_FWD = 0, NT_FWD_RELU = 1, NT_DX = 2, NT_DX_MASK = 3, NT_DW = 4 };
+// NT_FWD_UNPRE: last layer of predict with preprocess.unpreproc fused in: (z + bias) * aff_std + aff_mean[n]
+enum { NT_FWD = 0, NT_FWD_RELU = 1, NT_DX = 2, NT_DX_MASK = 3, NT_DW = 4, NT_FWD_UNPRE = 5 };
 
 constexpr int kNtMaxKPerWg = 512;
 
@@ -185,13 +187,15 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GROUP grp) {
       const int mrow = m0 + 32 * ti + 8 * wave + 4 * lh;  // rows mrow .. mrow+3
       if (n >= g.N) continue;
       float bias = 0.f;
-      if (EP == NT_FWD || EP == NT_FWD_RELU) bias = g.bias[n];
+      if (EP == NT_FWD || EP == NT_FWD_RELU || EP == NT_FWD_UNPRE) bias = g.bias[n];
+      const float amean = EP == NT_FWD_UNPRE ? g.aff_mean[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = mrow + e;
         float v = r[e];
         if (EP == NT_FWD) v = v + bias;
         if (EP == NT_FWD_RELU) v = fmaxf(v + bias, 0.f);
+        if (EP == NT_FWD_UNPRE) v = (v + bias) * g.aff_std + amean;  // rounded as numpy does: (p * std) + mean
         if (EP == NT_DX_MASK) v = (m < g.M && g.mask[(long long)m * g.ldmask + n] > 0.f) ? v : 0.f;
         r[e] = v;
         if (m < g.M) C[(long long)m * g.ldc + n] = v;

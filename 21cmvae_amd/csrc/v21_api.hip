@@ -55,6 +55,7 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 extern "C" const char* v21_last_error(void) { return g_err.c_str(); }
+static inline long long p16(int d) { return (d + 15) & ~15; }  // row pitch: whole 16-float groups
 extern "C" int v21_version(void) { return 100; }
 extern "C" int v21_device_count(int* n) {
   if (!n) return fail(V21_ERR_ARG, "null n");
@@ -258,6 +259,8 @@ struct v21_mlp {
   std::vector<long long> wt_off;
   bool wt_ok = false;
   float* d_small[2] = {nullptr, nullptr};
+  float* d_xpad = nullptr;  // host-API staging of zero-padded input rows
+  long long stage_pad_rows = 0;
   // width of layer l's Dense output: dims[l+1], or 2*dims[l+1] = [z_mean | z_log_var] for V21_ACT_GAUSS
   int nw(int l) const { return act[l] == V21_ACT_GAUSS ? 2 * dims[l + 1] : dims[l + 1]; }
 };
@@ -319,6 +322,7 @@ extern "C" int v21_mlp_destroy(v21_mlp* m) {
   for (int i = 0; i < 2; ++i) if (m->d_act[i]) hipFree(m->d_act[i]);
   for (int i = 0; i < 2; ++i) if (m->d_small[i]) hipFree(m->d_small[i]);
   if (m->d_wt) hipFree(m->d_wt);
+  if (m->d_xpad) hipFree(m->d_xpad);
   if (m->d_xs) hipFree(m->d_xs);
   if (m->d_ys) hipFree(m->d_ys);
   delete m;
@@ -497,6 +501,16 @@ static int forward_generic(v21_mlp* m, const float* d_x, long long ldx, long lon
 
 static int forward_small(v21_mlp* m, const float* d_x, long long ldx, long long n, float* d_y, long long ldy, int prec,
                          int flags);
+// internal: d_x rows are already zero-padded to a multiple of 16 floats (ldx) in a buffer with slack --
+// the small-batch path reads them in place (set by v21_mlp_forward, which pads on the host)
+#define V21_FWD_X_PADDED 0x100
+static bool takes_small_path(const v21_mlp* m, long long n, int precision, int flags) {
+  const bool fused = m->fused_id >= 0 && !(flags & V21_FWD_FORCE_GENERIC) &&
+                     (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8);
+  return n <= V21_SMALL_BATCH_ROWS && !(flags & (V21_FWD_NO_SMALL | V21_FWD_FORCE_GENERIC)) &&
+         (precision == V21_PREC_F32 || !fused) && (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) &&
+         m->maxdim <= kNtMaxKPerWg;
+}
 
 extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, int64_t n, float* d_y, int64_t ldy,
                                    int precision, int flags) {
@@ -511,9 +525,7 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
                      (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) && ldy < (1ll << 21);
   // few rows: one latency-oriented launch per layer beats one wave walking the whole stack in f32
   // (and the K-loop GEMM of the generic path in any precision)
-  if (n <= V21_SMALL_BATCH_ROWS && !(flags & (V21_FWD_NO_SMALL | V21_FWD_FORCE_GENERIC)) &&
-      (precision == V21_PREC_F32 || !fused) && (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) &&
-      m->maxdim <= kNtMaxKPerWg)
+  if (takes_small_path(m, n, precision, flags) && ldy < (1ll << 21))
     return forward_small(m, d_x, ldx, n, d_y, ldy, precision, flags);
   if (!fused) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
   const int s16 = getenv("V21_FUSED_S16") ? atoi(getenv("V21_FUSED_S16")) : 0;
@@ -579,6 +591,28 @@ extern "C" int v21_mlp_forward(v21_mlp* m, const void* x, int x_dtype, int64_t n
     m->stage_rows = need;
   }
   std::vector<float> tmp;
+  flags &= 0xFF;
+  if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
+  if ((flags & V21_FWD_IN_TRANSFORM) && !m->has_tin) return fail(V21_ERR_STATE, "input transform requested but not set");
+  if ((flags & V21_FWD_OUT_TRANSFORM) && !m->has_tout) return fail(V21_ERR_STATE, "output transform requested but not set");
+  if (takes_small_path(m, n, precision, flags) && !(flags & V21_FWD_IN_TRANSFORM)) {
+    // few rows: pad the rows on the host, so the first layer reads the staging buffer in place (one launch fewer)
+    const long long ldp = p16(din);
+    if (m->stage_pad_rows < n) {
+      if (m->d_xpad) HIPCHK(hipFree(m->d_xpad));
+      HIPCHK(hipMalloc((void**)&m->d_xpad, (size_t)(n + 2) * ldp * sizeof(float)));
+      m->stage_pad_rows = n;
+    }
+    tmp.assign((size_t)n * ldp, 0.f);
+    for (long long r = 0; r < n; ++r)
+      for (int j = 0; j < din; ++j)
+        tmp[(size_t)r * ldp + j] = x_dtype == V21_DTYPE_F64 ? (float)((const double*)x)[r * din + j] : ((const float*)x)[r * din + j];
+    HIPCHK(hipMemcpyAsync(m->d_xpad, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    CHK(forward_small(m, m->d_xpad, ldp, n, m->d_ys, dout, precision, flags | V21_FWD_X_PADDED));
+    HIPCHK(hipMemcpyAsync(y, m->d_ys, (size_t)n * dout * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return V21_OK;
+  }
   for (long long r0 = 0; r0 < n; r0 += chunk) {
     const long long rows = std::min(chunk, n - r0);
     const float* src;
@@ -647,7 +681,6 @@ extern "C" int v21_comm_allreduce_f32(v21_ctx* c, float* d_buf, size_t n) {
 //   dzt[l] (dims[l] x Bp)              its transpose                    (weight-gradient B operand)
 //   wt[l]  (N x p16(K)) = W^T          forward B operand;   wp[l] (K x p16(N)) = row-padded W: backward B operand
 // ---------------------------------------------------------------------------------
-static inline long long p16(int d) { return (d + 15) & ~15; }
 
 struct v21_trainer {
   v21_mlp* mlp = nullptr;
@@ -934,7 +967,11 @@ static int forward_small(v21_mlp* m, const float* d_x, long long ldx, long long 
     m->wt_ok = true;
   }
   const long long ld0 = p16(m->dims[0]);
-  if ((flags & V21_FWD_IN_TRANSFORM) && m->has_tin) {
+  const float* a0 = m->d_small[0];
+  long long lda0 = ld0;
+  if (flags & V21_FWD_X_PADDED) {
+    a0 = d_x; lda0 = ldx;
+  } else if ((flags & V21_FWD_IN_TRANSFORM) && m->has_tin) {
     const long long tot = (long long)rows * m->dims[0];
     hipLaunchKernelGGL(affine_in_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->d_small[0], ld0, d_x,
                        ldx, (long long)rows, m->tin);
@@ -945,23 +982,28 @@ static int forward_small(v21_mlp* m, const float* d_x, long long ldx, long long 
   }
   HIPCHK(hipGetLastError());
   int cur = 0;
+  bool unpre_done = false;
   for (int l = 0; l < L; ++l) {
     const bool last = l == L - 1;
     NtGroup grp{};
     grp.count = 1;
     NtArgs& g = grp.p[0];
-    g.A = m->d_small[cur]; g.lda = p16(m->dims[l]);
+    g.A = l == 0 ? a0 : m->d_small[cur]; g.lda = l == 0 ? lda0 : p16(m->dims[l]);
     g.B = m->d_wt + m->wt_off[l]; g.ldb = p16(m->dims[l]);
     g.C = last ? d_y : m->d_small[cur ^ 1]; g.ldc = last ? ldy : p16(m->dims[l + 1]);
     g.CT = nullptr;
     g.M = rows; g.N = m->dims[l + 1]; g.K = m->dims[l];  // V21_ACT_GAUSS: the z_mean rows of W^T only
     g.bias = m->d_w + m->b_off[l];
     g.ep = m->act[l] == V21_ACT_RELU ? NT_FWD_RELU : NT_FWD;
+    if (last && (flags & V21_FWD_OUT_TRANSFORM) && m->has_tout && m->act[l] != V21_ACT_RELU) {
+      g.ep = NT_FWD_UNPRE; g.aff_mean = m->d_mean; g.aff_std = m->out_std;  // unpreproc in the epilogue
+      unpre_done = true;
+    }
     g.nz = 1;
     CHK(launch_nt(prec, grp, st));
     cur ^= 1;
   }
-  if ((flags & V21_FWD_OUT_TRANSFORM) && m->has_tout) {
+  if ((flags & V21_FWD_OUT_TRANSFORM) && m->has_tout && !unpre_done) {
     const long long tot = (long long)rows * m->dims[L];
     hipLaunchKernelGGL(affine_out_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_y, ldy, (long long)rows,
                        m->dims[L], m->out_std, m->d_mean);
