@@ -175,6 +175,37 @@ def sweep_leg(native, ctx, precision, batch=256, steps_per_epoch=48, epochs=3):
             "configs": "latent/enc/dec widths " + " ".join("%d/%d/%d-%d" % (c[0], c[1], c[2][0], c[2][1]) for c in SWEEP_CONFIGS)}
 
 
+def accuracy_leg(native, ctx):
+    """Accuracy of the reduced-precision modes on the reference's TRAINED stack (the packaged conversion of
+    its shipped autoencoder-path weights: emulator 7->352->352->352->224->9 + decoder 9->32->352->451), as
+    the reference's own metric (emulator.py:188-191: rms over bins / max|signal|, in %) between the device
+    output and a float64 evaluation of the same weights, and the implied ratio to the published 0.34 %
+    test error if the two errors are independent (bar: <= 1.05)."""
+    base = os.path.join(ROOT, "21cmvae_amd", "models", "autoencoder_based_emulator")
+    Ws, bs, act = [], [], []
+    for stem in ("ae_emulator", "decoder"):
+        d = np.load(os.path.join(base, stem + ".npz"))
+        n = int(d["n_layers"])
+        for i in range(n):
+            Ws.append(d["W%d" % i]); bs.append(d["b%d" % i]); act.append(1 if str(d["act%d" % i]) == "relu" else 0)
+    dims = [Ws[0].shape[0]] + [W.shape[1] for W in Ws]
+    st = native.Stack(ctx, dims, act)
+    st.set_weights(np.concatenate([a.ravel() for W, b in zip(Ws, bs) for a in (W, b)]).astype(np.float32))
+    x = np.random.default_rng(0).uniform(-1, 1, size=(4096, dims[0]))
+    h = x
+    for W, b, a in zip(Ws, bs, act):  # float64 evaluation of the same weights (a checker, not a product path)
+        h = h @ W.astype(np.float64) + b.astype(np.float64)
+        h = np.maximum(h, 0) if a else h
+    out = {}
+    for prec in ("f32", "f16", "bf16"):
+        y = st.forward(x, prec, flags=native.FWD_NO_SMALL).astype(np.float64)
+        e = 100.0 * np.sqrt(np.mean((y - h) ** 2, axis=1)) / np.max(np.abs(h), axis=1)
+        out[prec] = {"added_error_percent_mean": float(e.mean()), "added_error_percent_max": float(e.max()),
+                     "implied_ratio_to_0.34": float(np.sqrt(0.34 ** 2 + e.mean() ** 2) / 0.34)}
+    out["note"] = "pre-processed units; 4096 random parameter vectors in the training box; bar 1.05"
+    return out
+
+
 def latency_leg():
     """Auxiliary metric: what a sampler sees -- DirectEmulator.predict() on ONE parameter vector through
     the class surface (numpy in, numpy out; host transform, PCIe both ways, synchronisation included).
@@ -417,6 +448,10 @@ def main():
             out["fit_reference_recipe"] = [fit_leg("f32"), fit_leg("f16")]
         except Exception as e:
             out["fit_reference_recipe"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            out["accuracy_on_trained_stack"] = accuracy_leg(native, ctx)
+        except Exception as e:
+            out["accuracy_on_trained_stack"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             out["single_call_latency"] = latency_leg()
         except Exception as e:
