@@ -39,13 +39,18 @@ constexpr int kChainBufBytes = 2 * 32 * kChainPitch * 2;
 constexpr int kChainMaskBytes = kChainMaskTiles * 64 * 2;
 constexpr int kChainYPitch = kChainMaxDim + 4;  // floats; 2064 B = 16 B mod 128 B
 constexpr int kChainSmallBytes = kChainWaves * 32 * 4 + 32 * 4 + 32 * 8 + 16;
-constexpr int kChainLdsBytes = kChainBufBytes + kChainMaskBytes + kChainSmallBytes + 32 * kChainYPitch * 4;
+constexpr int kChainMaxLatent = 32;               // variational head: [z_mean | z_log_var] up to 64 wide
+constexpr int kChainZPitch = 2 * kChainMaxLatent + 4;
+constexpr int kChainZBytes = 32 * kChainZPitch * 4 + 32 * 4;  // fp32 (mu | lv) rows + kl_weight * KL per row
+constexpr int kChainLdsBytes = kChainBufBytes + kChainMaskBytes + kChainSmallBytes + 32 * kChainYPitch * 4 + kChainZBytes;
 
 struct ChainLayer {
   int K, N;            // Dense input / output width
   int KS4, NT;         // forward: k-steps of 16 (padded to a multiple of 4), 32-wide output tiles
   int NS4, KT;         // backward: n-steps of 16 (padded to 4), 32-wide input tiles
   int relu;            // ReLU on this layer's output
+  int gauss;           // variational head (V21_ACT_GAUSS): N = 2*latent Dense outputs [z_mean | z_log_var]; the
+                       // next layer sees z = z_mean + exp(z_log_var/2) eps (latent wide)
   int mask_tile;       // first tile of this layer's output mask in LDS (-1: none)
   long long fw_off, bw_off;  // fragment offsets (units of 8 elements) into the packed streams
   long long b_off;     // bias offset in the arena
@@ -75,6 +80,10 @@ struct ChainStep {
   int rows;                        // rows of this rank's batch
   float scale;                     // 2 / B_global
   float gs;                        // gradient operand scale (power of two)
+  // variational head: loss_i += kl_weight * KL_i; eps keyed on (seed, step, row0 + row, d) as in train_kernels.h
+  float kl_weight, kl_over_b;      // kl_weight, kl_weight / B_global
+  int sample;
+  unsigned long long seed, step, row0;
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
@@ -111,12 +120,15 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   float(*red)[32] = reinterpret_cast<float(*)[32]>(chain_smem + kChainBufBytes + kChainMaskBytes);
   float* rwl = reinterpret_cast<float*>(chain_smem + kChainBufBytes + kChainMaskBytes + NW * 32 * 4);
   float* ystg = reinterpret_cast<float*>(chain_smem + kChainBufBytes + kChainMaskBytes + kChainSmallBytes);
-  constexpr int YP = kChainYPitch;
+  constexpr int YP = kChainYPitch, ZP = kChainZPitch;
+  float* zs = ystg + 32 * YP;      // (mu | lv) of the variational head, fp32
+  float* klb = zs + 32 * ZP;       // kl_weight * KL_i
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * 32;
+  if (tid < 32) klb[tid] = 0.f;
 
   chain_stamp(a, 0);
   // ---- gather: x[idx] -> buf[0] (compute type) and H0^T (fp32)
@@ -244,7 +256,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
         acc[r] = n < ly.N ? bias[n] : 0.f;
       }
       contract(fw + ly.fw_off + ((long long)t * ly.KS4) * 64 + lane, act, nch, acc);
-      if (!last) {
+      if (ly.gauss) {  // keep (mu | lv) in fp32: the sampling pass below turns them into z
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + 8 * g + 4 * lh;
+          if (n < ZP) *reinterpret_cast<f32x4*>(zs + li * ZP + n) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        }
+      } else if (!last) {
         unsigned bits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -276,6 +294,26 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
         }
       }
     }
+    if (ly.gauss) {  // z = mu + exp(lv/2) eps -> the next layer's operand image; KL_i -> the row's loss
+      __syncthreads();
+      const int LAT = ly.N >> 1, c1 = a.lt[l + 1].KS4 * 16;
+      if (tid < 32) {
+        const bool ok = m0 + tid < st.rows;
+        float kl = 0.f;
+        for (int d = 0; d < c1; ++d) {
+          float z = 0.f;
+          if (d < LAT) {
+            const float mu = zs[tid * ZP + d], lv = zs[tid * ZP + LAT + d];
+            const float sd = expf(0.5f * lv);
+            const float e = st.sample ? gauss_eps(st.seed, st.step, st.row0 + m0 + tid, d) : 0.f;
+            z = mu + sd * e;
+            kl += -0.5f * (1.0f + lv - mu * mu - sd * sd);
+          }
+          out[tid * PITCH + d] = (elem)z;
+        }
+        klb[tid] = ok ? st.kl_weight * kl : 0.f;
+      }
+    } else
     // columns the tiles did not cover, up to the next contraction's padded range: zero
     {
       const int c0 = 32 * ly.NT, c1 = last ? ly.NS4 * 16 : a.lt[l + 1].KS4 * 16;
@@ -297,12 +335,31 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) s += red[w][tid];
+    s += klb[tid];
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (tid == 0) atomicAdd(a.loss_acc, (unsigned long long)(long long)llrint((double)s * 4294967296.0));
   }
 
   chain_stamp(a, 2 + a.L);
+  // gs * dL/dz (latent wide, in `b`) -> gs * dL/d[mu | lv] in place:  d mu = dz + beta mu,
+  // d lv = dz eps exp(lv/2)/2 + beta (exp lv - 1)/2, beta = kl_weight / B (the KL term's own gradient)
+  auto gauss_backward = [&](elem* b, int LAT) {
+    if (tid < 32) {
+      const int pad = ((2 * LAT + 63) & ~63);
+      for (int d = 0; d < LAT; ++d) {
+        const float mu = zs[tid * ZP + d], lv = zs[tid * ZP + LAT + d];
+        const float sd = expf(0.5f * lv);
+        const float e = st.sample ? gauss_eps(st.seed, st.step, st.row0 + m0 + tid, d) : 0.f;
+        const float g = (float)b[tid * PITCH + d];
+        const bool ok = m0 + tid < st.rows;
+        const float kb = ok ? st.gs * st.kl_over_b : 0.f;
+        b[tid * PITCH + d] = (elem)(g + kb * mu);                                          // d mu (in place)
+        b[tid * PITCH + LAT + d] = (elem)(g * e * 0.5f * sd + kb * 0.5f * (sd * sd - 1.0f));  // d lv (columns past dz)
+      }
+      for (int d = 2 * LAT; d < pad; ++d) b[tid * PITCH + d] = (elem)0.f;
+    }
+  };
   // ---- backward: layer l consumes dZ_l (gs-scaled, in buf[cur]) and produces dZ_{l-1}
   for (int l = a.L - 1; l >= 1; --l) {
     const ChainLayer& ly = a.lt[l];
@@ -310,6 +367,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
     const int nch = ly.NS4 >> 2;
+    if (ly.gauss) { gauss_backward(buf[cur], ly.N >> 1); __syncthreads(); }
     flush_t(act, ly.N, ly.dzt16, ly.KT);  // gs * dZ of this layer's output -> operand of its weight gradient
     for (int t = wave; t < ly.KT; t += NW) {
       const int k0 = 32 * t;
@@ -340,6 +398,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     cur ^= 1;
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
+  if (a.lt[0].gauss) { gauss_backward(buf[cur], a.lt[0].N >> 1); __syncthreads(); }
   flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
 }
 

@@ -787,7 +787,8 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
   CHK(zalloc(&t->d_evalsum, 4, st));
   {  // eligibility of the chain kernel
     const char* env = getenv("V21_TRAIN_CHAIN");
-    bool ok = precision != V21_PREC_F32 && t->gl < 0 && !(env && env[0] == '0');
+    bool ok = precision != V21_PREC_F32 && !(env && env[0] == '0') &&
+              (t->gl < 0 || m->dims[t->gl + 1] <= kChainMaxLatent);
     int mask_tiles = 0;
     for (int l = 0; l <= L && ok; ++l) ok = m->dims[l] <= kChainMaxDim;
     for (int l = 0; l + 1 < L; ++l) mask_tiles += m->act[l] == V21_ACT_RELU ? (m->dims[l + 1] + 31) / 32 : 0;
@@ -795,7 +796,7 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
     if (ok) {
       long long of = 0, ob = 0;
       for (int l = 0; l < L; ++l) {
-        const int K = m->dims[l], N = m->dims[l + 1];
+        const int K = m->dims[l], N = m->nw(l);
         const int KS4 = ((K + 15) / 16 + 3) / 4 * 4, NS4 = ((N + 15) / 16 + 3) / 4 * 4;
         t->fw_off.push_back(of); of += (long long)((N + 31) / 32) * KS4 * 512;
         t->bw_off.push_back(ob); ob += (long long)((K + 31) / 32) * NS4 * 512;
@@ -809,7 +810,7 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
       t->d_ht16.assign(L + 1, nullptr); t->d_dzt16.assign(L + 1, nullptr);
       const unsigned short one = precision == V21_PREC_F16 ? 0x3C00 : 0x3F80;
       for (int l = 0; l < L; ++l) {
-        const int K = m->dims[l], N = m->dims[l + 1];
+        const int K = m->dims[l], N = m->nw(l);
         const size_t na = (size_t)((K + 1 + 31) / 32) * t->BS * 512, nb = (size_t)((N + 31) / 32) * t->BS * 512;
         HIPCHK(hipMalloc(&t->d_ht16[l], na * 2)); HIPCHK(hipMemsetAsync(t->d_ht16[l], 0, na * 2, st));
         HIPCHK(hipMalloc(&t->d_dzt16[l + 1], nb * 2)); HIPCHK(hipMemsetAsync(t->d_dzt16[l + 1], 0, nb * 2, st));
@@ -1180,7 +1181,8 @@ static ChainModel chain_model(v21_trainer* t) {
   int mt = 0;
   for (int l = 0; l < L; ++l) {
     ChainLayer& c = a.lt[l];
-    c.K = m->dims[l]; c.N = m->dims[l + 1];
+    c.K = m->dims[l]; c.N = m->nw(l);
+    c.gauss = m->act[l] == V21_ACT_GAUSS;
     c.KS4 = ((c.K + 15) / 16 + 3) / 4 * 4; c.NT = (c.N + 31) / 32;
     c.NS4 = ((c.N + 15) / 16 + 3) / 4 * 4; c.KT = (c.K + 31) / 32;
     c.relu = m->act[l] == V21_ACT_RELU;
@@ -1197,12 +1199,18 @@ static ChainModel chain_model(v21_trainer* t) {
   return a;
 }
 static ChainStep chain_step(const float* x, long long ldx, const float* y, long long ldy, const float* rw,
-                            const int* d_idx, long long first, int rows, int brows, int dout) {
+                            const int* d_idx, long long first, int rows, int brows, int dout,
+                            const v21_trainer* vae = nullptr, long long row0 = 0) {
   ChainStep st{};
   st.x = x; st.ldx = ldx; st.y = y; st.ldy = ldy; st.rw = rw; st.idx = d_idx; st.first = first;
   st.rows = rows;
   st.scale = 2.0f / (float)brows;
   st.gs = grad_opscale(brows, dout);
+  if (vae && vae->gl >= 0) {
+    st.kl_weight = vae->kl_weight; st.kl_over_b = vae->kl_weight / (float)brows;
+    st.sample = vae->sample; st.seed = vae->seed; st.step = (unsigned long long)vae->iter;
+    st.row0 = (unsigned long long)row0;
+  }
   return st;
 }
 static int chain_attr(int prec) {
@@ -1219,10 +1227,10 @@ static int chain_attr(int prec) {
   return V21_OK;
 }
 static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
-                        const int* d_idx, long long first, int rows, int brows) {
+                        const int* d_idx, long long first, int rows, int brows, long long row0) {
   ChainArgs a{};
   static_cast<ChainModel&>(a) = chain_model(t);
-  static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, t->mlp->dims[t->mlp->L]);
+  static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, t->mlp->dims[t->mlp->L], t, row0);
   CHK(chain_attr(t->prec));
   const dim3 grid((rows + 31) / 32), block(64 * kChainWaves);
   if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
@@ -1244,8 +1252,8 @@ static void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, 
   for (int l = 0; l < L; ++l) {
     Dw16Args g{};
     g.A = t->d_ht16[l]; g.B = t->d_dzt16[l + 1];
-    g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = m->dims[l + 1];
-    g.M = m->dims[l] + 1; g.N = m->dims[l + 1];
+    g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = m->nw(l);
+    g.M = m->dims[l] + 1; g.N = m->nw(l);
     g.nx = (g.N + 63) / 64; g.ny = (g.M + 63) / 64; g.nz = nslice;
     g.steps = steps; g.steps_per_slice = sps; g.BS = t->BS;
     g.slab_stride = (long long)t->P + 4;
@@ -1291,7 +1299,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
     CHK(ensure_copies(t, false));
-    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows));
+    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
     int nslice = 1;
     std::vector<Dw16Args> probs;
     dw16_problems(t, rows, brows, &nslice, probs);  // every weight gradient in one launch: [dW; db] = [H^T; 1^T] dZ

@@ -483,8 +483,8 @@ def test_chain_kernel_odd_shapes(ctx, dims, act, n):
 
 
 def test_chain_path_is_actually_used(ctx):
-    """f16/bf16 trainers of stacks up to 512 wide run the chain kernel (its stamps exist); f32, wide
-    and variational stacks take the per-layer path."""
+    """f16/bf16 trainers of stacks up to 512 wide (variational heads up to 32 latent dimensions) run the
+    chain kernel (its stamps exist); f32, wider stacks and wider latents take the per-layer path."""
     native = pkg("_native")
     st = native.Stack(ctx, [16, 32, 16], [1, 0])
     x = np.zeros((8, 16), np.float32); w = np.ones(8, np.float32)
@@ -492,7 +492,7 @@ def test_chain_path_is_actually_used(ctx):
     s = tr.chain_stamps(6)
     assert s[0] > 0 and np.all(np.diff(s.astype(np.int64)[:5]) > 0)
     for stack, prec in ((st, "f32"), (native.Stack(ctx, [16, 600, 16], [1, 0]), "f16"),
-                        (native.Stack(ctx, [16, 8, 16], [2, 0]), "bf16")):
+                        (native.Stack(ctx, [16, 40, 16], [2, 0]), "bf16")):
         t2 = native.Trainer(stack, prec, 8)
         with pytest.raises(native.EngineError):
             t2.chain_stamps(4)
@@ -530,3 +530,47 @@ def test_data_parallel_arithmetic_without_a_communicator(ctx, prec):
     assert abs((l_a + l_b) - l_all) / l_all < tol
     err = np.abs(g_a + g_b - g_all).max() / np.abs(g_all).max()
     assert err < tol, err
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_variational_stack_on_the_chain_kernel(ctx, prec):
+    """A13 on the one-launch path: sampled latent + KL inside train_chain_kernel, against the float64
+    oracle fed the same counter-based noise, and against the per-layer path in the same precision."""
+    import os
+    synth = pkg("synth")
+    dims = [451, 96, 9, 32, 451]
+    n = 150
+    sig = synth.make_signals(n, seed=4)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    kl_weight, seed = 5e-3, 0x1234ABCD
+    res = {}
+    for chain in (True, False):
+        old = os.environ.get("V21_TRAIN_CHAIN")
+        os.environ["V21_TRAIN_CHAIN"] = "1" if chain else "0"
+        try:
+            st, tr, Ws, bs = _make_vae(ctx, dims, gl=1, seed=21, max_batch=160, prec=prec)
+        finally:
+            if old is None:
+                os.environ.pop("V21_TRAIN_CHAIN")
+            else:
+                os.environ["V21_TRAIN_CHAIN"] = old
+        tr.set_vae(kl_weight, sample=True, seed=seed)
+        tr.set_adam(lr=1e-3)
+        tr.set_state(7)
+        tr.set_data(0, y, None, w)
+        loss = tr.run_epoch(None, n)
+        res[chain] = (loss, tr.get_grad().astype(np.float64))
+        if chain:
+            assert tr.chain_stamps(4)[0] > 0  # really the chain kernel
+    eps = ora.gauss_eps(seed, 7, n, 9)
+    W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
+    lo, go = ora.vae_loss_and_grads(W, b, 1, y.astype(np.float64), y.astype(np.float64), w.astype(np.float64), eps, kl_weight)
+    (lc, gc), (ln, gn) = res[True], res[False]
+    ltol, ctol = (3e-3, 0.9995) if prec == "f16" else (3e-2, 0.995)
+    assert abs(lc - lo) / lo < ltol and abs(lc - ln) / ln < ltol, (lc, ln, lo)
+    assert _cos(gc, go) > ctol and _cos(gc, gn) > ctol, (_cos(gc, go), _cos(gc, gn))
+    # the KL term's own gradient reaches the z_log_var columns (they get nothing from the decoder when eps = 0)
+    o = Ws[0].size + bs[0].size
+    g_lv = gc[o:o + Ws[1].size].reshape(Ws[1].shape)[:, 9:]
+    assert np.abs(g_lv).max() > 0
