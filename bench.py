@@ -83,16 +83,26 @@ AE_ACT = [1, 0, 1, 1, 0]
 AE_FLOP_PER_SAMPLE = 1675840             # 6 x 332,224 - 2 x 158,752
 
 
-def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_all, batch, precision, steps, warmup):
+def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_all, batch, precision, steps, warmup,
+              variational=False):
     """Auxiliary metric: optimizer steps/s of the autoencoder stack (relative-MSE loss, Adam),
     per-GPU batch `batch`, gradients all-reduced over RCCL when world > 1."""
     synth = importlib.import_module("21cmvae_amd.synth")
     pp = importlib.import_module("21cmvae_amd.preprocess")
     losses = importlib.import_module("21cmvae_amd.losses")
-    st = native.Stack(ctx, AE_DIMS, AE_ACT)
-    st.set_weights(glorot(AE_DIMS, seed=4))
+    act = list(AE_ACT)
+    if variational:  # the encoder's last layer becomes the (z_mean | z_log_var) head: sampled latent + KL
+        act[1] = native.ACT_GAUSS
+    st = native.Stack(ctx, AE_DIMS, act)
+    if variational:
+        rngv = np.random.default_rng(4)
+        st.set_weights((rngv.normal(size=st.num_params) * 0.05).astype(np.float32))
+    else:
+        st.set_weights(glorot(AE_DIMS, seed=4))
     tr = native.Trainer(st, precision, batch)
     tr.set_adam(lr=1e-3)
+    if variational:
+        tr.set_vae(1e-3, sample=True, seed=11)
     sig = synth.make_signals(batch, seed=2000 + rank)
     y = pp.preproc(sig, sig)
     rw = losses.relative_mse_loss(sig)._v21_row_weight(y).astype(np.float32)
@@ -115,7 +125,8 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
     sps = steps / wall
     return {"steps_per_s": sps, "samples_per_s": sps * batch * world, "ms_per_step": 1e3 / sps,
             "batch_per_gpu": batch, "global_batch": batch * world, "precision": precision,
-            "model": "autoencoder 451-352-9-32-352-451, relative-MSE, Adam", "steps": steps,
+            "model": ("variational " if variational else "") + "autoencoder 451-352-9-32-352-451, relative-MSE" +
+                     (" + 1e-3 KL" if variational else "") + ", Adam", "steps": steps,
             "achieved_TFLOPs": sps * batch * world * AE_FLOP_PER_SAMPLE / 1e12, "final_batch_loss": loss,
             "collective": "RCCL all-reduce of the flat gradient arena (%d floats)" % (st.num_params + 1) if world > 1 else "none"}
 
@@ -426,6 +437,9 @@ def main():
                 if world == 1 and not args.no_extras:
                     out["train_ref_batch256_f32"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
                                                               sync_all, 256, "f32", 200, 10)
+                    out["train_variational"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
+                                                         sync_all, args.train_batch, args.precision, args.train_steps, 5,
+                                                         variational=True)
             except Exception as e:  # the headline metric must survive a failure of the auxiliary leg
                 out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world > 1:
