@@ -266,8 +266,8 @@ def fit_leg(precision, epochs=12):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=100)  # ~6 ms: lets the clocks settle before the timed steps
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
