@@ -501,4 +501,98 @@ __global__ void __launch_bounds__(256) gemm_dw16_kernel(const Dw16Group grp) {
     }
 }
 
+// ---- the same contraction for large batches: 128x128 output tile per workgroup, operands staged through LDS.
+// gemm_dw16_kernel pulls 1 KiB per MFMA into the CU (every wave loads its own A and B fragments); here a batch
+// step's 4 A + 4 B fragments enter LDS once (LDS-DMA, already lane-linear) and serve all four waves, each of
+// which owns a 64x64 quadrant over the whole batch slice: 0.5 KiB per MFMA and no cross-wave reduction.
+// Two stages of kDwStageSteps batch steps double-buffer the stream: one barrier per stage.
+#ifndef V21_DW_STAGE
+#define V21_DW_STAGE 8
+#endif
+constexpr int kDwStageSteps = V21_DW_STAGE;
+constexpr int kDwLdsBytes = 2 * kDwStageSteps * 8 * kFragBytes;
+template <class P>
+__global__ void __launch_bounds__(256) gemm_dw16_lds_kernel(const Dw16Group grp) {
+  using frag = typename P::frag;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+  int pi = 0;
+  while (pi + 1 < grp.count && (int)blockIdx.x >= grp.first[pi + 1]) ++pi;
+  const Dw16Args& g = grp.p[pi];
+  const int bid = blockIdx.x - grp.first[pi];
+  const int bx = bid % g.nx, by = (bid / g.nx) % g.ny, bz = bid / (g.nx * g.ny);
+  if (g.loss_acc && bid == 0 && threadIdx.x == 0) {
+    const float f = (float)((double)(long long)*g.loss_acc * (1.0 / 4294967296.0));
+    *g.loss_out = f;
+    if (g.loss_out2) *g.loss_out2 = f;
+    *g.loss_acc = 0ull;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int sbeg = bz * g.steps_per_slice, send = min(g.steps, sbeg + g.steps_per_slice);
+  const int nst = (send - sbeg + kDwStageSteps - 1) / kDwStageSteps;
+  const int mt = (g.M + 31) / 32, nt = (g.N + 31) / 32;
+  // fragment q of a step: q < 4 -> A tile 4*by + q, else B tile 4*bx + q - 4 (tiles past the operand: clamped,
+  // their rows/columns are never stored).  Wave w moves fragments w and w + 4 of every step of a stage.
+  const unsigned char* src[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = wave + 4 * u;
+    const int tile = q < 4 ? min(4 * by + q, mt - 1) : min(4 * bx + q - 4, nt - 1);
+    src[u] = reinterpret_cast<const unsigned char*>(q < 4 ? g.A : g.B) + ((long long)tile * g.BS) * kFragBytes;
+  }
+  auto issue = [&](int st) {  // stage st -> buffer st & 1; steps past the slice re-read its last step (unused)
+    const unsigned base = lds_addr(dw_smem) + (st & 1) * (kDwStageSteps * 8 * kFragBytes);
+#pragma unroll
+    for (int s = 0; s < kDwStageSteps; ++s) {
+      const int step = min(sbeg + st * kDwStageSteps + s, send - 1);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        glds16(src[u] + (long long)step * kFragBytes, lane * 16, base + (s * 8 + wave + 4 * u) * kFragBytes);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  issue(0);
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // stage st is in LDS; everyone is done with st-1
+    if (st + 1 < nst) issue(st + 1);
+    const unsigned char* buf = dw_smem + (st & 1) * (kDwStageSteps * 8 * kFragBytes) + lane * 16;
+    const int ns = min(kDwStageSteps, send - sbeg - st * kDwStageSteps);
+#pragma unroll
+    for (int s = 0; s < kDwStageSteps; ++s)
+      if (s < ns) {
+        frag fa[2], fb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[t] = *reinterpret_cast<const frag*>(buf + (s * 8 + 2 * wi + t) * kFragBytes);
+          fb[t] = *reinterpret_cast<const frag*>(buf + (s * 8 + 4 + 2 * wj + t) * kFragBytes);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = P::template mfma<false>(fa[i], fb[j], acc[i][j]);
+      }
+  }
+  float* C = g.C + (long long)bz * g.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = 128 * bx + 64 * wj + 32 * j + li;
+      const int m0r = 128 * by + 64 * wi + 32 * i + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0r + (r & 3) + 8 * (r >> 2);
+        if (n < g.N && m < g.M) C[(long long)m * g.ldc + n] = acc[i][j][r] * g.out_scale;
+      }
+    }
+}
+
 }  // namespace v21

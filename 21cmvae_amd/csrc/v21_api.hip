@@ -825,7 +825,7 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
       t->chain = true;
     }
   }
-  t->max_slices = std::max(1, (max_batch + kNtMaxKPerWg - 1) / kNtMaxKPerWg);
+  t->max_slices = std::max(1, (max_batch + 127) / 128);  // weight-gradient slices down to 8 batch steps
   CHK(zalloc(&t->d_slab, (size_t)t->max_slices * (t->P + 4), st));
   *out = t;
   return V21_OK;
@@ -1245,7 +1245,8 @@ static void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, 
   v21_mlp* m = t->mlp;
   const int L = m->L;
   const int steps = (rows + 15) / 16;
-  int nslice = (steps + 31) / 32;
+  static const int sps_big = getenv("V21_DW_SPS") ? atoi(getenv("V21_DW_SPS")) : 32;
+  int nslice = steps >= 64 ? (steps + sps_big - 1) / sps_big : (steps + 31) / 32;
   const int sps = (steps + nslice - 1) / nslice;
   nslice = (steps + sps - 1) / sps;
   const float gs = grad_opscale(brows, m->dims[L]);
@@ -1264,19 +1265,38 @@ static void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, 
   *nslice_out = nslice;
 }
 static int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t st) {
+  // large batches: 128x128 tiles staged through LDS (half the bytes pulled into a CU per MFMA)
+  const char* env = getenv("V21_DW_LDS");
+  const bool big = !probs.empty() && probs[0].steps >= 64 && !(env && env[0] == '0');
+  if (big) {
+    static bool attr_done[3] = {false, false, false};
+    if (!attr_done[prec]) {
+      if (prec == V21_PREC_F16)
+        HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
+      else
+        HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
+      attr_done[prec] = true;
+    }
+  }
   for (size_t o = 0; o < probs.size(); o += kNtMaxGroup) {
     Dw16Group grp{};
     grp.count = (int)std::min<size_t>(kNtMaxGroup, probs.size() - o);
     int blocks = 0;
     for (int i = 0; i < grp.count; ++i) {
       grp.p[i] = probs[o + i];
+      if (big) { grp.p[i].nx = (grp.p[i].N + 127) / 128; grp.p[i].ny = (grp.p[i].M + 127) / 128; }
       grp.first[i] = blocks;
       blocks += grp.p[i].nx * grp.p[i].ny * grp.p[i].nz;
     }
     grp.first[grp.count] = blocks;
     if (blocks <= 0) continue;
-    if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_kernel<PrecF16>, dim3(blocks), dim3(256), 0, st, grp);
-    else hipLaunchKernelGGL(gemm_dw16_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, st, grp);
+    if (big) {
+      if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecF16>, dim3(blocks), dim3(256), kDwLdsBytes, st, grp);
+      else hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecBF16>, dim3(blocks), dim3(256), kDwLdsBytes, st, grp);
+    } else {
+      if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_kernel<PrecF16>, dim3(blocks), dim3(256), 0, st, grp);
+      else hipLaunchKernelGGL(gemm_dw16_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, st, grp);
+    }
     HIPCHK(hipGetLastError());
   }
   return V21_OK;
