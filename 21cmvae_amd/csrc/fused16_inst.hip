@@ -15,7 +15,10 @@ hipError_t V21_EXPAND_SYM(V21_ARCH, V21_PREC)(const FusedArgs& a, int, hipStream
   using A = V21_ARCH_T(V21_ARCH);
   using P = V21_PREC_T(V21_PREC);
   auto kern = fused_fwd16<A, P>;
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {};  // the attribute belongs to (function, device): one process may drive several
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bool& attr_done = attr_done_dev[dev & 63];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds<P>());
     if (e != hipSuccess) return e;

@@ -1214,7 +1214,10 @@ static ChainStep chain_step(const float* x, long long ldx, const float* y, long 
   return st;
 }
 static int chain_attr(int prec) {
-  static bool done[3] = {false, false, false};
+  static bool done_dev[64][3] = {};  // per (device, precision): function attributes are per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bool* done = done_dev[dev & 63];
   if (done[prec]) return V21_OK;
   if (prec == V21_PREC_F16) {
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
@@ -1269,7 +1272,10 @@ static int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t
   const char* env = getenv("V21_DW_LDS");
   const bool big = !probs.empty() && probs[0].steps >= 64 && !(env && env[0] == '0');
   if (big) {
-    static bool attr_done[3] = {false, false, false};
+    static bool attr_done_dev[64][3] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool* attr_done = attr_done_dev[dev & 63];
     if (!attr_done[prec]) {
       if (prec == V21_PREC_F16)
         HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
