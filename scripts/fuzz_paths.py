@@ -1,0 +1,50 @@
+"""Randomised cross-check of the device paths against the float64 oracle (run on a GPU box; not part of the
+test suite: tests/ holds the fixed cases).  Forward: fused / small-batch / generic; training: chain and
+per-layer paths, random depths, widths, batch sizes and activations."""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+native = importlib.import_module("21cmvae_amd._native")
+from oracle import ref_numpy as ora
+ctx = native.Context.default()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = 0
+for case in range(ncase):
+    L = int(rng.integers(1, 6))
+    dims = [int(rng.integers(1, 513)) for _ in range(L + 1)]
+    act = [int(rng.integers(0, 2)) for _ in range(L - 1)] + [0]
+    n = int(rng.choice([1, 2, 31, 32, 33, 100, 257, 700]))
+    Ws, bs = ora.init_mlp(dims, seed=case)
+    bs = [rng.normal(scale=0.1, size=b.shape).astype(np.float32) for b in bs]
+    flat = ora.flatten_params(Ws, bs)
+    x = rng.normal(size=(n, dims[0])).astype(np.float32)
+    y = rng.normal(size=(n, dims[-1])).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, size=n).astype(np.float32) / dims[-1]
+    h = x.astype(np.float64); acts = [h]
+    for W_, b_, a_ in zip(Ws, bs, act):
+        h = h @ W_.astype(np.float64) + b_.astype(np.float64); h = np.maximum(h, 0) if a_ else h; acts.append(h)
+    st = native.Stack(ctx, dims, act); st.set_weights(flat)
+    for flags in (0, native.FWD_NO_SMALL, native.FWD_FORCE_GENERIC):
+        out = st.forward(x, "f32", flags)
+        scale = np.abs(h).max() + 1e-6
+        err = np.abs(out - h).max() / scale
+        if not err < 2e-5:
+            bad += 1; print("FORWARD MISMATCH", dims, act, n, flags, err)
+    lo, dz = ora.batch_loss_and_grad(h, y.astype(np.float64), w.astype(np.float64))
+    dWs, dbs = [None] * L, [None] * L
+    for li in range(L - 1, -1, -1):
+        dWs[li] = acts[li].T @ dz; dbs[li] = dz.sum(0)
+        dh = dz @ Ws[li].astype(np.float64).T
+        dz = dh * (acts[li] > 0) if li > 0 and act[li - 1] else dh
+    go = ora.flatten_params(dWs, dbs)
+    for prec, ctol in (("f32", 0.999999), ("f16", 0.999), ("bf16", 0.99)):
+        st2 = native.Stack(ctx, dims, act); st2.set_weights(flat)
+        tr = native.Trainer(st2, prec, max(n, 2)); tr.set_adam(lr=0.0); tr.set_data(0, x, y, w)
+        loss = tr.run_epoch(None, n)
+        g = tr.get_grad().astype(np.float64)
+        c = float(g @ go / (np.linalg.norm(g) * np.linalg.norm(go) + 1e-300))
+        ltol = 1e-4 if prec == "f32" else (2e-2 if prec == "f16" else 1e-1)
+        if not (c > ctol and abs(loss - lo) / lo < ltol):
+            bad += 1; print("TRAIN MISMATCH", prec, dims, act, n, "cos", c, "loss", loss, lo)
+print("cases %d, mismatches %d" % (ncase, bad))
