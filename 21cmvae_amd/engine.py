@@ -246,7 +246,10 @@ class Model:
 
     # -- training ------------------------------------------------------------------
     def compile(self, optimizer="adam", loss=None, **_):
+        prev = self.optimizer
         self.optimizer = opt_mod.get(optimizer)
+        if self.optimizer is not prev:
+            self._restore_state = None  # a new optimizer starts from zero moments (Keras semantics)
         self.loss = loss
         self._row_weight = loss_mod.row_weight_fn(loss)
         self._trainer = None
@@ -257,7 +260,12 @@ class Model:
         if self._trainer is None or self._trainer_sig != sig or self._trainer.max_batch < batch:
             self._trainer = _native.Trainer(stack, self.precision, max(batch, 1))
             self._trainer_sig = sig
-            self._trainer.set_state(self.optimizer.iterations)
+            mv = getattr(self, "_restore_state", None)  # Adam moments of a loaded file (h5lite.load_model)
+            if mv is not None and mv[0] is not None and mv[0].size == stack.num_params:
+                self._trainer.set_state(self.optimizer.iterations, mv[0], mv[1])
+            else:
+                self._trainer.set_state(self.optimizer.iterations)
+            self._restore_state = None
         o = self.optimizer
         self._trainer.set_adam(float(o.lr), o.beta_1, o.beta_2, o.epsilon)
         if any(isinstance(l, GaussianLatent) for l in self._dense_layers()):
@@ -320,10 +328,32 @@ class Model:
         tr.set_data(1, x, y, self._row_weight(y))
         return tr.evaluate(1, int(batch_size or 32))
 
-    def save(self, path):
-        """Weights (+ layer shapes) to a .npz; Keras-H5 writing is out of scope."""
+    def save(self, path, include_optimizer=True):
+        """``path`` ending in .h5/.hdf5: a Keras legacy-H5 model file (``h5write``: layer names, kernels, biases,
+        activations, and the Adam state when the model was trained) that ``tf.keras.models.load_model``,
+        h5py and ``h5lite.load_model`` read.  Anything else: a .npz of the same arrays."""
         self._sync_host()
         ls = self._dense_layers()
+        if str(path).endswith((".h5", ".hdf5")):
+            from . import h5write
+            names, seen = [], set()
+            for i, l in enumerate(ls):
+                n = l.name or ("dense" if i == 0 else "dense_%d" % i)
+                while n in seen:
+                    n += "_"
+                seen.add(n)
+                names.append(n)
+            opt = None
+            if include_optimizer and self._trainer is not None and self.optimizer is not None:
+                it, m, v = self._trainer.get_state()
+                o = self.optimizer
+                opt = {"iter": it, "m": m, "v": v,
+                       "config": {"learning_rate": float(o.lr), "beta_1": o.beta_1, "beta_2": o.beta_2, "epsilon": o.epsilon}}
+            h5write.write_keras_h5(path, names, [l.kernel for l in ls], [l.bias for l in ls],
+                                   ["linear" if l.activation == "gaussian" else l.activation for l in ls],
+                                   model_name=self.name, optimizer=opt,
+                                   extra_attrs={"v21_layer_kinds": ",".join(l.activation for l in ls)})
+            return
         blob = {"n_layers": np.array(len(ls))}
         for i, l in enumerate(ls):
             blob["W%d" % i], blob["b%d" % i] = l.kernel, l.bias

@@ -320,6 +320,8 @@ class File(Group):
 
 # ---- Keras legacy-H5 model files ------------------------------------------------------
 def _s(v):
+    if isinstance(v, np.ndarray):  # a scalar (0-d or 1-element) fixed-length string attribute
+        v = v.reshape(-1)[0]
     return v.decode("utf-8") if isinstance(v, (bytes, np.bytes_)) else str(v)
 
 
@@ -374,7 +376,13 @@ def read_keras_h5(path):
                     opt["config"] = json.loads(_s(tc)).get("optimizer_config", {}).get("config", {})
             except (H5Unsupported, KeyError, ValueError):
                 opt = None
-        return {"layers": [tuple(l) for l in layers], "optimizer": opt, "config": cfg}
+        kinds = None
+        try:
+            kv = f.attrs.get("v21_layer_kinds")  # written by Model.save: marks variational heads
+            kinds = _s(kv).split(",") if kv is not None else None
+        except H5Unsupported:
+            kinds = None
+        return {"layers": [tuple(l) for l in layers], "optimizer": opt, "config": cfg, "kinds": kinds}
 
 
 def load_model(path):
@@ -400,5 +408,21 @@ def load_model(path):
     m = sequential_from_arrays(Ws, bs, acts, name=(info["config"] or {}).get("config", {}).get("name") if isinstance((info["config"] or {}).get("config"), dict) else None)
     for layer, l in zip(m._layers, info["layers"]):
         layer.name = l[0]
+    if info.get("kinds") and len(info["kinds"]) == len(m._layers):
+        from .engine import GaussianLatent
+        for i, kind in enumerate(info["kinds"]):
+            if kind == "gaussian":  # (in, 2*latent) kernel of a variational head
+                old = m._layers[i]
+                g = GaussianLatent(old.kernel.shape[1] // 2, name=old.name)
+                g.kernel, g.bias, g.input_dim = old.kernel, old.bias, old.input_dim
+                m._layers[i] = g
     m._loaded_optimizer = info["optimizer"]
+    o = info["optimizer"]
+    if o is not None:  # as tf.keras.models.load_model does: the optimizer comes back with its state
+        from . import optimizers
+        c = o.get("config") or {}
+        m.optimizer = optimizers.Adam(c.get("learning_rate", 1e-3), c.get("beta_1", 0.9), c.get("beta_2", 0.999),
+                                      c.get("epsilon", 1e-7))
+        m.optimizer.iterations = int(o.get("iter", 0))
+        m._restore_state = (o.get("m"), o.get("v"))
     return m

@@ -205,3 +205,40 @@ def test_f16_training_early_stop_restores_best_weights(data):
     l2, v2 = direm.train(epochs=3, verbose=0)
     assert v2[-1] < 1.5 * v1[best]
     assert len(good) == len(direm.emulator.get_weights())
+
+
+def test_save_keras_h5_and_resume_training(data, tmp_path):
+    """Model.save('x.h5') writes a Keras legacy-H5 file (weights, layer names, activations, Adam state) that
+    load_model reads back; compiling the loaded model with ITS optimizer resumes training exactly where the
+    original would have continued (same weights after the same further epochs)."""
+    emulator, optm, eng, h5 = pkg("emulator"), pkg("optimizers"), pkg("engine"), pkg("h5lite")
+    eng.set_random_seed(5)
+    a = emulator.DirectEmulator(hidden_dims=[48, 32], **data)
+    a.emulator.compile(optimizer=optm.Adam(0.002), loss=emulator.relative_mse_loss(a.signal_train))
+    a.train(epochs=3, verbose=0)
+    p = str(tmp_path / "emulator.h5")
+    a.emulator.save(p)
+    b = emulator.DirectEmulator(hidden_dims=[48, 32], **data)
+    b.load_model(p)
+    for wa, wb in zip(a.emulator.get_weights(), b.emulator.get_weights()):
+        np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(a.predict(a.par_test[:9]), b.predict(b.par_test[:9]))
+    assert [l.name for l in b.emulator.layers] == [l.name or n for l, n in zip(a.emulator.layers, ["dense", "dense_1", "dense_2"])]
+    ob = b.emulator.optimizer
+    assert ob is not None and ob.iterations == a.emulator.optimizer.iterations and float(ob.lr) == np.float32(0.002)
+    # resume: same shuffles -> identical continuation
+    b.emulator.compile(optimizer=ob, loss=emulator.relative_mse_loss(b.signal_train))
+    eng.set_random_seed(9); la, _ = a.train(epochs=2, verbose=0)
+    eng.set_random_seed(9); lb, _ = b.train(epochs=2, verbose=0)
+    np.testing.assert_allclose(lb, la, rtol=1e-6)
+    for wa, wb in zip(a.emulator.get_weights(), b.emulator.get_weights()):
+        np.testing.assert_allclose(wb, wa, rtol=1e-5, atol=1e-7)
+    # a variational encoder keeps its head through the file
+    ae = emulator.AutoEncoder(a.signal_train, [16], [16], latent_dim=4, variational=True)
+    ae.build((None, 451))
+    pe = str(tmp_path / "encoder.h5")
+    ae.encoder.save(pe)
+    enc = h5.load_model(pe)
+    assert isinstance(enc.layers[-1], eng.GaussianLatent) and enc.layers[-1].kernel.shape == (16, 8)
+    y = pkg("preprocess").preproc(a.signal_test[:5], a.signal_train)
+    np.testing.assert_array_equal(enc.predict(y), ae.encoder.predict(y))
