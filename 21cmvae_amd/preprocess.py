@@ -74,7 +74,7 @@ def _to_log_space(p):
     for j in range(p.shape[1]):
         col = p[:, j]
         if j in ZERO_FLOOR:
-            col = col.copy()
+            col = col.astype(np.float64)  # (an integer array would truncate the floor to 0: preprocess.py:75-76)
             col[col == 0] = ZERO_FLOOR[j]
         out[:, j] = np.log10(col) if j in LOG_COLUMNS else col
     return out
