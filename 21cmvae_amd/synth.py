@@ -76,3 +76,15 @@ def make_dataset(n_train=N_TRAIN, n_val=N_VAL, n_test=N_TEST, seed=1):
     pt, pv, pe = make_params(n_train, seed, corners=True), make_params(n_val, seed + 100), make_params(n_test, seed + 200)
     return dict(par_train=pt, par_val=pv, par_test=pe, signal_train=signals_from_params(pt),
                 signal_val=signals_from_params(pv), signal_test=signals_from_params(pe))
+
+
+def save_dataset(path, data=None):
+    """Write the six arrays in the layout of ``dataset_21cmVAE.h5`` (emulator.py:198-204) with the
+    built-in HDF5 writer, so the no-argument constructors (``$V21_DATASET``) can be tried on synthetic data."""
+    from . import h5write
+    data = make_dataset() if data is None else data
+    f = h5write.FileW()
+    for k in ("par_train", "par_val", "par_test", "signal_train", "signal_val", "signal_test"):
+        f.create_dataset(k, np.ascontiguousarray(data[k]))
+    f.write(path)
+    return path

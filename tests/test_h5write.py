@@ -104,3 +104,18 @@ def test_real_hdf5_library_reads_the_file(tmp_path):
     assert out["shapes"] == [[16], [8], [451]]
     assert out["iter"] == 17568 and out["iter_shape"] == []
     np.testing.assert_allclose(out["vsum"], float(opt["v"][-451:].sum()), rtol=1e-6)
+
+
+def test_dataset_file_round_trip(tmp_path, monkeypatch):
+    """synth.save_dataset -> the file the no-argument constructors look for ($V21_DATASET): the six arrays come
+    back bit-identical through emulator.load_dataset (the reference reads them at import, emulator.py:198-204)."""
+    synth = importlib.import_module("21cmvae_amd.synth")
+    emu = importlib.import_module("21cmvae_amd.emulator")
+    data = synth.make_dataset(60, 20, 10, seed=4)
+    p = synth.save_dataset(str(tmp_path / "dataset_21cmVAE.h5"), data)
+    got = emu.load_dataset(p)
+    assert sorted(got) == sorted(data)
+    for k in data:
+        assert got[k].dtype == data[k].dtype and got[k].shape == data[k].shape
+        np.testing.assert_array_equal(got[k], data[k])
+    monkeypatch.setattr(emu, "_dataset", None)
