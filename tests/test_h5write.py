@@ -111,6 +111,7 @@ def test_dataset_file_round_trip(tmp_path, monkeypatch):
     back bit-identical through emulator.load_dataset (the reference reads them at import, emulator.py:198-204)."""
     synth = importlib.import_module("21cmvae_amd.synth")
     emu = importlib.import_module("21cmvae_amd.emulator")
+    monkeypatch.setattr(emu, "_dataset", emu._dataset)  # load_dataset caches: undo it at teardown
     data = synth.make_dataset(60, 20, 10, seed=4)
     p = synth.save_dataset(str(tmp_path / "dataset_21cmVAE.h5"), data)
     got = emu.load_dataset(p)
@@ -118,4 +119,3 @@ def test_dataset_file_round_trip(tmp_path, monkeypatch):
     for k in data:
         assert got[k].dtype == data[k].dtype and got[k].shape == data[k].shape
         np.testing.assert_array_equal(got[k], data[k])
-    monkeypatch.setattr(emu, "_dataset", None)
