@@ -160,6 +160,13 @@ struct PrecBF16w8 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 9, 
 // (A/B-tested and dropped in round 1: read-ahead depth 1/3 and ring geometries 20x4 / 12x6 -- all within
 // 0.5 % of the 16x5, depth-2 configuration above)
 
+// Variant "x2sp": x2 with the ring refill spread over the block being consumed (one DMA per wave every 4
+// k-steps, issued by every wave -- no wave-dependent branch) instead of a burst of 4 at each rendezvous.
+struct PrecF16x2sp : PrecF16x2 { static constexpr bool SPREAD_DMA = true; };
+struct PrecBF16x2sp : PrecBF16x2 { static constexpr bool SPREAD_DMA = true; };
+template <class P, class = void> struct spread_of { static constexpr bool value = false; };
+template <class P> struct spread_of<P, std::void_t<decltype(P::SPREAD_DMA)>> { static constexpr bool value = P::SPREAD_DMA; };
+
 // ---- compile-time geometry of (architecture, precision) ---------------------------
 // Arch::L layers, Arch::dims[L+1], Arch::act[L] (1 = ReLU).  The last layer is the
 // "output orientation" layer and must be linear.
@@ -375,7 +382,7 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
 #define V21_FUSED_SPREAD 0
 #endif
   constexpr int D = P::DEPTH;  // LDS read-ahead, in fragments
-  constexpr bool SPREAD = V21_FUSED_SPREAD != 0;
+  constexpr bool SPREAD = (V21_FUSED_SPREAD != 0) || spread_of<P>::value;
   constexpr int TOTAL = G::total();
   constexpr int NOUT = G::dim(L);
   constexpr int NCH = CT * 8;  // epilogue chunks per tile
@@ -550,9 +557,15 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
     if constexpr (S < TOTAL) {
       ring_boundary<G, CT, D, S, SPREAD>(a.stream, smem, wave, lane, a.dbg);
       if constexpr (SPREAD && S / kBlkFrags >= 2) {
-        // refill of slot (B-2): piece o/4 of block B+kRing-2, by wave o%4, at offset o
+        // refill of slot (B-2), spread over the block being consumed: EVERY wave issues its piece o/W of block
+        // B+kRing-2 at offsets o = 0, W, 2W, ... (W = waves) -- one DMA per W k-steps instead of a burst of
+        // BLK/W at the rendezvous, and no wave-dependent branch in the unrolled stream
         constexpr int Bc = S / kBlkFrags, o = S % kBlkFrags;
-        if (wave == (o & 3)) issue_piece<G, Bc + kRing - 2, o / 4>(a.stream, smem, wave, lane);
+#ifndef V21_SP_PHASE
+#define V21_SP_PHASE 3  // measured r1: the last step of each group of W beats the first (which coincides with the rendezvous)
+#endif
+        if constexpr (o % G::WAVES == V21_SP_PHASE % G::WAVES)
+          issue_piece<G, Bc + kRing - 2, o / G::WAVES>(a.stream, smem, wave, lane);
       }
       constexpr Item it = G::item_at(S);
       if constexpr (it.ks >= 0) {

@@ -206,6 +206,11 @@ V21_ARCH_LIST(V21_DECL3)
   hipError_t launch_fused_##a##_BF16w8(const FusedArgs&, int, hipStream_t);
 V21_ARCH_LIST(V21_DECL4)
 #undef V21_DECL4
+#define V21_DECL5(a)                                                         \
+  hipError_t launch_fused_##a##_F16x2sp(const FusedArgs&, int, hipStream_t); \
+  hipError_t launch_fused_##a##_BF16x2sp(const FusedArgs&, int, hipStream_t);
+V21_ARCH_LIST(V21_DECL5)
+#undef V21_DECL5
 }  // namespace v21
 
 typedef hipError_t (*fused_launcher)(const FusedArgs&, int, hipStream_t);
@@ -217,12 +222,14 @@ struct FusedEntry {
   fused_launcher fn_x2[3]; // two workgroups per CU, one column tile per wave (f16/bf16)
   fused_launcher fn_s16[3]; // same occupancy, 16x16x32 MFMA shape (fused_fwd16.h)
   fused_launcher fn_w8[3];  // one 8-wave workgroup per CU: the two waves of a SIMD share the weight ring
+  fused_launcher fn_sp[3];  // x2 with the ring refill spread over the block being consumed
 };
 #define V21_ENTRY(a)                                                                                          \
   {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_##a##_F32, launch_fused_##a##_F16, launch_fused_##a##_BF16}, \
    {nullptr, launch_fused_##a##_F16x2, launch_fused_##a##_BF16x2},                                         \
    {nullptr, launch_fused_##a##_F16s16, launch_fused_##a##_BF16s16},                                       \
-   {nullptr, launch_fused_##a##_F16w8, launch_fused_##a##_BF16w8}},
+   {nullptr, launch_fused_##a##_F16w8, launch_fused_##a##_BF16w8},                                         \
+   {nullptr, launch_fused_##a##_F16x2sp, launch_fused_##a##_BF16x2sp}},
 static const FusedEntry g_fused[] = {V21_ARCH_LIST(V21_ENTRY)};
 #undef V21_ENTRY
 
@@ -553,6 +560,13 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
     const char* w8 = getenv("V21_FUSED_W8");
     if (w8 && w8[0] == '1' && g_fused[m->fused_id].fn_w8[precision]) {
       HIPCHK(g_fused[m->fused_id].fn_w8[precision](a, 0, m->ctx->stream));
+      return V21_OK;
+    }
+  }
+  {
+    const char* sp = getenv("V21_FUSED_SP");  // default for f16/bf16 since r1 (2-3 % over plain x2); 0 = plain x2
+    if (!(sp && sp[0] == '0') && x2 && g_fused[m->fused_id].fn_sp[precision]) {
+      HIPCHK(g_fused[m->fused_id].fn_sp[precision](a, 0, m->ctx->stream));
       return V21_OK;
     }
   }

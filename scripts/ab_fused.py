@@ -15,7 +15,7 @@ B = 65536
 x = rng.uniform(-1, 1, size=(B, 7)).astype(np.float32)
 d_x, d_y = ctx.malloc(x.nbytes), ctx.malloc(B * 451 * 4)
 ctx.h2d(d_x, x)
-KEYS = ("X2", "PRIO", "DELAY", "PIN", "S16", "W8")
+KEYS = ("X2", "PRIO", "DELAY", "PIN", "S16", "W8", "SP")
 def setv(v):
     for k in KEYS:
         os.environ.pop("V21_FUSED_" + k, None)
