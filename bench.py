@@ -369,7 +369,8 @@ def main():
                    "batch_per_gpu": B, "weights": "Glorot-uniform seed 3", "parallelism": "rows sharded, no collective"},
         "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": PEAK_TFLOPS[args.precision],
                      "unit": "TFLOP/s", "frac": achieved_tf / PEAK_TFLOPS[args.precision], "traffic": None,
-                     "kernel": "fused_fwd<ArchS1>", "kernel_ms": kern_s * 1e3,
+                     "kernel": "fused_fwd<ArchS1, Prec%sx2sp>" % args.precision.upper() if args.precision != "f32" else "fused_fwd<ArchS1, PrecF32>",
+                     "kernel_ms": kern_s * 1e3,
                      "hbm_GBps_algorithmic": BYTES_PER_SIGNAL * B / kern_s / 1e9,
                      "hbm_frac_of_8TBps": BYTES_PER_SIGNAL * B / kern_s / 1e9 / PEAK_HBM_GBS},
     }
