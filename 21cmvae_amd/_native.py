@@ -90,6 +90,8 @@ SIGNATURES = {
     "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
     "v21_trainer_chain_stamps": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
+    "v21_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "v21_host_free": (C.c_int, [_P, _P]),
     "v21_sweep_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),
     "v21_sweep_destroy": (C.c_int, [_P]),
     "v21_sweep_run_epoch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
@@ -177,6 +179,49 @@ class Context:
         p = _P()
         check(self.lib.v21_malloc(self.h, nbytes, C.byref(p)))
         return p.value
+
+    # ---- page-locked result buffers -----------------------------------------------------------
+    # A large predict() result lands in host memory over PCIe; into an ordinary numpy array the
+    # runtime goes through an internal staging buffer (~10 GB/s), into page-locked memory it goes
+    # directly.  Pinning is expensive, so buffers are pooled: an array handed out owns its buffer
+    # until it is garbage-collected, then the buffer returns to the pool (at most PIN_POOL_MAX
+    # buffers are alive; beyond that, and for small results, plain numpy arrays are used).
+    PIN_MIN_BYTES = 8 << 20
+    PIN_POOL_MAX = 4
+
+    def pinned_empty(self, shape, dtype=np.float32):
+        """A numpy array in page-locked memory, or None (pool exhausted / small / unavailable)."""
+        import weakref
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if nbytes < self.PIN_MIN_BYTES:
+            return None
+        pool = self.__dict__.setdefault("_pin_pool", {"free": [], "live": 0})
+        ptr = None
+        for i, (p, cap) in enumerate(pool["free"]):
+            if cap >= nbytes:
+                ptr, cap_ = pool["free"].pop(i)
+                break
+        if ptr is None:
+            if pool["live"] + len(pool["free"]) >= self.PIN_POOL_MAX:
+                if pool["free"]:  # replace the smallest idle buffer by one that fits
+                    pool["free"].sort(key=lambda t: t[1])
+                    q, _ = pool["free"].pop(0)
+                    self.lib.v21_host_free(self.h, _P(q))
+                else:
+                    return None
+            hp = _P()
+            if self.lib.v21_host_alloc(self.h, nbytes, C.byref(hp)) != 0:
+                return None
+            ptr, cap_ = hp.value, nbytes
+        raw = (C.c_char * nbytes).from_address(ptr)
+        arr = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        pool["live"] += 1
+
+        def _back(pool=pool, ptr=ptr, cap=cap_):
+            pool["live"] -= 1
+            pool["free"].append((ptr, cap))
+        weakref.finalize(raw, _back)  # `raw` lives exactly as long as any view of the array
+        return arr
 
     def free(self, dptr):
         check(self.lib.v21_free(self.h, _P(dptr)))
@@ -290,7 +335,9 @@ class Stack:
         x = np.ascontiguousarray(x)
         if x.ndim != 2 or x.shape[1] != self.dims[0]:
             raise ValueError("expected input of shape (n, %d), got %r" % (self.dims[0], x.shape))
-        y = np.empty((x.shape[0], self.dims[-1]), np.float32)
+        y = self.ctx.pinned_empty((x.shape[0], self.dims[-1]))
+        if y is None:
+            y = np.empty((x.shape[0], self.dims[-1]), np.float32)
         with self.ctx.lock:
             check(self.lib.v21_mlp_forward(self.h, x.ctypes.data_as(_P), dt, x.shape[0], _fptr(y),
                                            precision_id(precision), flags))

@@ -151,6 +151,13 @@ extern "C" int v21_malloc(v21_ctx* c, size_t bytes, void** p) {
   HIPCHK(hipMalloc(p, bytes ? bytes : 4));
   return V21_OK;
 }
+extern "C" int v21_host_alloc(v21_ctx* c, size_t bytes, void** p) {
+  CHK(use(c));
+  if (!p || bytes == 0) return fail(V21_ERR_ARG, "bad host allocation request");
+  HIPCHK(hipHostMalloc(p, bytes, hipHostMallocDefault));
+  return V21_OK;
+}
+extern "C" int v21_host_free(v21_ctx* c, void* p) { CHK(use(c)); if (p) HIPCHK(hipHostFree(p)); return V21_OK; }
 extern "C" int v21_free(v21_ctx* c, void* p) { CHK(use(c)); if (p) HIPCHK(hipFree(p)); return V21_OK; }
 extern "C" int v21_memcpy_h2d(v21_ctx* c, void* d, const void* s, size_t b) {
   CHK(use(c));

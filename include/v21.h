@@ -88,6 +88,11 @@ int v21_ctx_get_stream(v21_ctx* ctx, void** hip_stream);
 /* device memory + copies + event timing, so a host program needs nothing else */
 int v21_malloc(v21_ctx* ctx, size_t bytes, void** dptr);
 int v21_free(v21_ctx* ctx, void* dptr);
+/* page-locked host memory: a result buffer of this kind is filled by the device over PCIe
+ * directly (no staging copy) -- the Python shim hands out numpy arrays backed by a pool of
+ * them for large predict() results */
+int v21_host_alloc(v21_ctx* ctx, size_t bytes, void** hptr);
+int v21_host_free(v21_ctx* ctx, void* hptr);
 int v21_memcpy_h2d(v21_ctx* ctx, void* dst, const void* src, size_t bytes);
 int v21_memcpy_d2h(v21_ctx* ctx, void* dst, const void* src, size_t bytes);
 int v21_memset(v21_ctx* ctx, void* dst, int value, size_t bytes);

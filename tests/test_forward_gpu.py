@@ -212,3 +212,29 @@ def test_small_batch_path_with_transforms_and_edges(ctx):
     sw = _stack(ctx, Ww, bw)
     x = np.random.default_rng(0).normal(size=(3, 7)).astype(np.float32)
     np.testing.assert_allclose(sw.forward(x, "f32"), ora.mlp_forward(Ww, bw, x), atol=3e-5, rtol=3e-5)
+
+
+def test_large_results_come_back_in_pooled_pinned_buffers(ctx):
+    """predict() results above 8 MB are written by the device straight into page-locked memory handed out as
+    numpy arrays from a pool: a result that is still referenced must never be overwritten by a later call,
+    and a released one is reused."""
+    Ws, bs = ora.init_mlp(S1, seed=2)
+    st = _stack(ctx, Ws, bs)
+    rng = np.random.default_rng(0)
+    n = 6000  # 6000 x 451 x 4 B = 10.8 MB
+    xs = [rng.uniform(-1, 1, size=(n, 7)).astype(np.float32) for _ in range(6)]
+    keep = [st.forward(x, "f16") for x in xs]          # six live results: more than the pool holds
+    copies = [k.copy() for k in keep]
+    again = [st.forward(x, "f16") for x in xs]
+    for k, c, a in zip(keep, copies, again):
+        np.testing.assert_array_equal(k, c)             # untouched by the later calls
+        np.testing.assert_array_equal(a, c)             # and reproducible
+    ref = ora.mlp_forward(Ws, bs, xs[0][:50])
+    np.testing.assert_allclose(keep[0][:50], ref, atol=3e-2, rtol=3e-2)
+    pool = ctx.__dict__.get("_pin_pool")
+    assert pool is not None and pool["live"] <= ctx.PIN_POOL_MAX
+    del keep, again
+    import gc; gc.collect()
+    assert pool["live"] == 0 and 1 <= len(pool["free"]) <= ctx.PIN_POOL_MAX
+    y = st.forward(xs[0], "f16")                        # served from the pool again
+    np.testing.assert_array_equal(y, copies[0])
