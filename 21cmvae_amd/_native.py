@@ -195,31 +195,34 @@ class Context:
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         if nbytes < self.PIN_MIN_BYTES:
             return None
-        pool = self.__dict__.setdefault("_pin_pool", {"free": [], "live": 0})
+        import threading
+        pool = self.__dict__.setdefault("_pin_pool", {"free": [], "live": 0, "lock": threading.Lock()})
         ptr = None
-        for i, (p, cap) in enumerate(pool["free"]):
-            if cap >= nbytes:
-                ptr, cap_ = pool["free"].pop(i)
-                break
-        if ptr is None:
-            if pool["live"] + len(pool["free"]) >= self.PIN_POOL_MAX:
-                if pool["free"]:  # replace the smallest idle buffer by one that fits
-                    pool["free"].sort(key=lambda t: t[1])
-                    q, _ = pool["free"].pop(0)
-                    self.lib.v21_host_free(self.h, _P(q))
-                else:
+        with pool["lock"]:  # finalizers of released arrays may run on any thread
+            for i, (p, cap) in enumerate(pool["free"]):
+                if cap >= nbytes:
+                    ptr, cap_ = pool["free"].pop(i)
+                    break
+            if ptr is None:
+                if pool["live"] + len(pool["free"]) >= self.PIN_POOL_MAX:
+                    if pool["free"]:  # replace the smallest idle buffer by one that fits
+                        pool["free"].sort(key=lambda t: t[1])
+                        q, _ = pool["free"].pop(0)
+                        self.lib.v21_host_free(self.h, _P(q))
+                    else:
+                        return None
+                hp = _P()
+                if self.lib.v21_host_alloc(self.h, nbytes, C.byref(hp)) != 0:
                     return None
-            hp = _P()
-            if self.lib.v21_host_alloc(self.h, nbytes, C.byref(hp)) != 0:
-                return None
-            ptr, cap_ = hp.value, nbytes
+                ptr, cap_ = hp.value, nbytes
+            pool["live"] += 1
         raw = (C.c_char * nbytes).from_address(ptr)
         arr = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-        pool["live"] += 1
 
         def _back(pool=pool, ptr=ptr, cap=cap_):
-            pool["live"] -= 1
-            pool["free"].append((ptr, cap))
+            with pool["lock"]:
+                pool["live"] -= 1
+                pool["free"].append((ptr, cap))
         weakref.finalize(raw, _back)  # `raw` lives exactly as long as any view of the array
         return arr
 
