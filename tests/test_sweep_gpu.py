@@ -86,3 +86,33 @@ def test_sweep_argument_errors(ctx):
     sw = native.Sweep([a, d])
     with pytest.raises(native.EngineError):
         sw.run_epoch(None, 16)  # trainer 0 has no training set
+
+
+def test_sweep_group_sizes(ctx):
+    """One model is a valid group; 16 is the most one launch group holds; 17 is refused."""
+    native = pkg("_native")
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(64, 12)).astype(np.float32)
+    w = np.full(64, 1.0 / 12, np.float32)
+
+    def make(k, prec="f16"):
+        st = native.Stack(ctx, [12, 8 + k, 12], [1, 0])
+        Ws, bs = ora.init_mlp([12, 8 + k, 12], seed=k)
+        st.set_weights(ora.flatten_params(Ws, bs))
+        tr = native.Trainer(st, prec, 64)
+        tr.set_adam(lr=1e-3)
+        return tr
+    solo = make(0); solo.set_data(0, x, None, w)
+    ref = [solo.run_epoch(None, 32) for _ in range(2)]
+    one = make(0); one.set_data(0, x, None, w)
+    sw1 = native.Sweep([one])
+    got = [sw1.run_epoch(None, 32)[0] for _ in range(2)]
+    np.testing.assert_allclose(got, ref, rtol=1e-6)
+    many = [make(k) for k in range(16)]
+    many[0].set_data(0, x, None, w)
+    sw16 = native.Sweep(many)
+    l16 = sw16.run_epoch(None, 32)
+    assert len(l16) == 16 and np.all(np.isfinite(l16))
+    np.testing.assert_allclose(l16[0], ref[0], rtol=1e-3)  # model 0 of the big group = the solo model's first epoch
+    with pytest.raises(native.EngineError):
+        native.Sweep(many + [make(16)])
