@@ -70,6 +70,11 @@ struct ChainModel {
   // depend on the order of arrival); gemm_dw16_kernel turns it into the float slot and clears it
   unsigned long long* loss_acc;
   unsigned long long* stamps;      // diagnostics: s_memtime of workgroup 0 at every phase boundary
+  // variational head (per model, so the members of a sweep may differ): loss_i += kl_weight * KL_i;
+  // eps keyed on (seed, step, row0 + row, d) as in train_kernels.h
+  float kl_weight;
+  int sample;
+  unsigned long long seed, step;
 };
 // the batch of this step (shared by every model of a sweep)
 struct ChainStep {
@@ -80,10 +85,9 @@ struct ChainStep {
   int rows;                        // rows of this rank's batch
   float scale;                     // 2 / B_global
   float gs;                        // gradient operand scale (power of two)
-  // variational head: loss_i += kl_weight * KL_i; eps keyed on (seed, step, row0 + row, d) as in train_kernels.h
-  float kl_weight, kl_over_b;      // kl_weight, kl_weight / B_global
-  int sample;
-  unsigned long long seed, step, row0;
+  float inv_b;                     // 1 / B_global (the KL term's own gradient)
+  unsigned long long row0;         // position of this rank's first row in the global batch (noise key)
+  unsigned long long step_off;     // steps since the per-model `step` was stored (a sweep stores it once per epoch)
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
@@ -305,13 +309,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
           if (d < LAT) {
             const float mu = zs[tid * ZP + d], lv = zs[tid * ZP + LAT + d];
             const float sd = expf(0.5f * lv);
-            const float e = st.sample ? gauss_eps(st.seed, st.step, st.row0 + m0 + tid, d) : 0.f;
+            const float e = a.sample ? gauss_eps(a.seed, a.step + st.step_off, st.row0 + m0 + tid, d) : 0.f;
             z = mu + sd * e;
             kl += -0.5f * (1.0f + lv - mu * mu - sd * sd);
           }
           out[tid * PITCH + d] = (elem)z;
         }
-        klb[tid] = ok ? st.kl_weight * kl : 0.f;
+        klb[tid] = ok ? a.kl_weight * kl : 0.f;
       }
     } else
     // columns the tiles did not cover, up to the next contraction's padded range: zero
@@ -350,10 +354,10 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       for (int d = 0; d < LAT; ++d) {
         const float mu = zs[tid * ZP + d], lv = zs[tid * ZP + LAT + d];
         const float sd = expf(0.5f * lv);
-        const float e = st.sample ? gauss_eps(st.seed, st.step, st.row0 + m0 + tid, d) : 0.f;
+        const float e = a.sample ? gauss_eps(a.seed, a.step + st.step_off, st.row0 + m0 + tid, d) : 0.f;
         const float g = (float)b[tid * PITCH + d];
         const bool ok = m0 + tid < st.rows;
-        const float kb = ok ? st.gs * st.kl_over_b : 0.f;
+        const float kb = ok ? st.gs * a.kl_weight * st.inv_b : 0.f;
         b[tid * PITCH + d] = (elem)(g + kb * mu);                                          // d mu (in place)
         b[tid * PITCH + LAT + d] = (elem)(g * e * 0.5f * sd + kb * 0.5f * (sd * sd - 1.0f));  // d lv (columns past dz)
       }

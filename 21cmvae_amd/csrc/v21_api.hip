@@ -1217,6 +1217,7 @@ static ChainModel chain_model(v21_trainer* t) {
   a.BS = t->BS;
   a.loss_acc = (unsigned long long*)t->d_ticket;
   a.stamps = t->d_stamps;
+  if (t->gl >= 0) { a.kl_weight = t->kl_weight; a.sample = t->sample; a.seed = t->seed; a.step = (unsigned long long)t->iter; }
   return a;
 }
 static ChainStep chain_step(const float* x, long long ldx, const float* y, long long ldy, const float* rw,
@@ -1227,11 +1228,9 @@ static ChainStep chain_step(const float* x, long long ldx, const float* y, long 
   st.rows = rows;
   st.scale = 2.0f / (float)brows;
   st.gs = grad_opscale(brows, dout);
-  if (vae && vae->gl >= 0) {
-    st.kl_weight = vae->kl_weight; st.kl_over_b = vae->kl_weight / (float)brows;
-    st.sample = vae->sample; st.seed = vae->seed; st.step = (unsigned long long)vae->iter;
-    st.row0 = (unsigned long long)row0;
-  }
+  st.inv_b = 1.0f / (float)brows;
+  st.row0 = (unsigned long long)row0;
+  (void)vae;
   return st;
 }
 static int chain_attr(int prec) {
@@ -1542,7 +1541,8 @@ extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** o
       return fail(V21_ERR_ARG, "model %d: context, precision and max_batch must match model 0", k);
     if (m->L != m0->L || m->act != m0->act || m->dims[0] != m0->dims[0] || m->dims[m->L] != m0->dims[m0->L])
       return fail(V21_ERR_ARG, "model %d: depth, activations and in/out width must match model 0", k);
-    if (t->gl >= 0) return fail(V21_ERR_UNSUPPORTED, "variational stacks are not swept in this build");
+    if (t->gl >= 0 && !t->chain)
+      return fail(V21_ERR_UNSUPPORTED, "variational stacks are swept on the chain path only (f16/bf16, latent <= %d)", kChainMaxLatent);
     for (int j = 0; j < k; ++j)
       if (trainers[j] == t) return fail(V21_ERR_ARG, "trainer %d listed twice", k);
   }
@@ -1795,8 +1795,10 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
     const long long lo = first + (long long)brows * rk / R, hi = first + (long long)brows * (rk + 1) / R;
     const int rows = (int)(hi - lo);
     if (s->chain) {
-      CHK(sweep_step_chain(s, chain_step(t0->d_x[0], din, t0->y_is_x[0] ? nullptr : t0->d_y[0], dout, t0->d_rw[0], d_idx,
-                                         lo, rows, brows, dout), brows, sidx));
+      ChainStep cs = chain_step(t0->d_x[0], din, t0->y_is_x[0] ? nullptr : t0->d_y[0], dout, t0->d_rw[0], d_idx, lo, rows,
+                                brows, dout, nullptr, lo - first);
+      cs.step_off = (unsigned long long)sidx;  // the table holds every model's step counter as of the epoch's start
+      CHK(sweep_step_chain(s, cs, brows, sidx));
       continue;
     }
     if (rows > 0)

@@ -116,3 +116,35 @@ def test_sweep_group_sizes(ctx):
     np.testing.assert_allclose(l16[0], ref[0], rtol=1e-3)  # model 0 of the big group = the solo model's first epoch
     with pytest.raises(native.EngineError):
         native.Sweep(many + [make(16)])
+
+
+def test_sweep_of_variational_models_equals_individual_training():
+    """Variational autoencoders of different latent widths and KL weights in one sweep (chain path, f16): the
+    per-model noise streams (seed, step, row) make the grouped run reproduce the individual runs."""
+    synth, eng, sweep, emulator, optm = pkg("synth"), pkg("engine"), pkg("sweep"), pkg("emulator"), pkg("optimizers")
+    sig = synth.make_signals(260, seed=3)
+    y = ora.preproc(sig, sig)
+    cfgs = [dict(latent_dim=4, kl_weight=1e-3), dict(latent_dim=9, kl_weight=1e-4), dict(latent_dim=16, kl_weight=0.0)]
+
+    def models():
+        eng.set_random_seed(21)
+        out = []
+        for c in cfgs:
+            ae = emulator.AutoEncoder(sig, enc_hidden_dims=[48], dec_hidden_dims=[32, 48], variational=True, **c)
+            ae.precision = "f16"
+            ae.build((None, 451))
+            ae._vae_seed = 1000 + c["latent_dim"]  # same noise stream in both runs
+            ae.compile(optimizer=optm.Adam(1e-3), loss=emulator.relative_mse_loss(sig))
+            out.append(ae)
+        return out
+    solo, grouped = models(), models()
+    hs = []
+    for m in solo:
+        eng.set_random_seed(5)
+        hs.append(m.fit(y, y, batch_size=128, epochs=3))
+    eng.set_random_seed(5)
+    hg = sweep.fit_models(grouped, y, y, batch_size=128, epochs=3)
+    for a, b, ha, hb in zip(solo, grouped, hs, hg):
+        np.testing.assert_allclose(hb.history["loss"], ha.history["loss"], rtol=3e-3)
+        for wa, wb in zip(a.get_weights(), b.get_weights()):
+            np.testing.assert_allclose(wb, wa, atol=3e-3, rtol=1e-3)
