@@ -84,9 +84,6 @@ struct FusedArgs {
   int in_transform;
   v21_affine_in tin;
   unsigned long long* dbg;      // diagnostic builds only (V21_FUSED_STAMP): cycle stamps
-  unsigned* phase_ctr;          // x2 variants: per-CU arrival counters (2048 words) for de-phasing
-  int prio_mode;                // x2 variants: 1 = the second workgroup of a CU runs at s_setprio 1 (static)
-  int delay_sleeps;             // x2 variants: start delay of the second workgroup of a CU, in s_sleep 127 units
 };
 
 // ---- precision traits ------------------------------------------------------------
@@ -152,13 +149,8 @@ struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 4, 
 struct PrecF16x2 : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
 struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 5, WPS = 2; };
 #endif
-// Variant "w8": the two waves of a SIMD belong to ONE 512-thread workgroup and share one ring, so every
-// weight fragment is pulled into the CU once for 256 signals instead of once per 128 (half the L2->LDS
-// stream per CU; ring up to 144 KiB since a single workgroup owns the CU's LDS).
-struct PrecF16w8 : PrecF16 { static constexpr int CT = 1, BLK = 16, RING = 9, WPS = 1, WAVES = 8; };
-struct PrecBF16w8 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 9, WPS = 1, WAVES = 8; };
-// (A/B-tested and dropped in round 1: read-ahead depth 1/3 and ring geometries 20x4 / 12x6 -- all within
-// 0.5 % of the 16x5, depth-2 configuration above)
+// (A/B-tested and dropped in round 1, see DESIGN.md: one wave per SIMD with two column tiles, a shared ring
+// for eight waves, the 16x16x32 MFMA shape, read-ahead depth 1/3, ring geometries 20x4 / 12x6, burst refill)
 
 // Variant "x2sp": x2 with the ring refill spread over the block being consumed (one DMA per wave every 4
 // k-steps, issued by every wave -- no wave-dependent branch) instead of a burst of 4 at each rendezvous.
@@ -355,15 +347,9 @@ template <class G, int F> __device__ __forceinline__ const unsigned char* frag_p
   return smem + ((B % G::RING) * G::BLK + (F % G::BLK)) * kFragBytes + lane * 16;
 }
 
-// Hook for pinning operand words to a register class.  Pinning them to AGPRs through
-// an inline-asm v_accvgpr_write was tried and REJECTED: hipcc cannot see the
-// VALU-write -> MFMA-operand-read wait states inside the asm (wrong results on the
-// single-tile layers of the S3 stack) and the VALU instructions it saved bought < 3 %.
-__device__ __forceinline__ unsigned to_areg(unsigned v) { return v; }
-
 // ---- the kernel -------------------------------------------------------------------
 // grid.x = ceil(n_rows / (WAVES*CT*32)); block = 64*WAVES threads; dynamic LDS fused_lds<P>().
-template <class Arch, class P, bool PIN>
+template <class Arch, class P>
 __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedArgs a) {
   constexpr int kWaves = P::WAVES;
   constexpr int kBlkFrags = P::BLK, kRing = P::RING, kFusedLds = fused_lds<P>();
@@ -371,7 +357,6 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = Geo<Arch, P>;
   using frag = typename P::frag;
-  using elem = typename P::elem;
   using Item = typename G::Item;
   constexpr int L = G::L, CT = P::CT, EPI = P::EPI, FPI = P::FPI, IPT = G::IPT;
   constexpr int KSM = G::ks_max();
@@ -394,33 +379,6 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
   const int r = lane & 31, h = lane >> 5;
   const long long wg_row0 = (long long)blockIdx.x * (kWaves * CT * 32);
   const long long row0 = wg_row0 + wave * (CT * 32);
-
-  // ---- de-phasing (two workgroups per CU): every workgroup reaches the store-heavy output
-  // layer at the same point of its own timeline, so if all start together the whole chip
-  // writes its 118 MB in one burst while the matrix pipes idle.  The second workgroup to
-  // arrive on a CU (per-CU arrival counter keyed by XCC/SE/SH/CU id; parity, so no reset is
-  // needed between launches) sleeps first: its hidden layers then overlap the first one's
-  // stores.  Placement only changes speed, never results.
-  unsigned group = 0;  // 0/1: first / second workgroup to arrive on this CU (x2 variants)
-  if constexpr (P::WPS == 2) {
-    if (a.phase_ctr != nullptr) {
-      if (threadIdx.x == 0) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
-        const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu);
-        *(volatile unsigned*)smem = atomicAdd(a.phase_ctr + key, 1u) & 1u;
-      }
-      __syncthreads();
-      const unsigned late = *(volatile unsigned*)smem;
-      __syncthreads();
-      group = __builtin_amdgcn_readfirstlane(late);
-      // Rejected: alternating s_setprio per ring block between the two workgroups (needs a
-      // branch inside the unrolled stream; that alone cost 20 %).  Static form only:
-      if (group && a.prio_mode) __builtin_amdgcn_s_setprio(1);
-      if (late)
-        for (int i = 0; i < a.delay_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
 
   // Operand registers of the two layers in flight, as 32-bit words (4 per item).
   unsigned bufA[CT][KSM][4], bufB[CT][KSM][4];
@@ -462,8 +420,8 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
         });
 #pragma unroll
         for (int wd = 0; wd < 4; ++wd) {
-          if constexpr (EPI == 8) bufA[ct][ks][wd] = to_areg(P::pack2(v[2 * wd], v[2 * wd + 1]));
-          else bufA[ct][ks][wd] = to_areg(__builtin_bit_cast(unsigned, v[wd]));
+          if constexpr (EPI == 8) bufA[ct][ks][wd] = P::pack2(v[2 * wd], v[2 * wd + 1]);
+          else bufA[ct][ks][wd] = __builtin_bit_cast(unsigned, v[wd]);
         }
       });
     });
@@ -513,12 +471,12 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
             const i16x2 z = {0, 0};
             w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), z));
           }
-          out[ct][item][e0 / 2] = to_areg(w);
+          out[ct][item][e0 / 2] = w;
         } else {
           int b0 = __builtin_bit_cast(int, x0), b1 = __builtin_bit_cast(int, x1);
           if constexpr (G::act(l) != 0) { b0 = max(b0, 0); b1 = max(b1, 0); }
-          out[ct][item][e0] = to_areg((unsigned)b0);
-          out[ct][item][e0 + 1] = to_areg((unsigned)b1);
+          out[ct][item][e0] = (unsigned)b0;
+          out[ct][item][e0 + 1] = (unsigned)b1;
         }
       }
     } else {
@@ -627,7 +585,6 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
           epilogue_range(std::integral_constant<int, GP>{}, std::integral_constant<int, lo>{},
                          std::integral_constant<int, hi>{});
         }
-        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
       }
     }
   });

@@ -12,11 +12,10 @@
 
 namespace v21 {
 
-template <bool PIN>
-static hipError_t launch_one(const FusedArgs& a, hipStream_t st) {
+hipError_t V21_EXPAND_SYM(V21_ARCH, V21_PREC)(const FusedArgs& a, hipStream_t st) {
   using A = V21_ARCH_T(V21_ARCH);
   using P = V21_PREC_T(V21_PREC);
-  auto kern = fused_fwd<A, P, PIN>;
+  auto kern = fused_fwd<A, P>;
   static bool attr_done_dev[64] = {};  // the attribute belongs to (function, device): one process may drive several
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -31,14 +30,6 @@ static hipError_t launch_one(const FusedArgs& a, hipStream_t st) {
   if (nwg <= 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * P::WAVES), fused_lds_alloc<P>(), st, a);
   return hipGetLastError();
-}
-
-hipError_t V21_EXPAND_SYM(V21_ARCH, V21_PREC)(const FusedArgs& a, int pin, hipStream_t st) {
-#ifdef V21_WITH_PIN
-  if (pin) return launch_one<true>(a, st);
-#endif
-  (void)pin;
-  return launch_one<false>(a, st);
 }
 
 }  // namespace v21

@@ -376,7 +376,6 @@ struct PackArgs {
   unsigned char* stream;
   int L, total, padded, fpi, epi, esize;  // esize: 2 (f16/bf16) or 4 (f32)
   int is_bf16;
-  int shape16;  // 1: fragments for v_mfma_*_16x16x32 (tiles of 16 outputs, k-steps of 32 features)
   PackLayer lt[16];
 };
 __global__ void pack_stream_kernel(const PackArgs a) {
@@ -393,29 +392,6 @@ __global__ void pack_stream_kernel(const PackArgs a) {
   const PackLayer L = a.lt[l];
   const int rel = F - L.first, tl = L.ks + 1;
   const int nt = rel / tl, ks = rel % tl - 1;
-  if (a.shape16) {
-    if (ks < 0) {  // aux: floats 0..15 = bias[16nt + i], 16..31 = mean[16nt + i] (output layer)
-      float out[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < 4; ++q) {
-        const int idx = lane * 4 + q;
-        float v = 0.f;
-        if (idx < 16) { const int n = 16 * nt + idx; if (n < L.N) v = a.w[L.b_off + n]; }
-        else if (idx < 32 && l == a.L - 1) { const int n = 16 * nt + idx - 16; if (n < L.N && a.mean) v = a.mean[n]; }
-        out[q] = v;
-      }
-      ((float4*)dst)[lane] = make_float4(out[0], out[1], out[2], out[3]);
-      return;
-    }
-    const int i = lane & 15, g = lane >> 4, n = 16 * nt + i;
-    for (int e = 0; e < 8; ++e) {
-      const int f = 32 * ks + 16 * (e >> 2) + 4 * g + (e & 3);
-      float v = 0.f;
-      if (f < L.K && n < L.N) v = a.w[L.w_off + (long long)f * L.N + n];
-      if (a.is_bf16) ((__bf16*)dst)[lane * 8 + e] = (__bf16)v;
-      else ((_Float16*)dst)[lane * 8 + e] = (_Float16)v;
-    }
-    return;
-  }
   const int r = lane & 31, h = lane >> 5;
   if (ks < 0) {  // aux fragment: 256 floats, 4 per lane
     float out[4] = {0.f, 0.f, 0.f, 0.f};

@@ -20,7 +20,6 @@
 #include "../../include/v21.h"
 #include "archs.h"
 #include "fused_fwd.h"
-#include "fused_fwd16.h"
 #include "gemm.h"
 #include "gemm_nt.h"
 #include "train_kernels.h"
@@ -192,51 +191,25 @@ extern "C" int v21_event_elapsed_ms(v21_ctx* c, void* a, void* b, float* ms) {
 // fused-kernel registry
 // ---------------------------------------------------------------------------------
 namespace v21 {
-#define V21_DECL(a)                                                          \
-  hipError_t launch_fused_##a##_F32(const FusedArgs&, int, hipStream_t);     \
-  hipError_t launch_fused_##a##_F16(const FusedArgs&, int, hipStream_t);     \
-  hipError_t launch_fused_##a##_BF16(const FusedArgs&, int, hipStream_t);
+#define V21_DECL(a)                                                      \
+  hipError_t launch_fused_##a##_F32(const FusedArgs&, hipStream_t);      \
+  hipError_t launch_fused_##a##_F16x2sp(const FusedArgs&, hipStream_t);  \
+  hipError_t launch_fused_##a##_BF16x2sp(const FusedArgs&, hipStream_t);
 V21_ARCH_LIST(V21_DECL)
 #undef V21_DECL
-#define V21_DECL2(a)                                                       \
-  hipError_t launch_fused_##a##_F16x2(const FusedArgs&, int, hipStream_t); \
-  hipError_t launch_fused_##a##_BF16x2(const FusedArgs&, int, hipStream_t);
-V21_ARCH_LIST(V21_DECL2)
-#undef V21_DECL2
-#define V21_DECL3(a)                                                        \
-  hipError_t launch_fused_##a##_F16s16(const FusedArgs&, int, hipStream_t); \
-  hipError_t launch_fused_##a##_BF16s16(const FusedArgs&, int, hipStream_t);
-V21_ARCH_LIST(V21_DECL3)
-#undef V21_DECL3
-#define V21_DECL4(a)                                                       \
-  hipError_t launch_fused_##a##_F16w8(const FusedArgs&, int, hipStream_t); \
-  hipError_t launch_fused_##a##_BF16w8(const FusedArgs&, int, hipStream_t);
-V21_ARCH_LIST(V21_DECL4)
-#undef V21_DECL4
-#define V21_DECL5(a)                                                         \
-  hipError_t launch_fused_##a##_F16x2sp(const FusedArgs&, int, hipStream_t); \
-  hipError_t launch_fused_##a##_BF16x2sp(const FusedArgs&, int, hipStream_t);
-V21_ARCH_LIST(V21_DECL5)
-#undef V21_DECL5
 }  // namespace v21
 
-typedef hipError_t (*fused_launcher)(const FusedArgs&, int, hipStream_t);
+typedef hipError_t (*fused_launcher)(const FusedArgs&, hipStream_t);
 struct FusedEntry {
   int L;
   const int* dims;
   const int* act;
-  fused_launcher fn[3];    // one wave per SIMD, two column tiles per wave (f32: one)
-  fused_launcher fn_x2[3]; // two workgroups per CU, one column tile per wave (f16/bf16)
-  fused_launcher fn_s16[3]; // same occupancy, 16x16x32 MFMA shape (fused_fwd16.h)
-  fused_launcher fn_w8[3];  // one 8-wave workgroup per CU: the two waves of a SIMD share the weight ring
-  fused_launcher fn_sp[3];  // x2 with the ring refill spread over the block being consumed
+  // per precision: f32 = one wave per SIMD on the exact f32 MFMA; f16 / bf16 = two workgroups per CU,
+  // one column tile per wave, ring refill spread over the block being consumed (fused_fwd.h: "x2sp")
+  fused_launcher fn[3];
 };
-#define V21_ENTRY(a)                                                                                          \
-  {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_##a##_F32, launch_fused_##a##_F16, launch_fused_##a##_BF16}, \
-   {nullptr, launch_fused_##a##_F16x2, launch_fused_##a##_BF16x2},                                         \
-   {nullptr, launch_fused_##a##_F16s16, launch_fused_##a##_BF16s16},                                       \
-   {nullptr, launch_fused_##a##_F16w8, launch_fused_##a##_BF16w8},                                         \
-   {nullptr, launch_fused_##a##_F16x2sp, launch_fused_##a##_BF16x2sp}},
+#define V21_ENTRY(a) \
+  {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_##a##_F32, launch_fused_##a##_F16x2sp, launch_fused_##a##_BF16x2sp}},
 static const FusedEntry g_fused[] = {V21_ARCH_LIST(V21_ENTRY)};
 #undef V21_ENTRY
 
@@ -253,8 +226,6 @@ struct v21_mlp {
   int fused_id = -1;
   unsigned char* d_stream[3] = {nullptr, nullptr, nullptr};
   bool stream_ok[3] = {false, false, false};
-  unsigned char* d_stream16[3] = {nullptr, nullptr, nullptr};  // 16x16x32-shape fragments
-  bool stream16_ok[3] = {false, false, false};
   bool has_tin = false, has_tout = false;
   v21_affine_in tin{};
   float out_std = 1.f;
@@ -266,7 +237,6 @@ struct v21_mlp {
   float *d_xs = nullptr, *d_ys = nullptr;
   long long stage_rows = 0;
   int maxdim = 0;
-  unsigned* d_phase = nullptr;  // per-CU arrival counters of the x2 fused variants
   bool wpad_ok = false;  // false after the arena was rewritten from outside a trainer (set_weights)
   // small-batch latency path: fp32 W^T copies + two padded activation images
   float* d_wt = nullptr;
@@ -330,9 +300,8 @@ extern "C" int v21_mlp_destroy(v21_mlp* m) {
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
   hipFree(m->d_w);
-  for (int i = 0; i < 3; ++i) { if (m->d_stream[i]) hipFree(m->d_stream[i]); if (m->d_stream16[i]) hipFree(m->d_stream16[i]); }
+  for (int i = 0; i < 3; ++i) if (m->d_stream[i]) hipFree(m->d_stream[i]);
   if (m->d_mean) hipFree(m->d_mean);
-  if (m->d_phase) hipFree(m->d_phase);
   for (int i = 0; i < 2; ++i) if (m->d_act[i]) hipFree(m->d_act[i]);
   for (int i = 0; i < 2; ++i) if (m->d_small[i]) hipFree(m->d_small[i]);
   if (m->d_wt) hipFree(m->d_wt);
@@ -348,7 +317,7 @@ extern "C" int v21_mlp_num_params(const v21_mlp* m, size_t* n) {
   return V21_OK;
 }
 static void invalidate_streams(v21_mlp* m) {
-  for (int i = 0; i < 3; ++i) m->stream_ok[i] = m->stream16_ok[i] = false;
+  for (int i = 0; i < 3; ++i) m->stream_ok[i] = false;
   m->wpad_ok = false;
   m->wt_ok = false;
 }
@@ -398,17 +367,11 @@ extern "C" int v21_mlp_has_fused(const v21_mlp* m, int precision, int* yes) {
   return V21_OK;
 }
 
-static int ensure_stream(v21_mlp* m, int prec, bool shape16 = false) {
-  if (shape16 ? m->stream16_ok[prec] : m->stream_ok[prec]) return V21_OK;
+static int ensure_stream(v21_mlp* m, int prec) {
+  if (m->stream_ok[prec]) return V21_OK;
   int total, padded;
-  if (shape16) {
-    total = 0;
-    for (int l = 0; l < m->L; ++l) total += ((m->dims[l + 1] + 15) / 16) * ((m->dims[l] + 31) / 32 + 1);
-    padded = (total + 3) / 4 * 4;
-  } else {
-    stream_geometry(m, prec, &total, &padded);
-  }
-  unsigned char*& dst = shape16 ? m->d_stream16[prec] : m->d_stream[prec];
+  stream_geometry(m, prec, &total, &padded);
+  unsigned char*& dst = m->d_stream[prec];
   if (!dst) HIPCHK(hipMalloc((void**)&dst, (size_t)padded * 1024));
   PackArgs pa{};
   pa.w = m->d_w;
@@ -417,8 +380,7 @@ static int ensure_stream(v21_mlp* m, int prec, bool shape16 = false) {
   pa.L = m->L;
   pa.total = total;
   pa.padded = padded;
-  pa.shape16 = shape16 ? 1 : 0;
-  pa.fpi = shape16 ? 32 : fpi_of(prec);
+  pa.fpi = fpi_of(prec);
   pa.epi = prec == V21_PREC_F32 ? 4 : 8;
   pa.esize = prec == V21_PREC_F32 ? 4 : 2;
   pa.is_bf16 = prec == V21_PREC_BF16;
@@ -426,14 +388,14 @@ static int ensure_stream(v21_mlp* m, int prec, bool shape16 = false) {
   for (int l = 0; l < m->L; ++l) {
     PackLayer& pl = pa.lt[l];
     pl.K = m->dims[l]; pl.N = m->dims[l + 1];
-    pl.ks = (pl.K + pa.fpi - 1) / pa.fpi; pl.nt = shape16 ? (pl.N + 15) / 16 : (pl.N + 31) / 32;
+    pl.ks = (pl.K + pa.fpi - 1) / pa.fpi; pl.nt = (pl.N + 31) / 32;
     pl.w_off = m->w_off[l]; pl.b_off = m->b_off[l];
     pl.first = f;
     f += pl.nt * (pl.ks + 1);
   }
   hipLaunchKernelGGL(pack_stream_kernel, dim3((padded + 3) / 4), dim3(256), 0, m->ctx->stream, pa);
   HIPCHK(hipGetLastError());
-  (shape16 ? m->stream16_ok[prec] : m->stream_ok[prec]) = true;
+  m->stream_ok[prec] = true;
   return V21_OK;
 }
 
@@ -542,55 +504,19 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
   if (takes_small_path(m, n, precision, flags) && ldy < (1ll << 21))
     return forward_small(m, d_x, ldx, n, d_y, ldy, precision, flags);
   if (!fused) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
-  const int s16 = getenv("V21_FUSED_S16") ? atoi(getenv("V21_FUSED_S16")) : 0;
-  const bool use16 = s16 && g_fused[m->fused_id].fn_s16[precision] != nullptr;
-  CHK(ensure_stream(m, precision, use16));
+  CHK(ensure_stream(m, precision));
   FusedArgs a{};
   a.x = d_x; a.ldx = ldx; a.y = d_y; a.ldy = ldy; a.n_rows = n;
-  a.stream = use16 ? m->d_stream16[precision] : m->d_stream[precision];
+  a.stream = m->d_stream[precision];
   const bool tout = (flags & V21_FWD_OUT_TRANSFORM) != 0;
   a.out_std = tout ? m->out_std : 1.0f;
   a.out_mean_scale = tout ? 1.0f : 0.0f;
   a.in_transform = (flags & V21_FWD_IN_TRANSFORM) ? 1 : 0;
   if (a.in_transform) a.tin = m->tin;
+#ifdef V21_FUSED_STAMP  // diagnostic build only: where the cycle stamps go
   a.dbg = (unsigned long long*)(getenv("V21_FUSED_DBG_PTR") ? strtoull(getenv("V21_FUSED_DBG_PTR"), nullptr, 0) : 0ull);
-  if (use16) {
-    a.in_transform = (flags & V21_FWD_IN_TRANSFORM) ? 1 : 0;
-  }
-  const int pin = getenv("V21_FUSED_PIN") ? atoi(getenv("V21_FUSED_PIN")) : 0;  // tuning knobs: read per call (A/B in one process)
-  if (use16) {
-    HIPCHK(g_fused[m->fused_id].fn_s16[precision](a, 0, m->ctx->stream));
-    return V21_OK;
-  }
-  const int x2 = getenv("V21_FUSED_X2") ? atoi(getenv("V21_FUSED_X2")) : 1;
-  {
-    const char* w8 = getenv("V21_FUSED_W8");
-    if (w8 && w8[0] == '1' && g_fused[m->fused_id].fn_w8[precision]) {
-      HIPCHK(g_fused[m->fused_id].fn_w8[precision](a, 0, m->ctx->stream));
-      return V21_OK;
-    }
-  }
-  {
-    const char* sp = getenv("V21_FUSED_SP");  // default for f16/bf16 since r1 (2-3 % over plain x2); 0 = plain x2
-    if (!(sp && sp[0] == '0') && x2 && g_fused[m->fused_id].fn_sp[precision]) {
-      HIPCHK(g_fused[m->fused_id].fn_sp[precision](a, 0, m->ctx->stream));
-      return V21_OK;
-    }
-  }
-  if (x2 && g_fused[m->fused_id].fn_x2[precision]) {  // default for f16/bf16: two 128-signal workgroups per CU
-    const int delay = getenv("V21_FUSED_DELAY") ? atoi(getenv("V21_FUSED_DELAY")) : 0;
-    const int prio = getenv("V21_FUSED_PRIO") ? atoi(getenv("V21_FUSED_PRIO")) : 0;
-    a.prio_mode = prio;
-    if ((delay > 0 || prio) && !m->d_phase) {
-      HIPCHK(hipMalloc((void**)&m->d_phase, 2048 * sizeof(unsigned)));
-      HIPCHK(hipMemsetAsync(m->d_phase, 0, 2048 * sizeof(unsigned), m->ctx->stream));
-    }
-    a.phase_ctr = m->d_phase;
-    a.delay_sleeps = delay;
-    HIPCHK(g_fused[m->fused_id].fn_x2[precision](a, pin, m->ctx->stream));
-    return V21_OK;
-  }
-  HIPCHK(g_fused[m->fused_id].fn[precision](a, pin, m->ctx->stream));
+#endif
+  HIPCHK(g_fused[m->fused_id].fn[precision](a, m->ctx->stream));
   return V21_OK;
 }
 

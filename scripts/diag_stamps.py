@@ -15,7 +15,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 x = rng.uniform(-1, 1, size=(B, 7)).astype(np.float32)
 d_x, d_y = ctx.malloc(x.nbytes), ctx.malloc(B * 451 * 4)
 ctx.h2d(d_x, x)
-rows_per_wg = 128 if (prec == "f32" or os.environ.get("V21_FUSED_X2") == "1") else 256
+rows_per_wg = 128  # f32: 4 waves x 1 column tile; f16/bf16 (x2sp): the same, two workgroups per CU
 nwg = B // rows_per_wg
 dbg = np.zeros((nwg * 4, 512), np.uint64)
 d_dbg = ctx.malloc(dbg.nbytes)
@@ -28,7 +28,7 @@ st.forward_dev(d_x, 7, B, d_y, 451, prec, 0)
 ctx.sync()
 ctx.d2h(dbg, d_dbg)
 t = dbg.astype(np.int64)
-nb = int(sys.argv[3]) if len(sys.argv) > 3 else (58 if os.environ.get("V21_FUSED_X2") == "1" else 39)
+nb = int(sys.argv[3]) if len(sys.argv) > 3 else (39 if prec == "f32" else 58)  # ring blocks: 24 / 16 fragments each
 start, end = t[:, 0], t[:, 127]
 print("precision", prec, "blocks", nb, "waves", t.shape[0])
 half = t.shape[0] // 2
