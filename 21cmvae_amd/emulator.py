@@ -36,6 +36,22 @@ def _gen_model(in_dim, hidden_dims, out_dim, activation_func, name=None, variati
 
 NU_0 = 1420405751.7667  # Hz, rest frequency of the 21-cm line
 
+# Three places where this module deliberately does NOT reproduce an accident of the reference
+# (INTEGRATION.md section 6).  ``set_strict_reference(True)`` switches all three back to the
+# reference's observable behaviour, for callers that depend on it:
+#   * ``error(..., flow=x)`` or ``error(..., fhigh=x)`` with ONE bound returns shape (N, 1), because the
+#     reference indexes with an (k, 1) argwhere result (emulator.py:179-184); both bounds give (N,)
+#   * ``freq2redshift`` multiplies an ndarray argument by 1e6 IN PLACE (emulator.py:124), so a
+#     ``frequencies=`` array passed to a constructor is left in Hz (emulator.py:314-317)
+#   * the latent emulator's model name keeps the reference's spelling "ae_emualtor" (emulator.py:662)
+strict_reference = False
+
+
+def set_strict_reference(on=True):
+    """Reproduce the reference's three accidental behaviours listed above (default: off)."""
+    global strict_reference
+    strict_reference = bool(on)
+
 
 def redshift2freq(z):
     """Redshift -> frequency in MHz."""
@@ -45,8 +61,12 @@ def redshift2freq(z):
 
 
 def freq2redshift(nu):
-    """Frequency in MHz -> redshift.  (Unlike the reference, emulator.py:124, the
-    argument is not modified in place.)"""
+    """Frequency in MHz -> redshift.  The argument is left untouched unless
+    ``strict_reference`` is set (the reference converts an ndarray to Hz in place,
+    emulator.py:124)."""
+    if strict_reference:
+        nu *= 1e6  # to Hz -- in place for ndarrays, exactly as the reference does
+        return NU_0 / nu - 1
     return NU_0 / (np.asarray(nu, dtype=float) * 1e6) - 1 if np.ndim(nu) else NU_0 / (nu * 1e6) - 1
 
 
@@ -66,6 +86,8 @@ def error(true_signal, pred_signal, relative=True, nu_arr=None, flow=None, fhigh
         if fhigh:
             sel &= nu_arr <= fhigh
         f = np.flatnonzero(sel)
+        if strict_reference and not (flow and fhigh):
+            f = f[:, None]  # the reference's (k, 1) index -> (N, k, 1) selection -> (N, 1) result
         pred_signal, true_signal = pred_signal[:, f], true_signal[:, f]
     err = np.sqrt(np.mean((pred_signal - true_signal) ** 2, axis=1))
     if relative:
@@ -121,10 +143,14 @@ def _grid(redshifts_, frequencies):
 class _EmulatorBase:
     par_labels = ["fstar", "Vc", "fx", "tau", "alpha", "nu_min", "Rmfp"]
 
-    def _set_data(self, par_train, par_val, par_test, signal_train, signal_val, signal_test):
+    def _set_data(self, par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data=False):
         d = _resolve_data(dict(par_train=par_train, par_val=par_val, par_test=par_test,
                                signal_train=signal_train, signal_val=signal_val, signal_test=signal_test))
         for k, v in d.items():
+            # freeze_data: private read-only copies of the two arrays whose statistics every call needs, so the
+            # statistics cache is exact without hashing ~44 MB per predict() (preprocess.freeze)
+            if freeze_data and k in ("par_train", "signal_train"):
+                v = pp.freeze(v)
             setattr(self, k, v)
         self.par_labels = list(_EmulatorBase.par_labels)
 
@@ -136,10 +162,9 @@ class _EmulatorBase:
         x = pp.par_transform(params, self.par_train)
         st = model._ensure_stack()
         ss = pp.SignalStats.of(self.signal_train)
-        key = (id(self.signal_train), float(ss.std))
-        if getattr(st, "_out_key", None) != key:
+        if getattr(st, "_out_stats", None) is not ss:  # a new record whenever the training set changed (even in place)
             st.set_output_transform(ss.std, ss.mean)
-            st._out_key = key
+            st._out_stats = ss
         from . import _native as nat
         pred = st.forward(x, model.precision, flags=nat.FWD_OUT_TRANSFORM)
         return pred[0, :] if pred.shape[0] == 1 else pred
@@ -153,8 +178,8 @@ class DirectEmulator(_EmulatorBase):
 
     def __init__(self, par_train=None, par_val=None, par_test=None, signal_train=None, signal_val=None,
                  signal_test=None, hidden_dims=hidden_dims, activation_func="relu", redshifts=redshifts,
-                 frequencies=None, precision="f32"):
-        self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test)
+                 frequencies=None, precision="f32", freeze_data=False):
+        self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data)
         self.emulator = _gen_model(self.par_train.shape[-1], hidden_dims, self.signal_train.shape[-1],
                                    activation_func, name="emulator")
         self.emulator.precision = precision
@@ -232,8 +257,9 @@ class AutoEncoderEmulator(_EmulatorBase):
     def __init__(self, par_train=None, par_val=None, par_test=None, signal_train=None, signal_val=None,
                  signal_test=None, latent_dim=latent_dim, enc_hidden_dims=enc_hidden_dims,
                  dec_hidden_dims=dec_hidden_dims, em_hidden_dims=em_hidden_dims, activation_func="relu",
-                 redshifts=redshifts, frequencies=None, precision="f32", variational=False, kl_weight=0.0):
-        self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test)
+                 redshifts=redshifts, frequencies=None, precision="f32", variational=False, kl_weight=0.0,
+                 freeze_data=False):
+        self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data)
         self.redshifts, self.frequencies = _grid(redshifts, frequencies)
         autoencoder = AutoEncoder(self.signal_train, enc_hidden_dims, dec_hidden_dims, latent_dim, activation_func,
                                   variational=variational, kl_weight=kl_weight)
@@ -241,7 +267,7 @@ class AutoEncoderEmulator(_EmulatorBase):
         autoencoder.precision = precision
         self.autoencoder = autoencoder
         self.emulator = _gen_model(self.par_train.shape[-1], em_hidden_dims, latent_dim, activation_func,
-                                   name="ae_emulator")
+                                   name="ae_emualtor" if strict_reference else "ae_emulator")
         self.emulator.precision = precision
         self.precision = precision
         self._chain_model = None

@@ -258,10 +258,16 @@ class Model:
         stack = self._ensure_stack()
         sig = (id(stack), self.precision, id(self.optimizer))
         if self._trainer is None or self._trainer_sig != sig or self._trainer.max_batch < batch:
+            old = self._trainer if self._trainer_sig == sig else None
+            # a trainer that is only being replaced by a roomier one (evaluate / fit with a larger batch)
+            # hands its optimizer state over: Keras keeps iterations, m and v across fit()/evaluate() calls [K]
+            carried = old.get_state() if old is not None else None
             self._trainer = _native.Trainer(stack, self.precision, max(batch, 1))
             self._trainer_sig = sig
             mv = getattr(self, "_restore_state", None)  # Adam moments of a loaded file (h5lite.load_model)
-            if mv is not None and mv[0] is not None and mv[0].size == stack.num_params:
+            if carried is not None:
+                self._trainer.set_state(*carried)
+            elif mv is not None and mv[0] is not None and mv[0].size == stack.num_params:
                 self._trainer.set_state(self.optimizer.iterations, mv[0], mv[1])
             else:
                 self._trainer.set_state(self.optimizer.iterations)
@@ -323,10 +329,15 @@ class Model:
         return history
 
     def evaluate(self, x, y, batch_size=None, verbose=0, **_):
-        tr = self._ensure_trainer(int(batch_size or 32))
+        """Mean per-sample loss over (x, y).  The batch size does not change the result (rows are
+        independent, the mean is sample-weighted), so an existing trainer is used at its own capacity."""
+        b = int(batch_size or 32)
+        if self._trainer is not None:
+            b = min(b, self._trainer.max_batch)
+        tr = self._ensure_trainer(b)
         x = np.ascontiguousarray(x, dtype=np.float32); y = np.ascontiguousarray(y, dtype=np.float32)
         tr.set_data(1, x, y, self._row_weight(y))
-        return tr.evaluate(1, int(batch_size or 32))
+        return tr.evaluate(1, b)
 
     def save(self, path, include_optimizer=True):
         """``path`` ending in .h5/.hdf5: a Keras legacy-H5 model file (``h5write``: layer names, kernels, biases,

@@ -75,6 +75,8 @@ def fit_models(models, x, y, batch_size=256, epochs=1, validation_data=None, cal
         for i in active:
             cbs[i].on_epoch_begin(epoch)
             trainers[i].set_lr(float(models[i].optimizer.lr))
+            if getattr(models[i], "_vae_seed", None) is not None:  # a callback may anneal kl_weight (as Model.fit)
+                trainers[i].set_vae(models[i].kl_weight, models[i].sample_latent, models[i]._vae_seed)
         perm = engine._rng.permutation(n).astype(np.int32) if shuffle else None
         losses = group.run_epoch(perm, batch_size)
         still = []

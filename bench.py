@@ -457,7 +457,7 @@ def main():
                 out["train"] = {"error": "timeout: the data-parallel training leg did not finish"}
                 if rank == 0:
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)  # a hung leg is a failed run: the JSON line is still printed, the exit status says so
         else:
             run_train()
 
