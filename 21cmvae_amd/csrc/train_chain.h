@@ -6,21 +6,28 @@
 // pass and through the activation-gradient chain, so a workgroup can carry its 32 rows through
 // every layer with the activations in LDS and only workgroup barriers between layers:
 //
-//   gather x[idx] -> LDS (f16) and H0^T (global, for the weight gradient)
+//   gather x[idx] -> LDS (f16; the fp32 rows stay in LDS as the loss targets when y == x)
 //   for each layer:  Z^T(n, m) = sum_k W^T(n, k) H^T(k, m)      "transposed orientation":
 //       MFMA A operand = weights (rows = output features), B operand = activations (columns
 //       = batch rows), so a lane owns ONE batch row and 4 x 4 consecutive features: the
 //       result goes back to LDS as four 8-byte writes in the [row][feature] layout the
 //       next layer reads with one ds_read_b128 per MFMA.
 //       Weights come straight from L2 into registers as 1-KiB fragments, pre-packed by the
-//       Adam kernel (train_kernels.h) in exactly the order a wave reads them; a wave issues
-//       every load of a tile before its first MFMA, two waves per SIMD cover each other.
+//       Adam kernel (train_kernels.h) in exactly the order a wave reads them.  A wave owns the
+//       output tiles t = wave, wave + 16, ... and walks their fragments with a ROLLING prefetch:
+//       while the four fragments of one chunk feed the MFMAs, the next chunk -- of this tile, of
+//       the wave's next tile, or of its first tile in a LATER layer -- is in flight (weights do
+//       not depend on activations, so the loads cross tile ends, layer barriers and the
+//       forward/backward turn).  What bounds the kernel is how fast ONE CU pulls the packed
+//       weight set (1.2 MB for the autoencoder; every workgroup needs all of it): the load path
+//       moves 64 B/clk per CU (~130 GB/s, scripts/diag/stream_probe.hip), i.e. >= 9 us.
 //   last layer: loss_i and dL/dz = 2 w_i (p - y) / B in the epilogue (relative_mse_loss,
 //       emulator.py:68-81, as a row weight); row losses are reduced in a fixed order.
 //   for each layer, top down:  dX^T(k, m) = sum_n W(k, n) dZ^T(n, m), masked by the ReLU
 //       bits the forward epilogue left in LDS.
-//   H_l^T and dZ_l^T go to global memory (fp32, batch-contiguous): the weight gradients
-//   contract over the WHOLE batch and stay in the NT kernel (one grouped launch).
+//   H_l^T and dZ_l^T leave the kernel as f16 MFMA fragments (hardware-transposed LDS reads,
+//   16-byte coalesced stores): the weight gradients contract over the WHOLE batch and are a
+//   separate grouped launch (gemm_dw16*).
 //
 // Gradients are carried through the f16 operands multiplied by a power of two `gs`
 // (see gemm_nt.h: a_scale) and stored to global memory unscaled.
@@ -28,12 +35,13 @@
 #include <hip/hip_runtime.h>
 
 #include "fused_fwd.h"
+#include "train_kernels.h"
 
 namespace v21 {
 
 constexpr int kChainMaxDim = 512;             // widest layer the LDS layout holds
 constexpr int kChainPitch = kChainMaxDim + 8; // halfs; 1040 B = 16 B mod 128 B: conflict-free ds_read_b128
-constexpr int kChainWaves = 8;
+constexpr int kChainWaves = 16;  // 4 per SIMD: an 11- or 15-tile layer is ONE round of tiles, and 16 streams keep the CU's load path busy
 constexpr int kChainMaskTiles = 112;
 constexpr int kChainBufBytes = 2 * 32 * kChainPitch * 2;
 constexpr int kChainMaskBytes = kChainMaskTiles * 64 * 2;
@@ -46,8 +54,8 @@ constexpr int kChainLdsBytes = kChainBufBytes + kChainMaskBytes + kChainSmallByt
 
 struct ChainLayer {
   int K, N;            // Dense input / output width
-  int KS4, NT;         // forward: k-steps of 16 (padded to a multiple of 4), 32-wide output tiles
-  int NS4, KT;         // backward: n-steps of 16 (padded to 4), 32-wide input tiles
+  int KS, NT;          // forward: k-steps of 16 (padded to whole chunks: chain_steps), 32-wide output tiles
+  int NS, KT;          // backward: n-steps of 16 (padded likewise), 32-wide input tiles
   int relu;            // ReLU on this layer's output
   int gauss;           // variational head (V21_ACT_GAUSS): N = 2*latent Dense outputs [z_mean | z_log_var]; the
                        // next layer sees z = z_mean + exp(z_log_var/2) eps (latent wide)
@@ -113,11 +121,24 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_group_kernel(con
   train_chain_body<P>(tab[blockIdx.y], st);
 }
 
+// LDS-only rendezvous: own LDS writes retired, then the barrier.  Deliberately NOT __syncthreads():
+// its fence would also drain the weight loads that are in flight across the barrier (vmcnt(0)).
+__device__ __forceinline__ void chain_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef short chain_s4 __attribute__((ext_vector_type(4)));
+typedef short chain_s8 __attribute__((ext_vector_type(8)));
+// hardware transpose read (ds_read_b64_tr_b16): per 16-lane group a 4-row x 16-column block of 16-bit
+// elements; lane 4q+p supplies the address of row q, columns 4p..4p+3 and lane i receives column i of
+// the four rows.  EXEC must be all ones.
+__device__ __forceinline__ chain_s4 chain_tr_read(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((chain_s4 __attribute__((address_space(3)))*)p);
+}
+
 template <class P>
 __device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st) {
   using frag = typename P::frag;
   using elem = typename P::elem;
-  constexpr int NW = kChainWaves, PITCH = kChainPitch;
+  constexpr int NW = kChainWaves, PITCH = kChainPitch, RPW = 32 / NW;  // RPW: batch rows a wave gathers
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   elem(*buf)[32 * PITCH] = reinterpret_cast<elem(*)[32 * PITCH]>(chain_smem);
   unsigned short(*masks)[64] = reinterpret_cast<unsigned short(*)[64]>(chain_smem + kChainBufBytes);
@@ -132,113 +153,184 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * 32;
+  const int vrows = st.rows - m0;  // valid rows of this block (>= 1; < 32 only in the last block)
   if (tid < 32) klb[tid] = 0.f;
 
+  const frag* fw = reinterpret_cast<const frag*>(a.fw);
+  const frag* bw = reinterpret_cast<const frag*>(a.bw);
+
+  // ---- the wave's weight stream (see the header): a prefetch fetches a chunk of four fragments and, for a
+  // forward tile, its bias (lane i: bias[32 t + i], 0 past the layer's width; the tile start hands the 32
+  // values out by readlane).  Vector loads on purpose: the compiler cannot prove the arena read-only (no
+  // scalar loads), and sixteen dependent loads per lane at the start of a tile would stall the stream.
+  struct Job { const frag* w; const float* b; bool bok; };
+  auto fwd_job = [&](int l, int t) __attribute__((always_inline)) -> Job {
+    const ChainLayer& ly = a.lt[l];
+    const int n = 32 * t + li;
+    return Job{fw + ly.fw_off + ((long long)t * ly.KS) * 64 + lane, a.w + ly.b_off + (n < ly.N ? n : ly.N - 1), n < ly.N};
+  };
+  auto bwd_job = [&](int l, int t) __attribute__((always_inline)) -> Job {
+    const ChainLayer& ly = a.lt[l];
+    return Job{bw + ly.bw_off + ((long long)t * ly.NS) * 64 + lane, a.w, false};
+  };
+  auto bwd_from = [&](int l) __attribute__((always_inline)) -> Job {  // first tile of this wave in the activation-gradient layers <= l
+    for (; l >= 1; --l)
+      if (wave < a.lt[l].KT) return bwd_job(l, wave);
+    return Job{fw + lane, a.w, false};  // nothing left: any valid address (the data is never used)
+  };
+  auto fwd_from = [&](int l) __attribute__((always_inline)) -> Job {  // first tile of this wave in forward layers >= l, else backward
+    for (; l < a.L; ++l)
+      if (wave < a.lt[l].NT) return fwd_job(l, wave);
+    return bwd_from(a.L - 1);
+  };
+  frag wa[4], wb[4];  // chunk in use / chunk in flight (the roles alternate)
+  float bnext;        // bias values of the wave's next forward tile (in flight with its first chunk)
+  {
+    const Job j0 = fwd_from(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wa[j] = j0.w[j * 64];
+    bnext = j0.bok ? *j0.b : 0.f;
+  }
+
   chain_stamp(a, 0);
-  // ---- gather: x[idx] -> buf[0] (compute type) and H0^T (fp32)
-  {  // wave w moves rows 4w..4w+3, lanes run along the row (256-byte segments); targets stay in LDS as fp32.
-     // Two dependent round trips: the wave's four row indices, then rows + row weights together.
-    const int K0 = a.lt[0].K, K0p = a.lt[0].KS4 * 16, DO = a.lt[a.L - 1].N;
-    long long sr[4];
+  // ---- gather: x[idx] -> buf[0] (compute type) and the fp32 target rows
+  {  // wave w moves rows RPW w .. RPW w + RPW - 1, lanes run along the row (256-byte segments); targets stay in LDS as fp32.
+     // Two dependent round trips: the wave's row indices (one vector load, broadcast by readlane), then
+     // rows + row weights together.  Branch-free: loads past the end of a row / of the batch are clamped to
+     // a valid address and replaced by 0, and every lane writes its whole strip of the LDS images (columns
+     // >= K are the zero padding the first contraction reads).
+    const int K0 = a.lt[0].K, DO = a.lt[a.L - 1].N;
+    const int mq = m0 + RPW * wave + (lane & (RPW - 1));
+    long long srow = mq < st.rows ? st.first + mq : st.first + m0;  // clamped: always a valid position
+    if (st.idx) srow = st.idx[srow];
+    const float rwv = st.rw[srow];
+    long long sr[RPW];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 4 * wave + r;  // wave-uniform: scalar loads
-      sr[r] = m < st.rows ? (st.idx ? (long long)st.idx[st.first + m] : st.first + m) : 0;
+    for (int r = 0; r < RPW; ++r) {
+      sr[r] = ((long long)__builtin_amdgcn_readlane((int)(srow >> 32), r) << 32) |
+              (unsigned)__builtin_amdgcn_readlane((int)srow, r);
     }
-    if (lane < 4) {
-      const int m = 4 * wave + lane;
-      const long long s = lane == 0 ? sr[0] : lane == 1 ? sr[1] : lane == 2 ? sr[2] : sr[3];
-      rwl[m] = m0 + m < st.rows ? st.rw[s] : 0.f;
-    }
-    float v[4][8];
+    if (lane < RPW) rwl[RPW * wave + lane] = mq < st.rows ? rwv : 0.f;
+    float v[RPW][8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = m0 + 4 * wave + r < st.rows;
+    for (int r = 0; r < RPW; ++r) {
+      // (a select on a wave-uniform condition would make hipcc branch around every load and drain
+      // vmcnt(0) after each: the row's validity is folded into the per-lane column bound instead)
+      const int kmax = m0 + RPW * wave + r < st.rows ? K0 : 0;
       const float* xs = st.x + sr[r] * st.ldx;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = lane + 64 * i;
-        v[r][i] = (ok && k < K0) ? xs[k] : 0.f;
+        const float t = xs[k < K0 ? k : K0 - 1];
+        v[r][i] = k < kmax ? t : 0.f;
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = 4 * wave + r;
+    for (int r = 0; r < RPW; ++r) {
+      const int m = RPW * wave + r;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int k = lane + 64 * i;
-        if (k < K0p) buf[0][m * PITCH + k] = (elem)v[r][i];
+        const int k = lane + 64 * i;  // <= 511 < PITCH, YP
+        buf[0][m * PITCH + k] = (elem)v[r][i];
         if (!st.y) ystg[m * YP + k] = v[r][i];
       }
     }
     if (st.y) {  // separate targets: a second pass through the same registers
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool ok = m0 + 4 * wave + r < st.rows;
+      for (int r = 0; r < RPW; ++r) {
+        const int kmax = m0 + RPW * wave + r < st.rows ? DO : 0;
         const float* ys = st.y + sr[r] * st.ldy;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int k = lane + 64 * i;
-          v[r][i] = (ok && k < DO) ? ys[k] : 0.f;
+          const float t = ys[k < DO ? k : DO - 1];
+          v[r][i] = k < kmax ? t : 0.f;
         }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < RPW; ++r)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ystg[(4 * wave + r) * YP + lane + 64 * i] = v[r][i];
+        for (int i = 0; i < 8; ++i) ystg[(RPW * wave + r) * YP + lane + 64 * i] = v[r][i];
     }
   }
-  __syncthreads();
+  chain_barrier();
 
   chain_stamp(a, 1);
-  const frag* fw = reinterpret_cast<const frag*>(a.fw);
-  const frag* bw = reinterpret_cast<const frag*>(a.bw);
   float lsum = 0.f;  // this lane's share of the row losses
   int cur = 0;
 
-  // the 32 rows x F features in `act` -> fragment-ordered transposed copy (16 bytes per store: 8 batch
-  // rows of one feature); rows past the end of the batch are written as zeros
-  // `tiles`: tile count of the contraction that follows -- the waves that get one tile fewer do the flush
-  auto flush_t = [&](const elem* act, int F, void* dst, int tiles) {
-    const int F32 = (F + 31) & ~31;
+  // The 32 rows x F features in `act` ([row][feature], 16-bit) -> the weight-gradient operand in MFMA
+  // fragment order (one 1-KiB fragment = 32 features x 16 batch rows, 8 consecutive rows of a feature
+  // per lane): two transposed LDS reads and ONE fully coalesced 16-byte-per-lane store per fragment.
+  // Rows past the end of the batch are written as zeros; features >= F are left alone (feature K of
+  // an input operand is the constant row of ones).
+  auto flush_t = [&](const elem* act, int F, void* dst) __attribute__((always_inline)) {
+    const int nfrag = 2 * ((F + 31) >> 5);
     frag* d = reinterpret_cast<frag*>(dst);
-    const int w0 = tiles % NW;  // waves [0, w0) carry the extra tile (w0 == 0: all alike)
-    if (wave < w0) return;
-    for (int i = tid - 64 * w0; i < 4 * F32; i += 64 * (NW - w0)) {
-      const int q = i / F32, f = i % F32;
-      if (f >= F) continue;
-      frag v;
+    const int g = lane >> 4, i = lane & 15;
+    for (int id = wave; id < nfrag; id += NW) {
+      const int ft = id >> 1, q2 = id & 1;
+      const int r0 = 16 * q2 + 8 * (g >> 1);
+      const elem* p = act + (r0 + (i >> 2)) * PITCH + 32 * ft + 16 * (g & 1) + 4 * (i & 3);
+      const chain_s4 lo = chain_tr_read(p), hi = chain_tr_read(p + 4 * PITCH);
+      chain_s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (vrows < 32) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (m0 + 8 * q + j < st.rows) ? act[(8 * q + j) * PITCH + f] : (elem)0.f;
-      d[((long long)(f >> 5) * a.BS + (m0 >> 4) + (q >> 1)) * 64 + (q & 1) * 32 + (f & 31)] = v;
+        for (int j = 0; j < 8; ++j)
+          if (r0 + j >= vrows) v[j] = 0;
+      }
+      if (32 * ft + (lane & 31) < F)
+        d[((long long)ft * a.BS + (m0 >> 4) + q2) * 64 + lane] = __builtin_bit_cast(frag, v);
     }
   };
 
-  // one 32-wide tile: acc(rows = features of the tile, col = batch row li) over `nch` chunks of 4 k-steps
-  auto contract = [&](const frag* wsrc, const elem* act, int nch, f32x16& acc) {
-    frag wv[32];
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (c < nch) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wv[4 * c + j] = wsrc[(4 * c + j) * 64];
-      }
+  // One 32-wide tile: acc(rows = features of the tile, col = batch row li) over `nch` chunks of four
+  // k-steps.  On entry chunk 0 of `wsrc` is in `wa` (in flight or landed); on exit chunk 0 of `nxt` --
+  // the wave's next tile -- is in flight in `wa` (returns false) or in `wb` (returns true: nch was odd;
+  // the caller moves it to `wa` AFTER its epilogue, when the loads have had time to land).
+  auto contract = [&](const frag* wsrc, const elem* act, int nch, f32x16& acc, const Job nxt) __attribute__((always_inline)) -> bool {
     const elem* ap = act + li * PITCH + 8 * lh;
-    frag bc[4], bn[4];  // activation fragments of chunk c+1 are read from LDS under the MFMAs of chunk c
+    bnext = nxt.bok ? *nxt.b : 0.f;  // (the caller has consumed this tile's values; issued first: it returns first)
+    frag bc[4], bn[4];  // activation fragments of the next chunk are read from LDS under the MFMAs of this one
 #pragma unroll
     for (int j = 0; j < 4; ++j) bc[j] = *reinterpret_cast<const frag*>(ap + j * 16);
+    int c = 0;
+    for (; c + 2 <= nch; c += 2) {
+      {
+        const frag* p = wsrc + (long long)(4 * (c + 1)) * 64;
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (c < nch) {
-        if (c + 1 < nch) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bn[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 1) + j) * 16);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = P::template mfma<false>(wv[4 * c + j], bc[j], acc);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bc[j] = bn[j];
+        for (int j = 0; j < 4; ++j) wb[j] = p[j * 64];
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bn[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 1) + j) * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = P::template mfma<false>(wa[j], bc[j], acc);
+      {
+        const frag* p = c + 2 < nch ? wsrc + (long long)(4 * (c + 2)) * 64 : nxt.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wa[j] = p[j * 64];
+      }
+      if (c + 2 < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bc[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 2) + j) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = P::template mfma<false>(wb[j], bn[j], acc);
+    }
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wb[j] = nxt.w[j * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = P::template mfma<false>(wa[j], bc[j], acc);
+      return true;
+    }
+    return false;
+  };
+  auto settle = [&](bool odd) __attribute__((always_inline)) {
+    if (odd) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wa[j] = wb[j];
+    }
   };
 
   // ---- forward
@@ -247,19 +339,24 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const bool last = l == a.L - 1;
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
-    const int nch = ly.KS4 >> 2;
-    const float* bias = a.w + ly.b_off;
-    flush_t(act, ly.K, ly.ht16, ly.NT);  // this layer's input -> operand of its weight gradient
+    const int nch = ly.KS >> 2;
+    flush_t(act, ly.K, ly.ht16);  // this layer's input -> operand of its weight gradient
     const float wi = rwl[li];
     for (int t = wave; t < ly.NT; t += NW) {
       const int n0 = 32 * t;
       f32x16 acc;
+      {  // accumulator = bias: register r of lane half lh is feature n0 + (r & 3) + 8 (r >> 2) + 4 lh
+        const int bbits = __builtin_bit_cast(int, bnext);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        acc[r] = n < ly.N ? bias[n] : 0.f;
+        for (int r = 0; r < 16; ++r) {  // (lanes past the layer's width hold 0)
+          const int il = (r & 3) + 8 * (r >> 2), ih = il + 4;
+          const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bbits, il));
+          const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bbits, ih));
+          acc[r] = lh ? b1 : b0;
+        }
       }
-      contract(fw + ly.fw_off + ((long long)t * ly.KS4) * 64 + lane, act, nch, acc);
+      const Job nxt = t + NW < ly.NT ? fwd_job(l, t + NW) : fwd_from(l + 1);
+      const bool odd = contract(fw + ly.fw_off + ((long long)t * ly.KS) * 64 + lane, act, nch, acc, nxt);
       if (ly.gauss) {  // keep (mu | lv) in fp32: the sampling pass below turns them into z
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -268,11 +365,12 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
         }
       } else if (!last) {
         unsigned bits = 0;
+        if (ly.relu) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (ly.relu) acc[r] = fmaxf(acc[r], 0.f);
-          bits |= (acc[r] > 0.f ? 1u : 0u) << r;
+          for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= (acc[r] > 0.f ? 1u : 0u) << r;
         if (ly.mask_tile >= 0) masks[ly.mask_tile + t][lane] = (unsigned short)bits;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -297,10 +395,11 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
           *reinterpret_cast<uint2*>(out + li * PITCH + n) = pk;
         }
       }
+      settle(odd);
     }
     if (ly.gauss) {  // z = mu + exp(lv/2) eps -> the next layer's operand image; KL_i -> the row's loss
-      __syncthreads();
-      const int LAT = ly.N >> 1, c1 = a.lt[l + 1].KS4 * 16;
+      chain_barrier();
+      const int LAT = ly.N >> 1, c1 = a.lt[l + 1].KS * 16;
       if (tid < 32) {
         const bool ok = m0 + tid < st.rows;
         float kl = 0.f;
@@ -320,13 +419,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     } else
     // columns the tiles did not cover, up to the next contraction's padded range: zero
     {
-      const int c0 = 32 * ly.NT, c1 = last ? ly.NS4 * 16 : a.lt[l + 1].KS4 * 16;
+      const int c0 = 32 * ly.NT, c1 = last ? ly.NS * 16 : a.lt[l + 1].KS * 16;
       for (int i = tid; i < 32 * (c1 - c0); i += 64 * NW) {
         const int m = i / (c1 - c0), c = c0 + i % (c1 - c0);
         out[m * PITCH + c] = (elem)0.f;
       }
     }
-    __syncthreads();
+    chain_barrier();
     cur ^= 1;
     chain_stamp(a, 2 + l);
   }
@@ -334,7 +433,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // ---- loss: lanes -> rows -> workgroup (fixed order) -> one fixed-point atomic per workgroup
   lsum += __shfl_xor(lsum, 32, 64);
   if (lh == 0) red[wave][li] = lsum * rwl[li];
-  __syncthreads();
+  chain_barrier();
   if (tid < 32) {
     float s = 0.f;
 #pragma unroll
@@ -348,9 +447,8 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   chain_stamp(a, 2 + a.L);
   // gs * dL/dz (latent wide, in `b`) -> gs * dL/d[mu | lv] in place:  d mu = dz + beta mu,
   // d lv = dz eps exp(lv/2)/2 + beta (exp lv - 1)/2, beta = kl_weight / B (the KL term's own gradient)
-  auto gauss_backward = [&](elem* b, int LAT) {
+  auto gauss_backward = [&](elem* b, int LAT, int pad) __attribute__((always_inline)) {
     if (tid < 32) {
-      const int pad = ((2 * LAT + 63) & ~63);
       for (int d = 0; d < LAT; ++d) {
         const float mu = zs[tid * ZP + d], lv = zs[tid * ZP + LAT + d];
         const float sd = expf(0.5f * lv);
@@ -370,15 +468,16 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const ChainLayer& below = a.lt[l - 1];
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
-    const int nch = ly.NS4 >> 2;
-    if (ly.gauss) { gauss_backward(buf[cur], ly.N >> 1); __syncthreads(); }
-    flush_t(act, ly.N, ly.dzt16, ly.KT);  // gs * dZ of this layer's output -> operand of its weight gradient
+    const int nch = ly.NS >> 2;
+    if (ly.gauss) { gauss_backward(buf[cur], ly.N >> 1, ly.NS * 16); chain_barrier(); }
+    flush_t(act, ly.N, ly.dzt16);  // gs * dZ of this layer's output -> operand of its weight gradient
     for (int t = wave; t < ly.KT; t += NW) {
       const int k0 = 32 * t;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      contract(bw + ly.bw_off + ((long long)t * ly.NS4) * 64 + lane, act, nch, acc);
+      const Job nxt = t + NW < ly.KT ? bwd_job(l, t + NW) : bwd_from(l - 1);
+      const bool odd = contract(bw + ly.bw_off + ((long long)t * ly.NS) * 64 + lane, act, nch, acc, nxt);
       if (below.relu) {
         const unsigned bits = masks[below.mask_tile + t][lane];
 #pragma unroll
@@ -390,20 +489,21 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
         uint2 pk = {P::pack2(acc[4 * g], acc[4 * g + 1]), P::pack2(acc[4 * g + 2], acc[4 * g + 3])};
         *reinterpret_cast<uint2*>(out + li * PITCH + k) = pk;
       }
+      settle(odd);
     }
     {
-      const int c0 = 32 * ly.KT, c1 = below.NS4 * 16;
+      const int c0 = 32 * ly.KT, c1 = below.NS * 16;
       for (int i = tid; i < 32 * (c1 - c0); i += 64 * NW) {
         const int m = i / (c1 - c0), c = c0 + i % (c1 - c0);
         out[m * PITCH + c] = (elem)0.f;
       }
     }
-    __syncthreads();
+    chain_barrier();
     cur ^= 1;
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
-  if (a.lt[0].gauss) { gauss_backward(buf[cur], a.lt[0].N >> 1); __syncthreads(); }
-  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
+  if (a.lt[0].gauss) { gauss_backward(buf[cur], a.lt[0].N >> 1, a.lt[0].NS * 16); chain_barrier(); }
+  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16);
 }
 
 // ---- weight gradients from the fragment-ordered operands: [dW; db](k, n) = sum_b HT(k, b) dZT(n, b).

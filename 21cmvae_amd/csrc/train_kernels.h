@@ -190,6 +190,10 @@ __global__ void gauss_sample_bwd_kernel(const GaussArgs a) {
 
 // ---- sweep forms (BASELINE configs[4]: many models, one batch): blockIdx.y = model ----------
 constexpr int kSweepMax = 16;
+// train_chain.h walks the packed weight streams in chunks of kChainUnit 1-KiB fragments (k-steps of 16
+// features); a tile's k-steps are padded to whole chunks
+constexpr int kChainUnit = 4;
+__host__ __device__ constexpr int chain_steps(int d) { return ((d + 15) / 16 + kChainUnit - 1) / kChainUnit * kChainUnit; }
 struct LossGroup {
   const float* p[kSweepMax]; long long ldp[kSweepMax];
   float* dz[kSweepMax]; long long lddz[kSweepMax];
@@ -249,7 +253,7 @@ __global__ void sum_group_kernel(const SumGroup a) {  // one workgroup per model
 // W^T (rows = outputs, padded) for the forward, row-padded W for the backward.
 struct AdamLayer {
   long long w_off, wt_off, wp_off; int K, N; long long ldwt, ldwp;
-  long long fw_off, bw_off; int KS4, NS4;  // train_chain.h streams (element offsets; k-/n-steps padded to 4)
+  long long fw_off, bw_off; int KS, NS;  // train_chain.h streams (element offsets; k-/n-steps padded to whole units: chain_steps())
 };
 struct AdamArgs {
   float *w, *m, *v;
@@ -309,9 +313,9 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
     }
     if (a.cprec) {
       // forward fragment (tile n/32, k-step k/16): lane = 32*((k%16)/8) + n%32, element k%8
-      const long long pf = L.fw_off + ((((long long)(n >> 5) * L.KS4 + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 3) + (k & 7);
+      const long long pf = L.fw_off + ((((long long)(n >> 5) * L.KS + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 3) + (k & 7);
       // backward fragment (tile k/32, n-step n/16): lane = 32*((n%16)/8) + k%32, element n%8
-      const long long pb = L.bw_off + ((((long long)(k >> 5) * L.NS4 + (n >> 4)) * 64 + ((n >> 3) & 1) * 32 + (k & 31)) << 3) + (n & 7);
+      const long long pb = L.bw_off + ((((long long)(k >> 5) * L.NS + (n >> 4)) * 64 + ((n >> 3) & 1) * 32 + (k & 31)) << 3) + (n & 7);
       if (a.cprec == 1) {
         reinterpret_cast<_Float16*>(a.fw)[pf] = (_Float16)wi;
         reinterpret_cast<_Float16*>(a.bw)[pb] = (_Float16)wi;

@@ -744,9 +744,8 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
       long long of = 0, ob = 0;
       for (int l = 0; l < L; ++l) {
         const int K = m->dims[l], N = m->nw(l);
-        const int KS4 = ((K + 15) / 16 + 3) / 4 * 4, NS4 = ((N + 15) / 16 + 3) / 4 * 4;
-        t->fw_off.push_back(of); of += (long long)((N + 31) / 32) * KS4 * 512;
-        t->bw_off.push_back(ob); ob += (long long)((K + 31) / 32) * NS4 * 512;
+        t->fw_off.push_back(of); of += (long long)((N + 31) / 32) * chain_steps(K) * 512;
+        t->bw_off.push_back(ob); ob += (long long)((K + 31) / 32) * chain_steps(N) * 512;
       }
       HIPCHK(hipMalloc(&t->d_fw, (size_t)of * 2 + 64)); HIPCHK(hipMemsetAsync(t->d_fw, 0, (size_t)of * 2 + 64, st));
       HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 2 + 64)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 2 + 64, st));
@@ -983,7 +982,7 @@ static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_n
     al.K = m->dims[l]; al.N = m->nw(l); al.ldwt = p16(al.K); al.ldwp = p16(al.N);
     if (t->chain) {
       al.fw_off = t->fw_off[l]; al.bw_off = t->bw_off[l];
-      al.KS4 = ((al.K + 15) / 16 + 3) / 4 * 4; al.NS4 = ((al.N + 15) / 16 + 3) / 4 * 4;
+      al.KS = chain_steps(al.K); al.NS = chain_steps(al.N);
     }
   }
   if (t->chain) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->prec == V21_PREC_F16 ? 1 : 2; }
@@ -1130,8 +1129,8 @@ static ChainModel chain_model(v21_trainer* t) {
     ChainLayer& c = a.lt[l];
     c.K = m->dims[l]; c.N = m->nw(l);
     c.gauss = m->act[l] == V21_ACT_GAUSS;
-    c.KS4 = ((c.K + 15) / 16 + 3) / 4 * 4; c.NT = (c.N + 31) / 32;
-    c.NS4 = ((c.N + 15) / 16 + 3) / 4 * 4; c.KT = (c.K + 31) / 32;
+    c.KS = chain_steps(c.K); c.NT = (c.N + 31) / 32;
+    c.NS = chain_steps(c.N); c.KT = (c.K + 31) / 32;
     c.relu = m->act[l] == V21_ACT_RELU;
     c.mask_tile = -1;
     if (c.relu && l + 1 < L) { c.mask_tile = mt; mt += c.NT; }
