@@ -99,7 +99,7 @@ struct ChainStep {
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (physical block 0 is row block 0)
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     a.stamps[i] = t;
@@ -152,7 +152,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * 32;
+  // XCD-major row blocks: workgroups b, b + 8, ... share an XCD (observed round-robin dispatch; speed only), and
+  // XCD x carries the CONSECUTIVE row blocks x * ceil(nb / 8) ...: the batch slice whose weight-gradient tiles
+  // gemm_dw16* then runs on the same XCD, so that it finds the operands this kernel wrote in its own L2.
+  const int nrb = (st.rows + 31) >> 5;
+  const int rb = (int)(blockIdx.x & 7) * ((nrb + 7) >> 3) + (int)(blockIdx.x >> 3);
+  if (rb >= nrb) return;  // (the grid is rounded up to a multiple of 8)
+  const int m0 = rb * 32;
   const int vrows = st.rows - m0;  // valid rows of this block (>= 1; < 32 only in the last block)
   if (tid < 32) klb[tid] = 0.f;
 
@@ -523,19 +529,28 @@ struct Dw16Args {
   unsigned long long* loss_acc; float* loss_out; float* loss_out2;
 };
 struct Dw16Group {
-  Dw16Args p[kNtMaxGroup];
-  int first[kNtMaxGroup + 1];
+  Dw16Args p[kNtMaxGroup];     // all with the same nz
+  int first[kNtMaxGroup + 1];  // output tiles (nx * ny) of the problems before this one
   int count;
 };
 template <class P>
 __global__ void __launch_bounds__(256) gemm_dw16_kernel(const Dw16Group grp) {
   using frag = typename P::frag;
+  // XCD-aware order.  Workgroups b, b + 8, ... land on one XCD (observed round-robin dispatch; a wrong guess
+  // costs speed, never results); physical block p works on logical block (p % 8) * ceil(n / 8) + p / 8, and the
+  // logical order is SLICE-major over all problems of the group (grp.first counts output tiles): the tiles of
+  // batch slice z -- which read the same operand fragments -- sit on one XCD, and with 8 slices on XCD z, where
+  // train_chain_kernel wrote those fragments (its row blocks are XCD-major too).
+  const int ntile = grp.first[grp.count], nblk = ntile * grp.p[0].nz, xper = (nblk + 7) >> 3;
+  const int lb = (int)(blockIdx.x & 7) * xper + (int)(blockIdx.x >> 3);
+  if (lb >= nblk) return;  // (the grid is rounded up to a multiple of 8)
+  const int bz = lb / ntile, tl = lb - bz * ntile;
   int pi = 0;
-  while (pi + 1 < grp.count && (int)blockIdx.x >= grp.first[pi + 1]) ++pi;
+  while (pi + 1 < grp.count && tl >= grp.first[pi + 1]) ++pi;
   const Dw16Args& g = grp.p[pi];
-  const int bid = blockIdx.x - grp.first[pi];
-  const int bx = bid % g.nx, by = (bid / g.nx) % g.ny, bz = bid / (g.nx * g.ny);
-  if (g.loss_acc && bid == 0 && threadIdx.x == 0) {
+  const int bid = tl - grp.first[pi];
+  const int bx = bid % g.nx, by = bid / g.nx;
+  if (g.loss_acc && bid == 0 && bz == 0 && threadIdx.x == 0) {
     const float f = (float)((double)(long long)*g.loss_acc * (1.0 / 4294967296.0));
     *g.loss_out = f;
     if (g.loss_out2) *g.loss_out2 = f;
@@ -607,24 +622,38 @@ __global__ void __launch_bounds__(256) gemm_dw16_kernel(const Dw16Group grp) {
 
 // ---- the same contraction for large batches: 128x128 output tile per workgroup, operands staged through LDS.
 // gemm_dw16_kernel pulls 1 KiB per MFMA into the CU (every wave loads its own A and B fragments); here a batch
-// step's 4 A + 4 B fragments enter LDS once (LDS-DMA, already lane-linear) and serve all four waves, each of
+// step's 4 A + 4 B fragments enter LDS once (LDS-DMA, already lane-linear) and serve four COMPUTE waves, each of
 // which owns a 64x64 quadrant over the whole batch slice: 0.5 KiB per MFMA and no cross-wave reduction.
-// Two stages of kDwStageSteps batch steps double-buffer the stream: one barrier per stage.
-#ifndef V21_DW_STAGE
-#define V21_DW_STAGE 8
-#endif
-constexpr int kDwStageSteps = V21_DW_STAGE;
-constexpr int kDwLdsBytes = 2 * kDwStageSteps * 8 * kFragBytes;
+// Eight more waves do nothing but issue the LDS-DMA: an in-order wave that issues 16 DMA pieces (60-180 cycles
+// each) cannot issue MFMAs meanwhile, and with one workgroup per CU nobody else covers for it (r1: 16 us for
+// ~2 us of MFMA work; with four loaders a stage still took 910 cycles against 512 of MFMAs).  Loader q moves
+// fragment q of every batch step; the loaders run two stages ahead through a ring of four 32-KiB stages (4
+// batch steps each) behind a counted vmcnt -- they issue nothing else, so the count is exact -- and one barrier
+// per stage hands a stage over.
+constexpr int kDwStageSteps = 4;
+constexpr int kDwRing = 4;
+constexpr int kDwStageBytes = kDwStageSteps * 8 * kFragBytes;
+constexpr int kDwLdsBytes = kDwRing * kDwStageBytes;
+constexpr int kDwThreads = 768;  // 4 compute + 8 loader waves
 template <class P>
-__global__ void __launch_bounds__(256) gemm_dw16_lds_kernel(const Dw16Group grp) {
+__global__ void __launch_bounds__(kDwThreads) gemm_dw16_lds_kernel(const Dw16Group grp) {
   using frag = typename P::frag;
   extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+  // XCD-aware order.  Workgroups b, b + 8, ... land on one XCD (observed round-robin dispatch; a wrong guess
+  // costs speed, never results); physical block p works on logical block (p % 8) * ceil(n / 8) + p / 8, and the
+  // logical order is SLICE-major over all problems of the group (grp.first counts output tiles): the tiles of
+  // batch slice z -- which read the same operand fragments -- sit on one XCD, and with 8 slices on XCD z, where
+  // train_chain_kernel wrote those fragments (its row blocks are XCD-major too).
+  const int ntile = grp.first[grp.count], nblk = ntile * grp.p[0].nz, xper = (nblk + 7) >> 3;
+  const int lb = (int)(blockIdx.x & 7) * xper + (int)(blockIdx.x >> 3);
+  if (lb >= nblk) return;  // (the grid is rounded up to a multiple of 8)
+  const int bz = lb / ntile, tl = lb - bz * ntile;
   int pi = 0;
-  while (pi + 1 < grp.count && (int)blockIdx.x >= grp.first[pi + 1]) ++pi;
+  while (pi + 1 < grp.count && tl >= grp.first[pi + 1]) ++pi;
   const Dw16Args& g = grp.p[pi];
-  const int bid = blockIdx.x - grp.first[pi];
-  const int bx = bid % g.nx, by = (bid / g.nx) % g.ny, bz = bid / (g.nx * g.ny);
-  if (g.loss_acc && bid == 0 && threadIdx.x == 0) {
+  const int bid = tl - grp.first[pi];
+  const int bx = bid % g.nx, by = bid / g.nx;
+  if (g.loss_acc && bid == 0 && bz == 0 && threadIdx.x == 0) {
     const float f = (float)((double)(long long)*g.loss_acc * (1.0 / 4294967296.0));
     *g.loss_out = f;
     if (g.loss_out2) *g.loss_out2 = f;
@@ -632,30 +661,39 @@ __global__ void __launch_bounds__(256) gemm_dw16_lds_kernel(const Dw16Group grp)
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 31, lh = lane >> 5;
-  const int wi = wave >> 1, wj = wave & 1;
   const int sbeg = bz * g.steps_per_slice, send = min(g.steps, sbeg + g.steps_per_slice);
   const int nst = (send - sbeg + kDwStageSteps - 1) / kDwStageSteps;
-  const int mt = (g.M + 31) / 32, nt = (g.N + 31) / 32;
-  // fragment q of a step: q < 4 -> A tile 4*by + q, else B tile 4*bx + q - 4 (tiles past the operand: clamped,
-  // their rows/columns are never stored).  Wave w moves fragments w and w + 4 of every step of a stage.
-  const unsigned char* src[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int q = wave + 4 * u;
+  if (wave >= 4) {
+    // ---- loader wave q: fragment q of every step (q < 4: A tile 4 by + q, else B tile 4 bx + q - 4; tiles past
+    // the operand are clamped -- their rows / columns are never stored; steps past the slice re-read its last
+    // step, so that every stage is exactly kDwStageSteps pieces per loader)
+    const int q = wave - 4;
+    const int mt = (g.M + 31) / 32, nt = (g.N + 31) / 32;
     const int tile = q < 4 ? min(4 * by + q, mt - 1) : min(4 * bx + q - 4, nt - 1);
-    src[u] = reinterpret_cast<const unsigned char*>(q < 4 ? g.A : g.B) + ((long long)tile * g.BS) * kFragBytes;
-  }
-  auto issue = [&](int st) {  // stage st -> buffer st & 1; steps past the slice re-read its last step (unused)
-    const unsigned base = lds_addr(dw_smem) + (st & 1) * (kDwStageSteps * 8 * kFragBytes);
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(q < 4 ? g.A : g.B) + ((long long)tile * g.BS) * kFragBytes;
+    auto issue = [&](int st) __attribute__((always_inline)) {
+      const unsigned base = lds_addr(dw_smem) + (st % kDwRing) * kDwStageBytes;
 #pragma unroll
-    for (int s = 0; s < kDwStageSteps; ++s) {
-      const int step = min(sbeg + st * kDwStageSteps + s, send - 1);
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        glds16(src[u] + (long long)step * kFragBytes, lane * 16, base + (s * 8 + wave + 4 * u) * kFragBytes);
+      for (int s = 0; s < kDwStageSteps; ++s) {
+        const int step = min(sbeg + st * kDwStageSteps + s, send - 1);
+        glds16(src + (long long)step * kFragBytes, lane * 16, base + (s * 8 + q) * kFragBytes);
+      }
+    };
+    issue(0);
+    if (nst > 1) issue(1);
+    for (int st = 0; st < nst; ++st) {
+      // stage st has landed (this wave's share) once at most stage st+1's pieces are outstanding; after the
+      // barrier the compute waves are done with stage st-1, hence with the ring slot of stage st+2 as well
+      static_assert(kDwStageSteps == 4, "the counted wait below is one stage of pieces");
+      if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (st + 2 < nst) issue(st + 2);
     }
-  };
+    return;
+  }
+  // ---- compute wave (wi, wj): quadrant rows 64 wi .., columns 64 wj ..
+  const int li = lane & 31, lh = lane >> 5;
+  const int wi = wave >> 1, wj = wave & 1;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -663,40 +701,70 @@ __global__ void __launch_bounds__(256) gemm_dw16_lds_kernel(const Dw16Group grp)
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  issue(0);
   for (int st = 0; st < nst; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // stage st is in LDS; everyone is done with st-1
-    if (st + 1 < nst) issue(st + 1);
-    const unsigned char* buf = dw_smem + (st & 1) * (kDwStageSteps * 8 * kFragBytes) + lane * 16;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage st is in LDS; this wave's reads of st-1 are done
+    const unsigned char* buf = dw_smem + (st % kDwRing) * kDwStageBytes + lane * 16;
     const int ns = min(kDwStageSteps, send - sbeg - st * kDwStageSteps);
+    // the fragments of step s+1 are read under the MFMAs of step s (steps past the slice hold a re-read of its
+    // last step: reading them is harmless, they are not multiplied)
+    frag fa[2][2], fb[2][2];
 #pragma unroll
-    for (int s = 0; s < kDwStageSteps; ++s)
-      if (s < ns) {
-        frag fa[2], fb[2];
+    for (int t = 0; t < 2; ++t) {
+      fa[0][t] = *reinterpret_cast<const frag*>(buf + (2 * wi + t) * kFragBytes);
+      fb[0][t] = *reinterpret_cast<const frag*>(buf + (4 + 2 * wj + t) * kFragBytes);
+    }
+#pragma unroll
+    for (int s = 0; s < kDwStageSteps; ++s) {
+      if (s + 1 < kDwStageSteps) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          fa[t] = *reinterpret_cast<const frag*>(buf + (s * 8 + 2 * wi + t) * kFragBytes);
-          fb[t] = *reinterpret_cast<const frag*>(buf + (s * 8 + 4 + 2 * wj + t) * kFragBytes);
+          fa[(s + 1) & 1][t] = *reinterpret_cast<const frag*>(buf + ((s + 1) * 8 + 2 * wi + t) * kFragBytes);
+          fb[(s + 1) & 1][t] = *reinterpret_cast<const frag*>(buf + ((s + 1) * 8 + 4 + 2 * wj + t) * kFragBytes);
         }
+      }
+      if (s < ns) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = P::template mfma<false>(fa[i], fb[j], acc[i][j]);
+          for (int j = 0; j < 2; ++j) acc[i][j] = P::template mfma<false>(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
       }
+    }
   }
-  float* C = g.C + (long long)bz * g.slab_stride;
+  // ---- epilogue.  Straight from the accumulators a lane would store one float per instruction (lane = column,
+  // registers = rows): 64 store instructions per wave, and a row-per-lane store tail is ISSUE-bound (~170 cycles
+  // each: measured 10.9k cycles here, more than the whole contraction).  So the 64x64 quadrant goes through
+  // this wave's 16 KiB of the (now idle) ring as [row][column] and leaves as 16 stores of 16 bytes per lane:
+  // one instruction = 4 rows x 256 contiguous bytes.
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every compute wave is done reading the ring (loaders have left)
+  float* tile = reinterpret_cast<float*>(dw_smem) + wave * (64 * 68);  // pitch 68 floats: 4 compute waves x 17 KiB
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = 128 * bx + 64 * wj + 32 * j + li;
-      const int m0r = 128 * by + 64 * wi + 32 * i + 4 * lh;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0r + (r & 3) + 8 * (r >> 2);
-        if (n < g.N && m < g.M) C[(long long)m * g.ldc + n] = acc[i][j][r] * g.out_scale;
+      for (int r = 0; r < 16; ++r)
+        tile[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + 32 * j + li] = acc[i][j][r] * g.out_scale;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (own writes only: the tile is private to the wave)
+  float* C = g.C + (long long)bz * g.slab_stride;
+  const int n0 = 128 * bx + 64 * wj + 4 * (lane & 15);
+  // (16-byte stores at 4-byte alignment: the arena offsets and odd widths such as 451 are not multiples of 16 bytes;
+  // gfx950 under ROCm runs with unaligned vector access enabled)
+  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+  const bool vec = n0 + 3 < g.N;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int row = 4 * k + (lane >> 4), m = 128 * by + 64 * wi + row;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * 68 + 4 * (lane & 15));
+    if (m < g.M) {
+      float* dst = C + (long long)m * g.ldc + n0;
+      if (vec) *reinterpret_cast<f32x4_u*>(dst) = v;
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n0 + e < g.N) dst[e] = v[e];
       }
     }
+  }
 }
 
 }  // namespace v21

@@ -1180,7 +1180,7 @@ static int launch_chain(v21_trainer* t, const float* x, long long ldx, const flo
   static_cast<ChainModel&>(a) = chain_model(t);
   static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, t->mlp->dims[t->mlp->L], t, row0);
   CHK(chain_attr(t->prec));
-  const dim3 grid((rows + 31) / 32), block(64 * kChainWaves);
+  const dim3 grid(((rows + 31) / 32 + 7) / 8 * 8), block(64 * kChainWaves);  // whole rounds of the 8 XCDs
   if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
   else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
   HIPCHK(hipGetLastError());
@@ -1193,8 +1193,8 @@ static void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, 
   v21_mlp* m = t->mlp;
   const int L = m->L;
   const int steps = (rows + 15) / 16;
-  static const int sps_big = getenv("V21_DW_SPS") ? atoi(getenv("V21_DW_SPS")) : 32;
-  int nslice = steps >= 64 ? (steps + sps_big - 1) / sps_big : (steps + 31) / 32;
+  // large batches: 8 slices, one per XCD (train_chain_kernel leaves slice z's operands in XCD z's L2)
+  int nslice = steps >= 64 ? 8 : (steps + 31) / 32;
   const int sps = (steps + nslice - 1) / nslice;
   nslice = (steps + sps - 1) / sps;
   const float gs = grad_opscale(brows, m->dims[L]);
@@ -1236,17 +1236,19 @@ static int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t
     for (int i = 0; i < grp.count; ++i) {
       grp.p[i] = probs[o + i];
       if (big) { grp.p[i].nx = (grp.p[i].N + 127) / 128; grp.p[i].ny = (grp.p[i].M + 127) / 128; }
-      grp.first[i] = blocks;
-      blocks += grp.p[i].nx * grp.p[i].ny * grp.p[i].nz;
+      grp.first[i] = blocks;  // tiles; every problem of a step has the same slice count
+      blocks += grp.p[i].nx * grp.p[i].ny;
     }
     grp.first[grp.count] = blocks;
+    blocks *= grp.p[0].nz;
     if (blocks <= 0) continue;
+    const dim3 grid((blocks + 7) / 8 * 8);  // whole rounds of the 8 XCDs (the kernels remap block ids XCD-wise)
     if (big) {
-      if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecF16>, dim3(blocks), dim3(256), kDwLdsBytes, st, grp);
-      else hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecBF16>, dim3(blocks), dim3(256), kDwLdsBytes, st, grp);
+      if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecF16>, grid, dim3(kDwThreads), kDwLdsBytes, st, grp);
+      else hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecBF16>, grid, dim3(kDwThreads), kDwLdsBytes, st, grp);
     } else {
-      if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_kernel<PrecF16>, dim3(blocks), dim3(256), 0, st, grp);
-      else hipLaunchKernelGGL(gemm_dw16_kernel<PrecBF16>, dim3(blocks), dim3(256), 0, st, grp);
+      if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_kernel<PrecF16>, grid, dim3(256), 0, st, grp);
+      else hipLaunchKernelGGL(gemm_dw16_kernel<PrecBF16>, grid, dim3(256), 0, st, grp);
     }
     HIPCHK(hipGetLastError());
   }
@@ -1624,7 +1626,7 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long l
   if (rows > 0) {
     for (v21_trainer* t : s->tr) CHK(ensure_copies(t, false));
     CHK(chain_attr(t0->prec));
-    const dim3 grid((rows + 31) / 32, G), block(64 * kChainWaves);
+    const dim3 grid(((rows + 31) / 32 + 7) / 8 * 8, G), block(64 * kChainWaves);
     if (t0->prec == V21_PREC_F16)
       hipLaunchKernelGGL(train_chain_group_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, cs);
     else
