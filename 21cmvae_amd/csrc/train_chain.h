@@ -96,6 +96,7 @@ struct ChainStep {
   float inv_b;                     // 1 / B_global (the KL term's own gradient)
   unsigned long long row0;         // position of this rank's first row in the global batch (noise key)
   unsigned long long step_off;     // steps since the per-model `step` was stored (a sweep stores it once per epoch)
+  StepCtx sc;                      // replayed step (hipGraph): `first` comes from the step descriptor
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
@@ -152,6 +153,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
+  const long long first = st.sc.desc ? st.sc.desc[*st.sc.cur].first : st.first;
   // XCD-major row blocks: workgroups b, b + 8, ... share an XCD (observed round-robin dispatch; speed only), and
   // XCD x carries the CONSECUTIVE row blocks x * ceil(nb / 8) ...: the batch slice whose weight-gradient tiles
   // gemm_dw16* then runs on the same XCD, so that it finds the operands this kernel wrote in its own L2.
@@ -207,7 +209,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
      // >= K are the zero padding the first contraction reads).
     const int K0 = a.lt[0].K, DO = a.lt[a.L - 1].N;
     const int mq = m0 + RPW * wave + (lane & (RPW - 1));
-    long long srow = mq < st.rows ? st.first + mq : st.first + m0;  // clamped: always a valid position
+    long long srow = mq < st.rows ? first + mq : first + m0;  // clamped: always a valid position
     if (st.idx) srow = st.idx[srow];
     const float rwv = st.rw[srow];
     long long sr[RPW];
@@ -527,6 +529,7 @@ struct Dw16Args {
   float out_scale;
   // on the first problem of a model: fixed-point batch loss -> float slot(s), accumulator cleared
   unsigned long long* loss_acc; float* loss_out; float* loss_out2;
+  StepCtx sc;  // replayed step: the loss also goes to loss_out2[slot of the step]
 };
 struct Dw16Group {
   Dw16Args p[kNtMaxGroup];     // all with the same nz
@@ -553,7 +556,7 @@ __global__ void __launch_bounds__(256) gemm_dw16_kernel(const Dw16Group grp) {
   if (g.loss_acc && bid == 0 && bz == 0 && threadIdx.x == 0) {
     const float f = (float)((double)(long long)*g.loss_acc * (1.0 / 4294967296.0));
     *g.loss_out = f;
-    if (g.loss_out2) *g.loss_out2 = f;
+    if (g.loss_out2) g.loss_out2[g.sc.desc ? g.sc.desc[*g.sc.cur].slot : 0] = f;
     *g.loss_acc = 0ull;
   }
   __shared__ __attribute__((aligned(16))) float part[4][4][16][64];
@@ -656,7 +659,7 @@ __global__ void __launch_bounds__(kDwThreads) gemm_dw16_lds_kernel(const Dw16Gro
   if (g.loss_acc && bid == 0 && bz == 0 && threadIdx.x == 0) {
     const float f = (float)((double)(long long)*g.loss_acc * (1.0 / 4294967296.0));
     *g.loss_out = f;
-    if (g.loss_out2) *g.loss_out2 = f;
+    if (g.loss_out2) g.loss_out2[g.sc.desc ? g.sc.desc[*g.sc.cur].slot : 0] = f;
     *g.loss_acc = 0ull;
   }
   const int lane = threadIdx.x & 63;

@@ -8,6 +8,14 @@
 
 namespace v21 {
 
+// What differs between two optimizer steps of one epoch when a captured step is replayed (hipGraph):
+// where the batch starts, Adam's bias-corrected step size, and the slot of the step's loss.  The host
+// writes one descriptor per step of the epoch; the kernels read descriptor number *cur; the last
+// node of the captured step increments *cur.  desc == nullptr: the values in the kernel arguments.
+struct StepDesc { long long first; float alpha; int slot; };
+struct StepCtx { const StepDesc* desc; const int* cur; };
+__global__ void step_tick_kernel(int* cur) { *cur += 1; }
+
 // K2: loss_i = w_i sum_j (p - y)^2 (relative_mse_loss, emulator.py:68-81, with
 // w_i = 1/(D amp_i^2); plain MSE w_i = 1/D) and dL/dp = scale * w_i * (p - y),
 // scale = 2 / B_global ([K]: batch loss = mean of per-sample losses).
@@ -37,7 +45,8 @@ __global__ void loss_grad_kernel(const float* __restrict__ p, long long ldp,
 }
 
 // deterministic sum of n floats by ONE workgroup -> out[0] (n <= a few 10^5)
-__global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out, int accumulate) {
+__global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out, int accumulate,
+                           float* __restrict__ slots = nullptr, StepCtx sc = StepCtx{nullptr, nullptr}) {
   __shared__ double part[16];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)v[i];
@@ -49,6 +58,7 @@ __global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict
     double t = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
     out[0] = accumulate ? out[0] + (float)t : (float)t;
+    if (slots && sc.desc) slots[sc.desc[*sc.cur].slot] = (float)t;  // the step's loss, where run_epoch collects it
   }
 }
 
@@ -78,10 +88,11 @@ __global__ void gather_batch_kernel(const float* __restrict__ x, int din, float*
                                     float* __restrict__ h0t, long long ldt, const float* __restrict__ y, int dout,
                                     float* __restrict__ yb, long long ldy, const float* __restrict__ w,
                                     float* __restrict__ wb, const int* __restrict__ idx, long long first, int n,
-                                    long long ldx_src, long long ldy_src) {
+                                    long long ldx_src, long long ldy_src, StepCtx sc = StepCtx{nullptr, nullptr}) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
+  if (sc.desc) first = sc.desc[*sc.cur].first;
   const long long s = idx ? (long long)idx[first + row] : first + row;
   const float* xs = x + s * ldx_src;
   for (int j = lane; j < din; j += 64) {
@@ -268,13 +279,14 @@ struct AdamArgs {
   // split-K slabs of the weight gradient still to be summed (single rank: the separate
   // reduce_slabs launch is folded in here; g is rewritten with the sum, same fixed order)
   float* gw; const float* slab; int nslab; long long slab_stride;
+  StepCtx sc;  // replayed step: alpha comes from the descriptor
   AdamLayer lt[16];
 };
 __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha);
 __global__ void adam_repack_kernel(const AdamArgs a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  adam_repack_element(a, i, a.alpha);
+  adam_repack_element(a, i, a.sc.desc ? a.sc.desc[*a.sc.cur].alpha : a.alpha);
 }
 // sweep form: blockIdx.y = model, argument blocks in device memory (one per model)
 struct AlphaGroup { float a[kSweepMax]; };

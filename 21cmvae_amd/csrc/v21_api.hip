@@ -674,7 +674,27 @@ struct v21_trainer {
   std::vector<void*> d_ht16, d_dzt16;  // fragment-ordered weight-gradient operands (train_chain.h)
   long long BS = 0;                    // batch steps of 16 per feature tile
   unsigned long long* d_stamps = nullptr;
+  // ---- replayed steps (hipGraph).  One optimizer step is captured once per (rows, global rows, data pointers)
+  // and replayed; what differs between steps comes from a device table of StepDesc (train_kernels.h) that the
+  // host fills for the steps ahead: an epoch's steps in run_epoch, the next kDescRing steps in step_dev.
+  int graph_mode = 0;         // 0: off (default, see graph_eligible), 1: asked for (v21_trainer_use_graph)
+  bool capturing = false;     // train_on_rows is being recorded, not run
+  StepDesc* d_desc = nullptr; StepDesc* h_desc = nullptr;  // device table, page-locked staging copy
+  long long desc_cap = 0;
+  int* d_cur = nullptr;       // index of the next step's descriptor
+  long long desc_next = 0, desc_count = 0;  // host mirror of *d_cur, entries valid in the table
+  long long desc_iter0 = -1; float desc_lr = -1.f; bool desc_epoch = false;  // what the table was built for
+  struct StepGraph { int rows, brows; const void *x, *y, *rw, *idx; long long row0; hipGraph_t graph; hipGraphExec_t exec; };
+  std::vector<StepGraph> graphs;
+  int graph_misses = 0;
 };
+constexpr long long kDescRing = 1024;
+static StepCtx step_ctx(const v21_trainer* t) { return t->capturing ? StepCtx{t->d_desc, t->d_cur} : StepCtx{nullptr, nullptr}; }
+static void destroy_graphs(v21_trainer* t) {
+  for (auto& g : t->graphs) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
+  t->graphs.clear();
+  t->desc_count = 0; t->desc_next = 0; t->desc_iter0 = -1;
+}
 
 static int zalloc(float** p, size_t nfloat, hipStream_t st) {
   HIPCHK(hipMalloc((void**)p, nfloat * sizeof(float)));
@@ -791,6 +811,10 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
     for (float* p : *v) if (p) hipFree(p);
   hipFree(t->d_wt); hipFree(t->d_wp);
   hipFree(t->d_yb); hipFree(t->d_wb); hipFree(t->d_rowloss); hipFree(t->d_evalsum);
+  destroy_graphs(t);
+  if (t->d_desc) hipFree(t->d_desc);
+  if (t->h_desc) hipHostFree(t->h_desc);
+  if (t->d_cur) hipFree(t->d_cur);
   if (t->d_steploss) hipFree(t->d_steploss);
   if (t->d_slab) hipFree(t->d_slab);
   if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
@@ -804,6 +828,8 @@ extern "C" int v21_trainer_set_adam(v21_trainer* t, const v21_adam* cfg) {
   if (!t || !cfg) return fail(V21_ERR_ARG, "null argument");
   if (!(cfg->lr >= 0.f) || !(cfg->beta1 >= 0.f && cfg->beta1 < 1.f) || !(cfg->beta2 >= 0.f && cfg->beta2 < 1.f) || !(cfg->eps >= 0.f))
     return fail(V21_ERR_ARG, "bad Adam hyper-parameters");
+  if (cfg->beta1 != t->adam.beta1 || cfg->beta2 != t->adam.beta2 || cfg->eps != t->adam.eps)
+    destroy_graphs(t);  // (lr only enters through the step descriptors)
   t->adam = *cfg;
   return V21_OK;
 }
@@ -819,6 +845,7 @@ extern "C" int v21_trainer_set_data(v21_trainer* t, int which, const float* x, c
   const int din = m->dims[0], dout = m->dims[m->L];
   if (!y && din != dout) return fail(V21_ERR_ARG, "y == NULL (y = x) needs in_dim == out_dim");
   hipStream_t st = t->ctx->stream;
+  if (which == 0) { HIPCHK(hipStreamSynchronize(st)); destroy_graphs(t); }  // captured steps hold the old pointers
   if (t->d_x[which]) { HIPCHK(hipFree(t->d_x[which])); t->d_x[which] = nullptr; }
   if (t->d_y[which] && !t->y_is_x[which]) HIPCHK(hipFree(t->d_y[which]));
   t->d_y[which] = nullptr;
@@ -987,6 +1014,7 @@ static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_n
   }
   if (t->chain) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->prec == V21_PREC_F16 ? 1 : 2; }
   a.skip_nt = (skip_nt && t->chain) ? 1 : 0;
+  a.sc = step_ctx(t);
   return a;
 }
 // need_nt: the caller reads the fp32 copies (per-layer forward/backward); chain steps do not
@@ -1056,7 +1084,8 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
                        ldy, t->d_wb, t->d_dz[L], p16(dout), t->d_dzt[L], t->Bp, t->d_rowloss, rows, dout,
                        2.0f / (float)brows, (const float*)t->d_klrow);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_g + t->P, 0);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_g + t->P, 0, t->d_steploss,
+                       step_ctx(t));
     HIPCHK(hipGetLastError());
     // weight gradients contract over the batch: slices of <= kNtMaxKPerWg rows -> slabs
     int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
@@ -1105,6 +1134,10 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
     }
   } else {
     HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
+  }
+  if (t->capturing) {  // recorded, not run: iteration count, step size and loss slot come from the descriptors
+    CHK(adam_and_copies(t, true, 0.f));
+    return V21_OK;
   }
   CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
   t->iter += 1;
@@ -1155,7 +1188,7 @@ static ChainStep chain_step(const float* x, long long ldx, const float* y, long 
   st.gs = grad_opscale(brows, dout);
   st.inv_b = 1.0f / (float)brows;
   st.row0 = (unsigned long long)row0;
-  (void)vae;
+  if (vae) st.sc = step_ctx(vae);
   return st;
 }
 static int chain_attr(int prec) {
@@ -1207,28 +1240,32 @@ static void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, 
     g.steps = steps; g.steps_per_slice = sps; g.BS = t->BS;
     g.slab_stride = (long long)t->P + 4;
     g.out_scale = 1.0f / gs;
-    if (l == 0) { g.loss_acc = (unsigned long long*)t->d_ticket; g.loss_out = t->d_g + t->P; g.loss_out2 = loss_out2; }
+    if (l == 0) {
+      g.loss_acc = (unsigned long long*)t->d_ticket; g.loss_out = t->d_g + t->P; g.loss_out2 = loss_out2;
+      if (t->capturing) { g.loss_out2 = t->d_steploss; g.sc = step_ctx(t); }
+    }
     probs.push_back(g);
   }
   *nslice_out = nslice;
 }
+static int dw16_attr(int prec) {  // (function attributes are per device; set outside any stream capture)
+  static bool attr_done_dev[64][3] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bool* attr_done = attr_done_dev[dev & 63];
+  if (!attr_done[prec]) {
+    if (prec == V21_PREC_F16)
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
+    else
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
+    attr_done[prec] = true;
+  }
+  return V21_OK;
+}
 static int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t st) {
   // large batches: 128x128 tiles staged through LDS (half the bytes pulled into a CU per MFMA)
-  const char* env = getenv("V21_DW_LDS");
-  const bool big = !probs.empty() && probs[0].steps >= 64 && !(env && env[0] == '0');
-  if (big) {
-    static bool attr_done_dev[64][3] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    bool* attr_done = attr_done_dev[dev & 63];
-    if (!attr_done[prec]) {
-      if (prec == V21_PREC_F16)
-        HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
-      else
-        HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
-      attr_done[prec] = true;
-    }
-  }
+  const bool big = !probs.empty() && probs[0].steps >= 64;
+  if (big) CHK(dw16_attr(prec));
   for (size_t o = 0; o < probs.size(); o += kNtMaxGroup) {
     Dw16Group grp{};
     grp.count = (int)std::min<size_t>(kNtMaxGroup, probs.size() - o);
@@ -1287,6 +1324,10 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   } else {
     HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
   }
+  if (t->capturing) {
+    CHK(adam_and_copies(t, true, 0.f, true, fold));
+    return V21_OK;
+  }
   CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
   t->iter += 1;
   CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter), true, fold));
@@ -1303,9 +1344,95 @@ static int gather_batch(v21_trainer* t, const float* x, long long ldx, const flo
   const int wpb = 4;
   hipLaunchKernelGGL(gather_batch_kernel, dim3((rows + wpb - 1) / wpb), dim3(64 * wpb), 0, t->ctx->stream, x, din,
                      t->d_h[0], p16(din), t->d_ht[0], t->Bp, y, dout, t->d_yb, p16(dout), rw, t->d_wb, d_idx, first,
-                     rows, ldx, ldy_src);
+                     rows, ldx, ldy_src, step_ctx(t));
   HIPCHK(hipGetLastError());
   return V21_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// replayed steps (hipGraph): SURVEY 7.1 step 6.  A captured step costs the host one
+// hipGraphLaunch (7 us per step instead of 43 us for the 14 launches of an f32 step).
+// OPT-IN (v21_trainer_use_graph), because measured on MI355X in r2 it does not pay: the
+// steps are bound by the GPU, not by the host -- an f32 batch-256 step is 14 dependent
+// kernels of ~7 us each (kernel boundary + a cold-L2 round trip + a short MFMA chain):
+// 96 us eager, 102 us replayed; the 3-launch f16 step 45 us eager, 50 us replayed (the
+// cursor-tick node and the boundary between two graph launches cost more than they save).
+// ---------------------------------------------------------------------------------
+static bool graph_eligible(const v21_trainer* t) {
+  return t->graph_mode == 1 && t->ctx->nranks == 1 && t->gl < 0;
+}
+static int ensure_desc(v21_trainer* t, long long n) {
+  if (t->desc_cap >= n) return V21_OK;
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  if (t->d_desc) HIPCHK(hipFree(t->d_desc));
+  if (t->h_desc) HIPCHK(hipHostFree(t->h_desc));
+  HIPCHK(hipMalloc((void**)&t->d_desc, (size_t)n * sizeof(StepDesc)));
+  HIPCHK(hipHostMalloc((void**)&t->h_desc, (size_t)n * sizeof(StepDesc), hipHostMallocDefault));
+  if (!t->d_cur) HIPCHK(hipMalloc((void**)&t->d_cur, 16));
+  t->desc_cap = n;
+  destroy_graphs(t);  // captured steps hold the old table
+  return V21_OK;
+}
+// upload descriptors [0, count) from h_desc and point the device cursor at the first
+static int publish_desc(v21_trainer* t, long long count) {
+  hipStream_t st = t->ctx->stream;
+  HIPCHK(hipMemcpyAsync(t->d_desc, t->h_desc, (size_t)count * sizeof(StepDesc), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(t->d_cur, 0, 4, st));
+  t->desc_count = count; t->desc_next = 0;
+  return V21_OK;
+}
+static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
+                         const int* d_idx, long long first, int rows, int brows, float* loss_out, long long row0);
+// the captured step for this batch geometry and these pointers (captured on first use); nullptr if capture failed
+static int step_graph(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
+                      const int* d_idx, int rows, int brows, long long row0, hipGraphExec_t* out) {
+  *out = nullptr;
+  for (auto& g : t->graphs)
+    if (g.rows == rows && g.brows == brows && g.x == x && g.y == y && g.rw == rw && g.idx == d_idx && g.row0 == row0) {
+      *out = g.exec;
+      return V21_OK;
+    }
+  if (t->graphs.size() >= 8) {  // callers that pass new pointers every step would re-capture every step
+    if (++t->graph_misses > 16) { t->graph_mode = 0; destroy_graphs(t); return V21_OK; }
+    hipGraphExecDestroy(t->graphs.front().exec); hipGraphDestroy(t->graphs.front().graph);
+    t->graphs.erase(t->graphs.begin());
+  }
+  hipStream_t st = t->ctx->stream;
+  // everything that may not happen inside a capture: lazy refreshes, function attributes
+  CHK(ensure_copies(t, !t->chain));
+  if (t->chain) { CHK(chain_attr(t->prec)); CHK(dw16_attr(t->prec)); }
+  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { (void)hipGetLastError(); t->graph_mode = 0; return V21_OK; }  // e.g. the legacy stream: run eagerly
+  t->capturing = true;
+  int r = train_on_rows(t, x, ldx, y, ldy, rw, d_idx, 0, rows, brows, nullptr, row0);
+  if (r == V21_OK) {
+    hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(1), 0, st, t->d_cur);
+    if (hipGetLastError() != hipSuccess) r = V21_ERR_HIP;
+  }
+  t->capturing = false;
+  hipGraph_t graph = nullptr;
+  e = hipStreamEndCapture(st, &graph);
+  if (r != V21_OK || e != hipSuccess || !graph) {
+    (void)hipGetLastError();
+    if (graph) hipGraphDestroy(graph);
+    t->graph_mode = 0;
+    return r != V21_OK ? r : V21_OK;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGetLastError(); hipGraphDestroy(graph); t->graph_mode = 0; return V21_OK; }
+  t->graphs.push_back(v21_trainer::StepGraph{rows, brows, x, y, rw, d_idx, row0, graph, exec});
+  *out = exec;
+  return V21_OK;
+}
+// bookkeeping train_on_rows does after a step, for a replayed one
+static void after_replay(v21_trainer* t) {
+  t->iter += 1;
+  t->desc_next += 1;
+  t->copies_ok = true;
+  t->nt_ok = !t->chain;
+  invalidate_streams(t->mlp);
+  t->mlp->wpad_ok = true;
 }
 
 extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int batch, double* loss) {
@@ -1329,19 +1456,39 @@ extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int ba
     d_idx = t->d_perm;
   }
   const long long steps = (n + batch - 1) / batch;
-  if (t->steploss_cap < steps) {
+  if (t->steploss_cap < std::max<long long>(steps, kDescRing)) {
+    HIPCHK(hipStreamSynchronize(st));
+    destroy_graphs(t);  // captured steps hold the old pointer
     if (t->d_steploss) HIPCHK(hipFree(t->d_steploss));
-    HIPCHK(hipMalloc((void**)&t->d_steploss, (size_t)steps * sizeof(float)));
-    t->steploss_cap = steps;
+    t->steploss_cap = std::max<long long>(steps, kDescRing);
+    HIPCHK(hipMalloc((void**)&t->d_steploss, (size_t)t->steploss_cap * sizeof(float)));
   }
   const int din = m->dims[0], dout = m->dims[m->L];
+  bool replay = graph_eligible(t);
+  if (replay) {  // one descriptor per step of this epoch
+    CHK(ensure_desc(t, std::max<long long>(steps, kDescRing)));
+    for (long long s = 0; s < steps; ++s) t->h_desc[s] = StepDesc{s * batch, adam_alpha(t->adam, t->iter + s + 1), (int)s};
+    CHK(publish_desc(t, steps));
+    t->desc_epoch = true;
+  }
   for (long long s = 0; s < steps; ++s) {
     const long long first = s * batch;
     const int brows = (int)std::min<long long>(batch, n - first);  // rows of the global batch
     const long long lo = first + (long long)brows * rk / R, hi = first + (long long)brows * (rk + 1) / R;
     const int rows = (int)(hi - lo);
-    CHK(train_on_rows(t, t->d_x[0], din, t->y_is_x[0] ? nullptr : t->d_y[0], dout, t->d_rw[0], d_idx, lo, rows, brows,
-                      t->d_steploss + s, lo - first));
+    const float* yy = t->y_is_x[0] ? nullptr : t->d_y[0];
+    if (replay) {
+      hipGraphExec_t exec = nullptr;
+      CHK(step_graph(t, t->d_x[0], din, yy, dout, t->d_rw[0], d_idx, rows, brows, 0, &exec));
+      if (exec) {
+        HIPCHK(hipGraphLaunch(exec, st));
+        after_replay(t);
+        continue;
+      }
+      // capture is not possible here: the rest of the epoch runs eagerly; the steps replayed so far are unaffected
+      replay = false;
+    }
+    CHK(train_on_rows(t, t->d_x[0], din, yy, dout, t->d_rw[0], d_idx, lo, rows, brows, t->d_steploss + s, lo - first));
   }
   std::vector<float> h(steps);
   HIPCHK(hipMemcpyAsync(h.data(), t->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1394,6 +1541,32 @@ extern "C" int v21_trainer_step_dev(v21_trainer* t, const float* d_x, const floa
   v21_mlp* m = t->mlp;
   const int din = m->dims[0], dout = m->dims[m->L];
   if (!d_y && din != dout) return fail(V21_ERR_ARG, "d_y == NULL (y = x) needs in_dim == out_dim");
+  if (graph_eligible(t) && n_rows > 0) {
+    // descriptors for the next kDescRing steps (first = 0: the caller's pointers are the batch); rebuilt when
+    // they run out, after an epoch used the table, or when lr / the iteration count changed behind them
+    CHK(ensure_desc(t, kDescRing));
+    if (t->steploss_cap < kDescRing) {
+      HIPCHK(hipStreamSynchronize(t->ctx->stream));
+      destroy_graphs(t);
+      if (t->d_steploss) HIPCHK(hipFree(t->d_steploss));
+      HIPCHK(hipMalloc((void**)&t->d_steploss, (size_t)kDescRing * sizeof(float)));
+      t->steploss_cap = kDescRing;
+    }
+    if (t->desc_epoch || t->desc_next >= t->desc_count || t->desc_lr != t->adam.lr ||
+        t->desc_iter0 + t->desc_next != t->iter) {
+      HIPCHK(hipStreamSynchronize(t->ctx->stream));  // the staging copy may still be in flight
+      for (long long i = 0; i < kDescRing; ++i) t->h_desc[i] = StepDesc{0, adam_alpha(t->adam, t->iter + i + 1), (int)i};
+      CHK(publish_desc(t, kDescRing));
+      t->desc_epoch = false; t->desc_lr = t->adam.lr; t->desc_iter0 = t->iter;
+    }
+    hipGraphExec_t exec = nullptr;
+    CHK(step_graph(t, d_x, din, d_y, dout, d_rw, nullptr, n_rows, global_rows, 0, &exec));
+    if (exec) {
+      HIPCHK(hipGraphLaunch(exec, t->ctx->stream));
+      after_replay(t);
+      return V21_OK;
+    }
+  }
   return train_on_rows(t, d_x, din, d_y, dout, d_rw, nullptr, 0, n_rows, global_rows, nullptr,
                        (long long)t->ctx->rank * t->max_batch);
 }
@@ -1763,6 +1936,10 @@ extern "C" int v21_trainer_chain_stamps(v21_trainer* t, uint64_t* out, int n) {
 }
 extern "C" int v21_trainer_use_graph(v21_trainer* t, int enable) {
   if (!t) return fail(V21_ERR_ARG, "null trainer");
-  (void)enable;  // hipGraph capture of the step: not in this build
+  CHK(use(t->ctx));
+  if (enable && (t->ctx->nranks > 1 || t->gl >= 0))
+    return fail(V21_ERR_UNSUPPORTED, "captured steps need one rank and a stack without a variational layer");
+  if (!enable) { HIPCHK(hipStreamSynchronize(t->ctx->stream)); destroy_graphs(t); }
+  t->graph_mode = enable ? 1 : 0;
   return V21_OK;
 }

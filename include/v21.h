@@ -173,6 +173,11 @@ int v21_trainer_set_state(v21_trainer* tr, int64_t iter, const float* m, const f
                           size_t n);
 /* gradient of the last step (after all-reduce), for tests */
 int v21_trainer_get_grad(v21_trainer* tr, float* g, size_t n);
+/* Captured-step replay (hipGraph): run_epoch / step_dev capture one optimizer step per
+ * batch geometry and replay it; first row, Adam step size and loss slot of each step come from a device
+ * table.  Bit-identical to eager launches.  Off by default (the steps are GPU-bound on MI355X: replay frees
+ * the host thread, it does not shorten a step); V21_ERR_UNSUPPORTED with a communicator or a
+ * V21_ACT_GAUSS layer.  Replaces nothing in the reference (Keras fit, emulator.py:369-378, has no analogue). */
 int v21_trainer_use_graph(v21_trainer* tr, int enable);
 /* diagnostics: s_memtime stamps of workgroup 0 of the last chain-kernel launch (train_chain.h):
  * [0] start, [1] batch gathered, [2..L+1] after forward layer l, [L+2] loss reduced,

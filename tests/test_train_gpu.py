@@ -574,3 +574,77 @@ def test_variational_stack_on_the_chain_kernel(ctx, prec):
     o = Ws[0].size + bs[0].size
     g_lv = gc[o:o + Ws[1].size].reshape(Ws[1].shape)[:, 9:]
     assert np.abs(g_lv).max() > 0
+
+
+# ---- captured steps (hipGraph): SURVEY 7.1 step 6 -------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_replayed_steps_equal_eager_steps_bit_for_bit(ctx, prec):
+    """A captured step replays the very kernels an eager step launches (first row / Adam step size / loss slot
+    come from a device table instead of the kernel arguments): weights, Adam state and epoch losses must be
+    IDENTICAL, over epochs with a partial last batch, a learning-rate change between epochs, and on the
+    step_dev path."""
+    native = pkg("_native")
+    dims, act = [451, 40, 9, 24, 451], [1, 0, 1, 0]
+    synth = pkg("synth")
+    sig = synth.make_signals(300, seed=9)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    res = {}
+    for graph in (True, False):
+        Ws, bs = ora.init_mlp(dims, seed=21)
+        st = native.Stack(ctx, dims, act)
+        st.set_weights(ora.flatten_params(Ws, bs))
+        tr = native.Trainer(st, prec, 128)
+        tr.use_graph(graph)  # (off by default)
+        tr.set_adam(lr=2e-3)
+        tr.set_data(0, y, None, w)
+        losses = []
+        for ep in range(3):
+            if ep == 2:
+                tr.set_lr(5e-4)
+            losses.append(tr.run_epoch(ora.epoch_permutation(300, 4, ep), 128))  # 128 + 128 + 44 rows
+        d_x, d_w = ctx.malloc(y[:96].nbytes), ctx.malloc(w[:96].nbytes)
+        ctx.h2d(d_x, np.ascontiguousarray(y[:96])); ctx.h2d(d_w, np.ascontiguousarray(w[:96]))
+        for _ in range(5):
+            tr.step_dev(d_x, None, d_w, 96, 96)
+        losses.append(tr.last_step_loss())
+        it, mm, vv = tr.get_state()
+        res[graph] = (np.array(losses), st.get_weights(), mm, vv, it)
+        ctx.free(d_x); ctx.free(d_w)
+    assert res[True][4] == res[False][4] == 3 * 3 + 5
+    for a, b in zip(res[True][:4], res[False][:4]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_replayed_steps_follow_data_and_state_changes(ctx):
+    """What a captured step bakes in must be re-captured when it changes: new training data (pointers), new
+    Adam betas, a restored optimizer state; and a variational stack refuses capture."""
+    native = pkg("_native")
+    dims, act = [7, 32, 16, 9], [1, 1, 0]
+    rng = np.random.default_rng(3)
+
+    def run(graph):
+        Ws, bs = ora.init_mlp(dims, seed=4)
+        st = native.Stack(ctx, dims, act)
+        st.set_weights(ora.flatten_params(Ws, bs))
+        tr = native.Trainer(st, "f32", 64)
+        tr.use_graph(graph)
+        out = []
+        for k in range(3):
+            r = np.random.default_rng(10 + k)
+            x = r.normal(size=(150 + 10 * k, 7)).astype(np.float32); yy = r.normal(size=(150 + 10 * k, 9)).astype(np.float32)
+            tr.set_data(0, x, yy, ora.mse_row_weight(yy).astype(np.float32))   # new buffers every time
+            tr.set_adam(lr=1e-3, beta1=0.9 - 0.1 * k)                           # betas live in kernel arguments
+            out.append(tr.run_epoch(None, 64))
+            if k == 1:
+                it, mm, vv = tr.get_state()
+                tr.set_state(it + 7, mm * 0.5, vv)                              # resumed optimizer state
+        return np.array(out), st.get_weights()
+    a, b = run(True), run(False)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    stv = native.Stack(ctx, [451, 32, 4, 16, 451], [1, native.ACT_GAUSS, 1, 0])
+    trv = native.Trainer(stv, "f16", 32)
+    with pytest.raises(native.EngineError):
+        trv.use_graph(True)
+    trv.use_graph(False)
