@@ -95,6 +95,9 @@ SIGNATURES = {
     "v21_sweep_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),
     "v21_sweep_destroy": (C.c_int, [_P]),
     "v21_sweep_run_epoch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
+    "v21_joint_create": (C.c_int, [_P, _P, C.c_int, C.POINTER(_P)]),
+    "v21_joint_destroy": (C.c_int, [_P]),
+    "v21_joint_run_epoch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
     "v21_comm_get_unique_id": (C.c_int, [_P, _P]),
     "v21_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "v21_comm_destroy": (C.c_int, [_P]),
@@ -447,6 +450,35 @@ class Trainer:
         g = np.empty(self.stack.num_params, np.float32)
         check(self.lib.v21_trainer_get_grad(self.h, _fptr(g), g.size))
         return g
+
+
+class Joint:
+    """Autoencoder + latent emulator stepping together on the same rows (v21_joint_*; BASELINE configs[2])."""
+
+    def __init__(self, ae_trainer, em_trainer, latent_layer):
+        self.lib = ae_trainer.lib
+        self.trainers = (ae_trainer, em_trainer)  # keep them alive
+        h = _P()
+        check(self.lib.v21_joint_create(ae_trainer.h, em_trainer.h, int(latent_layer), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.v21_joint_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def run_epoch(self, perm, batch):
+        """-> (autoencoder epoch loss, emulator epoch loss)"""
+        out = (C.c_double * 2)()
+        pp = None
+        if perm is not None:
+            perm = np.ascontiguousarray(perm, dtype=np.int32)
+            pp = perm.ctypes.data_as(C.POINTER(C.c_int32))
+        check(self.lib.v21_joint_run_epoch(self.h, pp, int(batch), out))
+        return float(out[0]), float(out[1])
 
 
 class Sweep:

@@ -83,6 +83,9 @@ struct ChainModel {
   float kl_weight;
   int sample;
   unsigned long long seed, step;
+  // joint step (train_chain_joint_kernel): the fp32 outputs of this (linear) layer stay in LDS as the NEXT
+  // model's targets (-1: none) -- the autoencoder's latent layer, emulator.py:753-754 without the host round trip
+  int zcap_layer;
 };
 // the batch of this step (shared by every model of a sweep)
 struct ChainStep {
@@ -97,6 +100,7 @@ struct ChainStep {
   unsigned long long row0;         // position of this rank's first row in the global batch (noise key)
   unsigned long long step_off;     // steps since the per-model `step` was stored (a sweep stores it once per epoch)
   StepCtx sc;                      // replayed step (hipGraph): `first` comes from the step descriptor
+  int y_from_lds;                  // joint step: the targets are the rows the previous model left in LDS (zcap_layer)
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
@@ -120,6 +124,17 @@ template <class P>
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_group_kernel(const ChainModel* __restrict__ tab,
                                                                              const ChainStep st) {
   train_chain_body<P>(tab[blockIdx.y], st);
+}
+
+// joint step: the SAME workgroup carries its 32 rows through model A (the autoencoder, signals -> signals) and then
+// through model B (the latent emulator, parameters -> latent), whose targets are the rows model A's latent layer
+// left in LDS: the reference's frozen-encoder targets (emulator.py:753-754) without leaving the chip.
+template <class P>
+__global__ void __launch_bounds__(64 * kChainWaves) train_chain_joint_kernel(const ChainModel* __restrict__ tab /* [2], device */,
+                                                                             const ChainStep sa, const ChainStep sb) {
+  train_chain_body<P>(tab[0], sa);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // model A's last LDS reads precede model B's gather
+  train_chain_body<P>(tab[1], sb);
 }
 
 // LDS-only rendezvous: own LDS writes retired, then the barrier.  Deliberately NOT __syncthreads():
@@ -240,10 +255,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       for (int i = 0; i < 8; ++i) {
         const int k = lane + 64 * i;  // <= 511 < PITCH, YP
         buf[0][m * PITCH + k] = (elem)v[r][i];
-        if (!st.y) ystg[m * YP + k] = v[r][i];
+        if (!st.y && !st.y_from_lds) ystg[m * YP + k] = v[r][i];
       }
     }
-    if (st.y) {  // separate targets: a second pass through the same registers
+    if (st.y_from_lds) {  // rows of the previous model's captured layer (fp32, in the variational head's buffer)
+      const int DOl = a.lt[a.L - 1].N;
+      for (int i = tid; i < 32 * DOl; i += 64 * NW) ystg[(i / DOl) * YP + i % DOl] = zs[(i / DOl) * ZP + i % DOl];
+    } else if (st.y) {  // separate targets: a second pass through the same registers
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         const int kmax = m0 + RPW * wave + r < st.rows ? DO : 0;
@@ -372,6 +390,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
           if (n < ZP) *reinterpret_cast<f32x4*>(zs + li * ZP + n) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
         }
       } else if (!last) {
+        if (l == a.zcap_layer) {  // joint step: this layer's outputs are the next model's targets (fp32)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = n0 + 8 * g + 4 * lh;
+            if (n < ZP) *reinterpret_cast<f32x4*>(zs + li * ZP + n) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+          }
+        }
         unsigned bits = 0;
         if (ly.relu) {
 #pragma unroll

@@ -1175,6 +1175,7 @@ static ChainModel chain_model(v21_trainer* t) {
   a.BS = t->BS;
   a.loss_acc = (unsigned long long*)t->d_ticket;
   a.stamps = t->d_stamps;
+  a.zcap_layer = -1;
   if (t->gl >= 0) { a.kl_weight = t->kl_weight; a.sample = t->sample; a.seed = t->seed; a.step = (unsigned long long)t->iter; }
   return a;
 }
@@ -1200,9 +1201,11 @@ static int chain_attr(int prec) {
   if (prec == V21_PREC_F16) {
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)train_chain_joint_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
   } else {
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)train_chain_joint_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
   }
   done[prec] = true;
   return V21_OK;
@@ -1913,6 +1916,131 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
   for (size_t k = 0; k < s->tr.size(); ++k) {
     double tot = 0.0;
     for (long long i = 0; i < steps; ++i) tot += (double)h[k * steps + i];
+    losses[k] = tot / (double)n;
+  }
+  return V21_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// joint step (BASELINE configs[2]: "encoder+decoder+emulator joint train"): the autoencoder
+// (signals -> signals, emulator.py:739-747) and the latent emulator (parameters -> latent, :756-764) take one
+// optimizer step each on the SAME rows of every batch, and the emulator's targets are the latents the
+// encoder produces for those rows in that very step (stop-gradient) instead of the reference's
+// encoder.predict() of the finished autoencoder (:753-754).  With the autoencoder frozen (lr = 0) it is
+// exactly the reference's phase 2.  One launch carries a row block through both models
+// (train_chain_joint_kernel), one grouped launch forms all weight gradients, two Adam launches.
+// ---------------------------------------------------------------------------------
+struct v21_joint {
+  v21_trainer *ae = nullptr, *em = nullptr;
+  int latent_layer = 0;
+  ChainModel* d_tab = nullptr;
+  std::vector<ChainModel> h_tab;
+};
+extern "C" int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_layer, v21_joint** out) {
+  if (!ae || !em || !out) return fail(V21_ERR_ARG, "null argument");
+  if (ae == em || ae->ctx != em->ctx || ae->prec != em->prec || ae->max_batch != em->max_batch)
+    return fail(V21_ERR_ARG, "the two trainers must be distinct and share context, precision and max_batch");
+  if (!ae->chain || !em->chain || ae->gl >= 0 || em->gl >= 0)
+    return fail(V21_ERR_UNSUPPORTED, "the joint step runs on the chain kernel: f16 / bf16, widths <= %d, no variational layer", kChainMaxDim);
+  const v21_mlp* ma = ae->mlp;
+  const v21_mlp* me = em->mlp;
+  if (latent_layer < 0 || latent_layer >= ma->L - 1 || ma->act[latent_layer] != V21_ACT_LINEAR)
+    return fail(V21_ERR_ARG, "latent_layer %d must be a linear layer below the autoencoder's output", latent_layer);
+  if (ma->dims[latent_layer + 1] != me->dims[me->L] || ma->dims[latent_layer + 1] > 2 * kChainMaxLatent)
+    return fail(V21_ERR_ARG, "latent width %d (autoencoder) vs emulator output %d (at most %d)", ma->dims[latent_layer + 1],
+                me->dims[me->L], 2 * kChainMaxLatent);
+  if (ma->dims[0] != ma->dims[ma->L]) return fail(V21_ERR_ARG, "the first trainer must be an autoencoder (in == out width)");
+  CHK(use(ae->ctx));
+  v21_joint* j = new v21_joint();
+  j->ae = ae; j->em = em; j->latent_layer = latent_layer;
+  hipError_t e = hipMalloc((void**)&j->d_tab, 2 * sizeof(ChainModel));
+  if (e != hipSuccess) { delete j; return fail(V21_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+  *out = j;
+  return V21_OK;
+}
+extern "C" int v21_joint_destroy(v21_joint* j) {
+  if (!j) return V21_OK;
+  hipSetDevice(j->ae->ctx->device);
+  hipStreamSynchronize(j->ae->ctx->stream);
+  hipFree(j->d_tab);
+  delete j;
+  return V21_OK;
+}
+// one epoch: the autoencoder trainer holds the signals (set_data(0, signals, NULL, w)), the emulator trainer the
+// parameters of the SAME rows (set_data(0, params, any (n, latent) array, w_mse)); losses[0] = autoencoder,
+// losses[1] = emulator (Keras epoch losses)
+extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch, double* losses) {
+  if (!j || !losses) return fail(V21_ERR_ARG, "null argument");
+  v21_trainer *ta = j->ae, *te = j->em;
+  if (ta->n[0] < 1 || te->n[0] != ta->n[0]) return fail(V21_ERR_STATE, "both trainers need training sets of the same row count");
+  if (!ta->y_is_x[0]) return fail(V21_ERR_STATE, "the autoencoder's targets must be its inputs (y == NULL)");
+  if (ta->ctx->nranks > 1) return fail(V21_ERR_UNSUPPORTED, "the joint step is single-rank");
+  CHK(use(ta->ctx));
+  hipStream_t st = ta->ctx->stream;
+  const long long n = ta->n[0];
+  if (batch < 1 || batch > ta->max_batch) return fail(V21_ERR_ARG, "batch %d not in [1, max_batch %d]", batch, ta->max_batch);
+  const int* d_idx = nullptr;
+  if (perm) {
+    if (ta->perm_cap < n) {
+      if (ta->d_perm) HIPCHK(hipFree(ta->d_perm));
+      HIPCHK(hipMalloc((void**)&ta->d_perm, (size_t)n * sizeof(int)));
+      ta->perm_cap = n;
+    }
+    HIPCHK(hipMemcpyAsync(ta->d_perm, perm, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    d_idx = ta->d_perm;
+  }
+  const long long steps = (n + batch - 1) / batch;
+  for (v21_trainer* t : {ta, te})
+    if (t->steploss_cap < steps) {
+      HIPCHK(hipStreamSynchronize(st));
+      destroy_graphs(t);
+      if (t->d_steploss) HIPCHK(hipFree(t->d_steploss));
+      HIPCHK(hipMalloc((void**)&t->d_steploss, (size_t)steps * sizeof(float)));
+      t->steploss_cap = steps;
+    }
+  {
+    std::vector<ChainModel> tab = {chain_model(ta), chain_model(te)};
+    tab[0].zcap_layer = j->latent_layer;
+    if (tab.size() != j->h_tab.size() || memcmp(tab.data(), j->h_tab.data(), 2 * sizeof(ChainModel)) != 0) {
+      j->h_tab = tab;
+      HIPCHK(hipMemcpyAsync(j->d_tab, j->h_tab.data(), 2 * sizeof(ChainModel), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  }
+  CHK(chain_attr(ta->prec));
+  const int dsig = ta->mlp->dims[0], dpar = te->mlp->dims[0], dlat = te->mlp->dims[te->mlp->L];
+  for (long long s = 0; s < steps; ++s) {
+    const long long first = s * batch;
+    const int rows = (int)std::min<long long>(batch, n - first);
+    for (v21_trainer* t : {ta, te}) CHK(ensure_copies(t, false));
+    ChainStep sa = chain_step(ta->d_x[0], dsig, nullptr, dsig, ta->d_rw[0], d_idx, first, rows, rows, dsig);
+    ChainStep sb = chain_step(te->d_x[0], dpar, nullptr, dlat, te->d_rw[0], d_idx, first, rows, rows, dlat);
+    sb.y_from_lds = 1;
+    const dim3 grid(((rows + 31) / 32 + 7) / 8 * 8), block(64 * kChainWaves);
+    if (ta->prec == V21_PREC_F16)
+      hipLaunchKernelGGL(train_chain_joint_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+    else
+      hipLaunchKernelGGL(train_chain_joint_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+    HIPCHK(hipGetLastError());
+    int nslice = 1;
+    std::vector<Dw16Args> probs;
+    dw16_problems(ta, rows, rows, &nslice, probs, ta->d_steploss + s);
+    dw16_problems(te, rows, rows, &nslice, probs, te->d_steploss + s);
+    CHK(launch_dw16(ta->prec, probs, st));
+    for (v21_trainer* t : {ta, te}) {
+      t->iter += 1;
+      CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter), true, nslice));  // Adam sums the slabs itself
+      invalidate_streams(t->mlp);
+      t->mlp->wpad_ok = true;
+    }
+  }
+  std::vector<float> h((size_t)steps * 2);
+  HIPCHK(hipMemcpyAsync(h.data(), ta->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(h.data() + steps, te->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int k = 0; k < 2; ++k) {
+    double tot = 0.0;
+    for (long long i = 0; i < steps; ++i) tot += (double)h[(size_t)k * steps + i];
     losses[k] = tot / (double)n;
   }
   return V21_OK;

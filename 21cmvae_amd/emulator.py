@@ -286,10 +286,16 @@ class AutoEncoderEmulator(_EmulatorBase):
         self.autoencoder = autoencoder
         self._chain_model = None
 
-    def train(self, epochs, ae_callbacks=[], em_callbacks=[], verbose="tqdm"):
+    def train(self, epochs, ae_callbacks=[], em_callbacks=[], verbose="tqdm", joint=False):
         """Sequential two-phase recipe of the reference (emulator.py:701-768): fit the
         autoencoder x -> x, encode the signals with the frozen encoder, fit the emulator
-        parameters -> latent.  Returns (ae_loss, ae_val_loss, loss, val_loss)."""
+        parameters -> latent.  Returns (ae_loss, ae_val_loss, loss, val_loss).
+
+        ``joint=True`` (not in the reference; BASELINE configs[2]): both models take one optimizer step
+        per batch on the SAME rows, the emulator's targets being the latents the encoder produces for those
+        rows in that step -- see ``_train_joint``."""
+        if joint:
+            return self._train_joint(epochs, ae_callbacks, em_callbacks, verbose)
         y_train = pp.preproc(self.signal_train, self.signal_train)
         y_val = pp.preproc(self.signal_val, self.signal_train)
         ae_callbacks, em_callbacks = list(ae_callbacks), list(em_callbacks)
@@ -308,6 +314,86 @@ class AutoEncoderEmulator(_EmulatorBase):
                                  validation_data=(X_val, z_val), callbacks=em_callbacks, verbose=verbose)
         self._chain_model = None
         return ae_loss, ae_val_loss, hist.history["loss"], hist.history["val_loss"]
+
+    def _train_joint(self, epochs, ae_callbacks, em_callbacks, verbose, batch_size=256):
+        """One pass over the data trains BOTH models (v21_joint_*): per batch, an autoencoder step (x -> x) and
+        an emulator step (parameters -> the latents the encoder has just produced for these rows; no gradient
+        into the encoder).  The reference's recipe waits for the autoencoder to finish first
+        (emulator.py:739-764); here the emulator tracks the encoder while it still moves, and when the
+        autoencoder's callbacks stop it, it is frozen (learning rate 0) and the remaining epochs ARE the
+        reference's second phase.  Keras bookkeeping per model (History, callbacks, epoch losses, validation
+        after every epoch -- the emulator's against the current encoder's latents of the validation set).
+        Needs precision f16 / bf16 and mean_squared_error on the emulator."""
+        from . import _native as nat, callbacks as cb_mod, engine
+        ae, em = self.autoencoder, self.emulator
+        for m in (ae, em):
+            if m.optimizer is None or m.loss is None:
+                raise RuntimeError("You must compile your model before training: model.compile(optimizer=, loss=)")
+        lat = em.layers[-1].units
+        if not np.array_equal(em._row_weight(np.zeros((2, lat), np.float32)), em._row_weight(np.ones((2, lat), np.float32))):
+            raise ValueError("joint training needs a target-independent emulator loss (mean_squared_error)")
+        y_train = np.ascontiguousarray(pp.preproc(self.signal_train, self.signal_train), dtype=np.float32)
+        y_val = np.ascontiguousarray(pp.preproc(self.signal_val, self.signal_train), dtype=np.float32)
+        X_train = np.ascontiguousarray(pp.par_transform(self.par_train, self.par_train), dtype=np.float32)
+        X_val = np.ascontiguousarray(pp.par_transform(self.par_val, self.par_train), dtype=np.float32)
+        n = y_train.shape[0]
+        ae_callbacks, em_callbacks = list(ae_callbacks), list(em_callbacks)
+        if verbose == "tqdm":
+            ae_callbacks.append(TqdmCallback())
+            em_callbacks.append(TqdmCallback())
+            verbose = 0
+        tra, tre = ae._ensure_trainer(batch_size), em._ensure_trainer(batch_size)
+        tra.set_data(0, y_train, None, ae._row_weight(y_train))
+        tra.set_data(1, y_val, None, ae._row_weight(y_val))
+        zdummy = np.zeros((n, lat), np.float32)
+        tre.set_data(0, X_train, zdummy, em._row_weight(zdummy))
+        joint = nat.Joint(tra, tre, latent_layer=len(ae.encoder.layers) - 1)
+        hists = [cb_mod.History(), cb_mod.History()]
+        params = {"epochs": epochs, "steps": -(-n // batch_size), "verbose": verbose}
+        cbs = [cb_mod.CallbackList([hists[0]] + ae_callbacks, ae, params), cb_mod.CallbackList([hists[1]] + em_callbacks, em, params)]
+        for m in (ae, em):
+            m.stop_training = False
+            m._dirty_host = True
+        for c in cbs:
+            c.on_train_begin()
+        ae_running = em_running = True
+        for epoch in range(epochs):
+            if not em_running and not ae_running:
+                break
+            if ae_running:
+                cbs[0].on_epoch_begin(epoch)
+            if em_running:
+                cbs[1].on_epoch_begin(epoch)
+            tra.set_lr(float(ae.optimizer.lr) if ae_running else 0.0)
+            tre.set_lr(float(em.optimizer.lr))
+            perm = engine._rng.permutation(n).astype(np.int32)
+            if em_running:
+                la, le = joint.run_epoch(perm, batch_size)
+            else:  # the emulator has stopped: the autoencoder goes on alone
+                la, le = tra.run_epoch(perm, batch_size), None
+            ae._dirty_host = em._dirty_host = True
+            if ae_running:
+                logs = {"loss": la, "val_loss": tra.evaluate(1, batch_size)}
+                cbs[0].on_epoch_end(epoch, logs)
+                if ae.stop_training:
+                    ae_running = False  # frozen from here on: the reference's phase 2
+            if em_running:
+                ae._sync_host()
+                z_val = ae.encoder.predict(y_val)
+                tre.set_data(1, X_val, z_val, em._row_weight(z_val))
+                logs = {"loss": le, "val_loss": tre.evaluate(1, batch_size)}
+                cbs[1].on_epoch_end(epoch, logs)
+                if em.stop_training:
+                    em_running = False
+            if verbose in (1, 2):
+                print("Epoch %d/%d - ae loss %.4e - emulator loss %s" % (epoch + 1, epochs, la, "%.4e" % le if le is not None else "-"))
+        for c in cbs:
+            c.on_train_end()
+        ae.optimizer.iterations = tra.get_state()[0]
+        em.optimizer.iterations = tre.get_state()[0]
+        ae._sync_host(); em._sync_host()
+        self._chain_model = None
+        return hists[0].history["loss"], hists[0].history["val_loss"], hists[1].history["loss"], hists[1].history["val_loss"]
 
     def _predict_chain(self):
         blocks = [self.emulator, self.autoencoder.decoder]

@@ -173,6 +173,18 @@ int v21_trainer_set_state(v21_trainer* tr, int64_t iter, const float* m, const f
                           size_t n);
 /* gradient of the last step (after all-reduce), for tests */
 int v21_trainer_get_grad(v21_trainer* tr, float* g, size_t n);
+/* ---- joint step (BASELINE configs[2]).  The reference trains the autoencoder, THEN encodes the
+ * training signals with the finished encoder and trains the latent emulator on those latents
+ * (emulator.py:739-764).  A joint epoch takes one optimizer step of EACH model on the same rows of every
+ * batch; the emulator's targets are the latents the encoder produces for those rows in that step (no
+ * gradient flows back into the encoder).  With the autoencoder's learning rate at 0 it is exactly the
+ * reference's second phase.  `ae` holds the signals (set_data(0, signals, NULL, w)), `em` the parameters of the
+ * same rows (its y argument is ignored); latent_layer = index of the encoder's linear output layer in `ae`'s
+ * stack.  f16 / bf16 trainers (chain kernel), one rank.  losses[0] = autoencoder, losses[1] = emulator. */
+typedef struct v21_joint v21_joint;
+int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_layer, v21_joint** out);
+int v21_joint_destroy(v21_joint* j);
+int v21_joint_run_epoch(v21_joint* j, const int32_t* perm /* nullable */, int batch, double* losses /* [2] */);
 /* Captured-step replay (hipGraph): run_epoch / step_dev capture one optimizer step per
  * batch geometry and replay it; first row, Adam step size and loss slot of each step come from a device
  * table.  Bit-identical to eager launches.  Off by default (the steps are GPU-bound on MI355X: replay frees

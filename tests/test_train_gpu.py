@@ -648,3 +648,129 @@ def test_replayed_steps_follow_data_and_state_changes(ctx):
     with pytest.raises(native.EngineError):
         trv.use_graph(True)
     trv.use_graph(False)
+
+
+# ---- BASELINE configs[2]: latent emulator at full width, and the joint enc + dec + emulator step ----------------
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_latent_emulator_full_width_mse_matches_oracle(ctx, prec):
+    """The reference's second phase at its real size (emulator.py:657-663, :756-764): 7 -> [352, 352, 352, 224]
+    -> 9 trained with mean_squared_error, batch 256 with a partial last batch, against the float64 oracle.
+    f32: per-layer path at the stated f32 tolerance; f16: chain kernel, operand-rounding tolerance."""
+    dims = [7, 352, 352, 352, 224, 9]
+    st, tr, Ws, bs = _make(ctx, dims, seed=12, prec=prec, max_batch=256)
+    rng = np.random.default_rng(3)
+    n, batch = 600, 256   # 256 + 256 + 88
+    x = rng.uniform(-1, 1, size=(n, 7)).astype(np.float32)
+    z = rng.normal(size=(n, 9)).astype(np.float32)
+    w = ora.mse_row_weight(z).astype(np.float32)
+    tr.set_adam(lr=1e-3)
+    tr.set_data(0, x, z, w)
+    sto = ora.AdamState(st.num_params, dtype=np.float64, lr=1e-3)
+    W, b = [a.astype(np.float64) for a in Ws], [a.astype(np.float64) for a in bs]
+    tol_l, tol_w = (2e-5, 2e-4) if prec == "f32" else (3e-3, 3e-2)
+    for ep in range(2):
+        loss = tr.run_epoch(ora.epoch_permutation(n, 5, ep), batch)
+        W, b, hist = ora.fit(W, b, sto, x.astype(np.float64), z.astype(np.float64), w.astype(np.float64), 1, batch, seed=5,
+                             dtype=np.float64, start_epoch=ep)
+        assert abs(loss - hist["loss"][0]) / hist["loss"][0] < tol_l, (ep, loss, hist["loss"][0])
+    # Adam's first steps move every weight by ~lr whatever the gradient's size: compare the MOVEMENT
+    w0 = ora.flatten_params(Ws, bs).astype(np.float64)
+    d_dev, d_ora = st.get_weights().astype(np.float64) - w0, ora.flatten_params(W, b) - w0
+    if prec == "f32":
+        _close(d_dev, d_ora, 5e-3, "weight movement after 2 epochs (f32)")
+    else:
+        cos = float(d_dev @ d_ora / (np.linalg.norm(d_dev) * np.linalg.norm(d_ora)))
+        assert cos > 0.99 and abs(np.linalg.norm(d_dev) / np.linalg.norm(d_ora) - 1) < tol_w, (cos,)
+    assert tr.get_state()[0] == 6
+
+
+def test_joint_step_is_phase_two_when_the_encoder_is_frozen(ctx):
+    """v21_joint_*: with the autoencoder's learning rate at 0 a joint epoch must be the reference's second phase
+    (emulator.py:753-764): the emulator trained on encoder(x) of exactly its batch rows.  Checked against (a) the
+    float64 oracle's fit on the oracle's latents, (b) a separate device trainer fed those latents; the
+    autoencoder must not move and must report the loss it reports alone."""
+    native, synth = pkg("_native"), pkg("synth")
+    n, batch = 300, 128
+    sig = synth.make_signals(n, seed=5)
+    y = ora.preproc(sig, sig)
+    par = rng_par = np.random.default_rng(8).uniform(-1, 1, size=(n, 7)).astype(np.float32)
+    wa = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    ae_dims, ae_act = [451, 48, 9, 24, 451], [1, 0, 1, 0]
+    em_dims, em_act = [7, 40, 9], [1, 0]
+    Wa, ba = ora.init_mlp(ae_dims, seed=31)
+    We, be = ora.init_mlp(em_dims, seed=32)
+    # oracle latents: encoder = the autoencoder's first two layers
+    h = y.astype(np.float64)
+    for W_, b_, a_ in list(zip(Wa, ba, ae_act))[:2]:
+        h = h @ W_.astype(np.float64) + b_.astype(np.float64)
+        h = np.maximum(h, 0) if a_ else h
+    z = h
+    wz = ora.mse_row_weight(z.astype(np.float32)).astype(np.float32)
+
+    def trainer(dims, act, Ws, bs, lr):
+        st = native.Stack(ctx, dims, act)
+        st.set_weights(ora.flatten_params(Ws, bs))
+        tr = native.Trainer(st, "f16", batch)
+        tr.set_adam(lr=lr)
+        return st, tr
+    sta, tra = trainer(ae_dims, ae_act, Wa, ba, 0.0)        # frozen autoencoder
+    ste, tre = trainer(em_dims, em_act, We, be, 2e-3)
+    tra.set_data(0, y, None, wa)
+    tre.set_data(0, par, np.zeros((n, 9), np.float32), wz)
+    joint = native.Joint(tra, tre, latent_layer=1)
+    stx, trx = trainer(em_dims, em_act, We, be, 2e-3)        # (b) the same emulator on precomputed latents
+    trx.set_data(0, par, z.astype(np.float32), wz)
+    sto = ora.AdamState(ste.num_params, dtype=np.float64, lr=2e-3)
+    W, b = [a.astype(np.float64) for a in We], [a.astype(np.float64) for a in be]
+    sta2, tra2 = trainer(ae_dims, ae_act, Wa, ba, 0.0)
+    tra2.set_data(0, y, None, wa)
+    for ep in range(2):
+        perm = ora.epoch_permutation(n, 9, ep)
+        la, le = joint.run_epoch(perm, batch)
+        lx = trx.run_epoch(perm, batch)
+        W, b, hist = ora.fit(W, b, sto, par.astype(np.float64), z, wz.astype(np.float64), 1, batch, seed=9, dtype=np.float64,
+                             start_epoch=ep)
+        assert la == tra2.run_epoch(perm, batch)                      # the autoencoder half is the plain chain step
+        assert abs(le - hist["loss"][0]) / hist["loss"][0] < 5e-3, (ep, le, hist["loss"][0])
+        assert abs(le - lx) / lx < 2e-3, (ep, le, lx)                 # latents from f16 operands vs fp64: tiny shift
+    np.testing.assert_array_equal(sta.get_weights(), ora.flatten_params(Wa, ba))   # lr = 0: untouched
+    w0 = ora.flatten_params(We, be).astype(np.float64)
+    dj, dx, do = (ste.get_weights() - w0), (stx.get_weights() - w0), (ora.flatten_params(W, b) - w0)
+    for d, what in ((dx, "separate trainer"), (do, "oracle")):
+        cos = float(dj @ d / (np.linalg.norm(dj) * np.linalg.norm(d)))
+        assert cos > 0.995 and abs(np.linalg.norm(dj) / np.linalg.norm(d) - 1) < 2e-2, (what, cos)
+    assert tra.get_state()[0] == tre.get_state()[0] == 6
+    # argument checks
+    with pytest.raises(native.EngineError):
+        native.Joint(tra, tre, latent_layer=0)      # a ReLU layer, and 48 wide: not the emulator's output
+    st32 = native.Stack(ctx, em_dims, em_act)
+    with pytest.raises(native.EngineError):
+        native.Joint(tra, native.Trainer(st32, "f32", batch), latent_layer=1)
+
+
+def test_autoencoder_emulator_joint_training_through_the_class_surface(ctx):
+    """AutoEncoderEmulator.train(joint=True): both histories fill, the models learn, early stopping of the
+    autoencoder freezes it and the emulator goes on (the reference's phase 2), predict works afterwards."""
+    synth, emu, optm, cbm = pkg("synth"), pkg("emulator"), pkg("optimizers"), pkg("callbacks")
+    data = synth.make_dataset(1200, 200, 100)
+    pkg("engine").set_random_seed(3)
+    ae = emu.AutoEncoderEmulator(precision="f16", enc_hidden_dims=[64], dec_hidden_dims=[32, 64], em_hidden_dims=[64, 64], **data)
+    ae.autoencoder.compile(optimizer=optm.Adam(2e-3), loss=emu.relative_mse_loss(ae.signal_train))
+    ae.emulator.compile(optimizer=optm.Adam(2e-3), loss=emu.mean_squared_error)
+
+    class StopAt:
+        def __init__(self, k): self.k = k
+        def set_model(self, m): self.model = m
+        def on_epoch_end(self, epoch, logs=None):
+            if epoch + 1 >= self.k: self.model.stop_training = True
+    out = ae.train(epochs=6, ae_callbacks=[StopAt(3)], em_callbacks=[], verbose=0, joint=True)
+    ae_loss, ae_val, em_loss, em_val = out
+    assert len(ae_loss) == len(ae_val) == 3 and len(em_loss) == len(em_val) == 6
+    assert ae_loss[-1] < ae_loss[0]
+    assert em_loss[5] < em_loss[3]  # (while the encoder still moves its latents the target moves too; once frozen, phase 2)
+    assert all(np.isfinite(v) for v in ae_val + em_val)
+    p = ae.predict(data["par_test"][:5])
+    assert p.shape == (5, 451) and np.isfinite(p).all()
+    with pytest.raises(ValueError):   # the emulator's loss must not depend on the targets
+        ae.emulator.compile(optimizer=optm.Adam(1e-3), loss=emu.relative_mse_loss(ae.signal_train))
+        ae.train(epochs=1, verbose=0, joint=True)
