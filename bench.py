@@ -54,28 +54,146 @@ def glorot(dims, seed):
     return np.concatenate(flat)
 
 
-def cpu_baseline(weights_flat, x_f32, budget_s=12.0):
-    """The CPU oracle (numpy fp32 restatement, oracle/ref_numpy.py) on a bounded sample of
-    the same workload: 8,192 of the 65,536 rows per pass, repeated for ~budget_s."""
+def usable_cores():
+    """Cores this process may really use: the scheduler affinity and the cgroup CPU quota, not the host's
+    core count (a 16-core share of a 256-core host runs 256 BLAS / torch threads many times slower than 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def _timed_reps(fn, budget_s, min_reps=2):
+    fn()  # warm-up
+    t0, n = time.perf_counter(), 0
+    while n < min_reps or time.perf_counter() - t0 < budget_s:
+        fn()
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(weights_flat, x_f32, budget_s=6.0):
+    """CPU baselines of BASELINE.md section 3 on BOUNDED samples of the same workloads (about 30 s in all),
+    timed on the GPU box's host cores.  `value` (the contract's figure) is row B2: the CPU oracle (numpy fp32
+    restatement, oracle/ref_numpy.py) on 8,192 of the 65,536 rows per pass, every core.  `rows` adds: the same
+    on ONE core, the Keras-like batch-of-32 predict loop the reference really runs (emulator.py:402 [K]), an
+    independent torch-CPU implementation (B3), and optimizer steps of the autoencoder stack (numpy oracle and
+    torch autograd with Keras' Adam restated) at the reference's batch 256 and at 4,096.  B1 (TensorFlow) is
+    probed and reported absent: it is not installable here."""
     from oracle import ref_numpy as ora
+    from threadpoolctl import threadpool_limits, threadpool_info
     if _BLAS_LIMIT is not None:
         _BLAS_LIMIT.restore_original_limits()  # the baseline gets every host core
+    ncpu = usable_cores()
+    threadpool_limits(limits=ncpu)  # (stays in force: numpy's BLAS pool = the cores this process may use)
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        threads = min(ncpu, max([p.get("num_threads", 1) for p in threadpool_info()] or [1]))
     except Exception:
-        threads = os.cpu_count() or 1
+        threads = ncpu
     Ws, bs = ora.unflatten_params(weights_flat, DIMS)
     rows = 8192
     xs = x_f32[:rows]
-    ora.mlp_forward(Ws, bs, xs, dtype=np.float32)  # warm-up
-    t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s:
-        ora.mlp_forward(Ws, bs, xs, dtype=np.float32)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": rows * n / dt, "unit": "signals/s", "cores": int(threads), "kind": "port",
-            "sample": "%d passes over the first %d rows of the batch, numpy fp32 (BLAS sgemm), %.1f s" % (n, rows, dt)}
+    n, dt = _timed_reps(lambda: ora.mlp_forward(Ws, bs, xs, dtype=np.float32), budget_s)
+    out = {"value": rows * n / dt, "unit": "signals/s", "cores": int(threads), "kind": "port",
+           "sample": "%d passes over the first %d rows of the batch, numpy fp32 (BLAS sgemm), %.1f s" % (n, rows, dt),
+           "host_cpu_count": os.cpu_count(), "usable_cores": ncpu}
+    more = {}
+    with threadpool_limits(limits=1):
+        x1 = xs[:2048]
+        n, dt = _timed_reps(lambda: ora.mlp_forward(Ws, bs, x1, dtype=np.float32), 2.5)
+        more["predict_numpy_1core"] = {"signals_per_s": 2048 * n / dt, "cores": 1, "sample": "%d passes over 2,048 rows" % n}
+
+    def keras_like(xb):  # Model.predict's default batch of 32 rows per call [K]
+        for i in range(0, xb.shape[0], 32):
+            ora.mlp_forward(Ws, bs, xb[i:i + 32], dtype=np.float32)
+    x32 = xs[:2048]
+    n, dt = _timed_reps(lambda: keras_like(x32), 2.5)
+    more["predict_numpy_batch32_loop"] = {"signals_per_s": 2048 * n / dt, "cores": int(threads),
+                                          "sample": "%d passes over 2,048 rows in calls of 32 rows (Keras predict's default)" % n}
+    # autoencoder optimizer steps, numpy oracle (fp32)
+    synth = importlib.import_module("21cmvae_amd.synth")
+    sig = synth.make_signals(4096, seed=2000)
+    yb = ora.preproc(sig, sig).astype(np.float32)
+    wb = ora.relative_mse_row_weight(yb, sig).astype(np.float32)
+    Wa, ba = ora.unflatten_params(glorot(AE_DIMS, seed=4), AE_DIMS)
+    for B, budget in ((256, 2.0), (4096, 3.0)):
+        sta = ora.AdamState(sum(W.size + b.size for W, b in zip(Wa, ba)), dtype=np.float32, lr=1e-3)
+        state = {"W": [W.copy() for W in Wa], "b": [b.copy() for b in ba]}
+
+        def step(B=B, state=state, sta=sta):
+            state["W"], state["b"], _, _ = ora.train_step(state["W"], state["b"], sta, yb[:B], yb[:B], wb[:B], np.float32)
+        n, dt = _timed_reps(step, budget)
+        more["train_step_numpy_b%d" % B] = {"steps_per_s": n / dt, "samples_per_s": n * B / dt, "cores": int(threads),
+                                           "sample": "%d optimizer steps of the autoencoder 451-352-9-32-352-451, relative-MSE, Keras Adam" % n}
+    try:
+        import torch
+        act = [1, 1, 1, 1, 0]
+
+        def tmodel(dims, flat, acts):
+            Wl, bl = ora.unflatten_params(flat, dims)
+            return [torch.tensor(W, requires_grad=True) for W in Wl], [torch.tensor(b, requires_grad=True) for b in bl], acts
+
+        def tforward(Wt, bt, acts, x):
+            h = x
+            for W, b, a in zip(Wt, bt, acts):
+                h = h @ W + b
+                h = torch.relu(h) if a else h
+            return h
+        Wt, bt, _ = tmodel(DIMS, weights_flat, act)
+        xt = torch.from_numpy(np.ascontiguousarray(xs))
+        for nthr, key in ((ncpu, "predict_torch_allcores"), (1, "predict_torch_1core")):
+            torch.set_num_threads(nthr)
+            xx = xt if nthr > 1 else xt[:2048]
+            with torch.no_grad():
+                n, dt = _timed_reps(lambda: tforward(Wt, bt, act, xx), 2.0)
+            more[key] = {"signals_per_s": xx.shape[0] * n / dt, "cores": nthr, "sample": "%d passes over %d rows, torch %s CPU" % (n, xx.shape[0], torch.__version__)}
+        torch.set_num_threads(ncpu)
+        Wt, bt, _ = tmodel(AE_DIMS, glorot(AE_DIMS, seed=4), AE_ACT)
+        prm = Wt + bt
+        ms = [torch.zeros_like(p) for p in prm]; vs = [torch.zeros_like(p) for p in prm]
+        yt, wt = torch.from_numpy(yb), torch.from_numpy(wb)
+        it = [0]
+
+        def tstep(B):
+            pred = tforward(Wt, bt, AE_ACT, yt[:B])
+            loss = (wt[:B] * ((pred - yt[:B]) ** 2).sum(1)).mean()
+            grads = torch.autograd.grad(loss, prm)
+            it[0] += 1
+            t = it[0]
+            alpha = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+            with torch.no_grad():  # Keras Adam: epsilon outside the bias correction [K]
+                for p, g, m, v in zip(prm, grads, ms, vs):
+                    m += (g - m) * 0.1
+                    v += (g * g - v) * 0.001
+                    p -= alpha * m / (v.sqrt() + 1e-7)
+        for B, budget in ((256, 2.0), (4096, 3.0)):
+            n, dt = _timed_reps(lambda B=B: tstep(B), budget)
+            more["train_step_torch_b%d" % B] = {"steps_per_s": n / dt, "samples_per_s": n * B / dt, "cores": ncpu,
+                                               "sample": "%d optimizer steps, torch CPU autograd + restated Keras Adam" % n}
+    except Exception as e:  # pragma: no cover
+        more["torch"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        import tensorflow  # noqa: F401  (B1: the reference's own engine)
+        more["tensorflow"] = "importable (not timed: the reference package itself needs its dataset)"
+    except Exception:
+        more["tensorflow"] = "absent on this box (BASELINE.md row B1 cannot be timed); upstream quotes 40 ms per predict() call (README.rst:11)"
+    out["rows"] = more
+    return out
 
 
 AE_DIMS = [451, 352, 9, 32, 352, 451]   # encoder 451->352->9, decoder 9->32->352->451 (emulator.py:522-524)
@@ -241,26 +359,30 @@ def latency_leg():
     return res
 
 
-def fit_leg(precision, epochs=12):
+def fit_leg(precision, epochs=12, n_train=None, joint=False):
     """Auxiliary metric (BASELINE configs[2]): the reference's whole training recipe through the class
     surface -- AutoEncoderEmulator.train(): autoencoder fit x -> x, encode, latent emulator fit, each
     with a validation pass per epoch -- on a synthetic data set of the reference's size (24,562 / 2,730
-    rows, batch 256).  Wall clock of the call, Python and callbacks included."""
+    rows, batch 256; n_train = 30,000 honours configs[2] literally).  joint=True: both models step on the
+    same rows of every batch (v21_joint_*).  Wall clock of the call, Python and callbacks included."""
     synth = importlib.import_module("21cmvae_amd.synth")
     emu = importlib.import_module("21cmvae_amd.emulator")
     optm = importlib.import_module("21cmvae_amd.optimizers")
-    data = synth.make_dataset()
+    data = synth.make_dataset(n_train) if n_train else synth.make_dataset()
     ae = emu.AutoEncoderEmulator(precision=precision, **data)
     ae.autoencoder.compile(optimizer=optm.Adam(1e-3), loss=emu.relative_mse_loss(ae.signal_train))
     ae.emulator.compile(optimizer=optm.Adam(1e-3), loss=emu.mean_squared_error)
-    ae.train(epochs=1, verbose=0)  # allocations, data upload
+    ae.train(epochs=1, verbose=0, joint=joint)  # allocations, data upload
     t0 = time.perf_counter()
-    out = ae.train(epochs=epochs, verbose=0)
+    out = ae.train(epochs=epochs, verbose=0, joint=joint)
     dt = time.perf_counter() - t0
     steps = 2 * epochs * -(-data["par_train"].shape[0] // 256)
+    err = ae.test_error()
     return {"precision": precision, "epochs": epochs, "rows": int(data["par_train"].shape[0]), "batch": 256,
+            "mode": "joint (enc+dec+emulator step per batch)" if joint else "sequential two-phase (emulator.py:739-764)",
             "optimizer_steps_per_s": steps / dt, "s_per_epoch_both_models": dt / epochs,
-            "final_ae_loss": out[0][-1], "final_emulator_loss": out[2][-1]}
+            "final_ae_loss": out[0][-1], "final_emulator_loss": out[2][-1],
+            "test_error_percent_mean_after_%d_epochs" % (epochs + 1): float(np.mean(err))}
 
 
 def main():
@@ -341,6 +463,15 @@ def main():
         sync_all(); barrier(); sync_all()
         wall = time.perf_counter() - t0
         ev_ms = ctx.elapsed_ms(e0, e1)
+        # per-launch durations of a second, untimed run of the same K launches (an event pair around every launch
+        # costs a few us of host time per step, so it stays out of the timed region): min / median beside the mean
+        evs = [ctx.event() for _ in range(steps + 1)]
+        ctx.record(evs[0])
+        for i in range(steps):
+            stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
+            ctx.record(evs[i + 1])
+        ctx.sync()
+        timed.per_launch_ms = [ctx.elapsed_ms(evs[i], evs[i + 1]) for i in range(steps)]
         if dist is not None:
             t = torch.tensor([wall], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -371,6 +502,11 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved_tf / PEAK_TFLOPS[args.precision], "traffic": None,
                      "kernel": "fused_fwd<ArchS1, Prec%sx2sp>" % args.precision.upper() if args.precision != "f32" else "fused_fwd<ArchS1, PrecF32>",
                      "kernel_ms": kern_s * 1e3,
+                     "kernel_ms_min": float(min(timed.per_launch_ms)), "kernel_ms_median": float(np.median(timed.per_launch_ms)),
+                     "time_base": "HIP events on the launch stream around the K timed launches (mean); min / median from "
+                                  "per-launch event pairs of a second run; profiles/r2/kernel_stats_bench_f16.csv "
+                                  "(rocprofv3 --kernel-trace --stats of this command) must agree with the mean",
+                     "algorithmic_flop_per_launch": FLOP_PER_SIGNAL * B,
                      "hbm_GBps_algorithmic": BYTES_PER_SIGNAL * B / kern_s / 1e9,
                      "hbm_frac_of_8TBps": BYTES_PER_SIGNAL * B / kern_s / 1e9 / PEAK_HBM_GBS},
     }
@@ -378,11 +514,12 @@ def main():
     # HBM traffic per launch of the headline kernel: PMC counters cannot be read from inside the timed
     # process; they were collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) on
     # this same command and are kept under profiles/ (hbm_bytes = 2*FETCH*1024 + WRITE*1024 on gfx950).
-    pmc = os.path.join(ROOT, "profiles", "r1_final", "pmc_fused_%s.json" % args.precision)
+    pmc = os.path.join(ROOT, "profiles", "r2", "pmc_fused_%s.json" % args.precision)
     if os.path.exists(pmc) and B == BATCH:
         try:
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r1_final/pmc_fused_%s.json (rocprofv3 --pmc)" % args.precision
+            out["roofline"]["traffic_source"] = "profiles/r2/pmc_fused_%s.json (rocprofv3 --pmc, kernel %s)" % (
+                args.precision, json.load(open(pmc)).get("_kernel", "?"))
             out["roofline"]["algorithmic_bytes"] = BYTES_PER_SIGNAL * B
         except Exception:
             pass
@@ -464,6 +601,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_train and not args.no_extras:
         try:
             out["fit_reference_recipe"] = [fit_leg("f32"), fit_leg("f16")]
+            out["fit_n30000"] = [fit_leg("f16", n_train=30000), fit_leg("f16", n_train=30000, joint=True)]
         except Exception as e:
             out["fit_reference_recipe"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:

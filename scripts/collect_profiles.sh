@@ -1,0 +1,37 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the GPU box into gpurun_out/<tag>/ (copied to profiles/<tag>/ afterwards).
+#   gpurun -- bash scripts/collect_profiles.sh r2
+# kernel-trace/--stats and --pmc passes are SEPARATE runs; the profiled program comes directly after `--`.
+set -u
+TAG=${1:-r2}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+PY=python3
+# 1. headline kernel: per-kernel stats + the per-dispatch trace (100 warm-up, 100 timed, 100 with per-launch events)
+rocprofv3 --kernel-trace --stats -d $OUT/bench -o b --output-format csv -- $PY $ROOT/bench.py --no-cpu-baseline --no-extras --no-train > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+cp $OUT/bench/b_kernel_stats.csv $OUT/kernel_stats_bench_f16.csv
+$PY $ROOT/scripts/kstats_trace.py $OUT/bench/b_kernel_trace.csv fused_fwd 100 100 > $OUT/kernel_trace_bench_f16_timed_launches.json
+# 2. HBM traffic + MFMA counters of the headline kernel: one --pmc pass per counter group
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --kernel-trace -d $OUT/pmc_$name -o p --output-format csv -- $PY $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-train > /dev/null 2>&1
+done
+$PY $ROOT/scripts/pmc_summary.py fused_fwd $OUT/pmc_*/p_counter_collection.csv > $OUT/pmc_fused_f16.json
+# 3. training steps
+rocprofv3 --kernel-trace --stats -d $OUT/t4096 -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 4096 f16 200 > $OUT/train_probe_b4096_f16.txt 2>&1
+cp $OUT/t4096/t_kernel_stats.csv $OUT/kernel_stats_train_b4096_f16.csv
+rocprofv3 --kernel-trace --stats -d $OUT/t256 -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 256 f32 200 > $OUT/train_probe_b256_f32.txt 2>&1
+cp $OUT/t256/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f32.csv
+rocprofv3 --kernel-trace --stats -d $OUT/t256h -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 256 f16 200 > $OUT/train_probe_b256_f16.txt 2>&1
+cp $OUT/t256h/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f16.csv
+for c in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --pmc $c --kernel-trace -d $OUT/tpmc_$c -o p --output-format csv -- $PY $ROOT/scripts/train_probe.py 4096 f16 30 > /dev/null 2>&1
+done
+$PY $ROOT/scripts/pmc_summary.py "train_chain|gemm_dw16|adam_repack" $OUT/tpmc_*/p_counter_collection.csv > $OUT/pmc_train_b4096_f16.json
+# 4. in-kernel cycle stamps of the SHIPPED headline kernel (diagnostic build: not a benchmark)
+cd $ROOT
+V21_LIB=$ROOT/21cmvae_amd/libv21_stamp.so $PY scripts/diag_stamps.py f16 > $OUT/stamps_fused_f16x2sp_block_tile_cycles.txt 2>&1
+rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t4096 $OUT/t256 $OUT/t256h $OUT/tpmc_*
+ls -la $OUT
