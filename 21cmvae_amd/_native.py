@@ -39,6 +39,14 @@ class AffineOut(C.Structure):
     _fields_ = [("std", C.c_float), ("mean", C.POINTER(C.c_float)), ("n", C.c_int32)]
 
 
+_HOST_AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_size_t)
+
+
+class CommHostOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allreduce_sum_f32", _HOST_AR), ("reduce_scatter_sum_f32", _HOST_AR),
+                ("allgather_f32", _HOST_AR)]
+
+
 class Adam(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
 
@@ -100,8 +108,12 @@ SIGNATURES = {
     "v21_joint_run_epoch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
     "v21_comm_get_unique_id": (C.c_int, [_P, _P]),
     "v21_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "v21_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(CommHostOps)]),
     "v21_comm_destroy": (C.c_int, [_P]),
+    "v21_comm_set_sharded": (C.c_int, [_P, C.c_int]),
     "v21_comm_allreduce_f32": (C.c_int, [_P, _P, C.c_size_t]),
+    "v21_comm_reduce_scatter_f32": (C.c_int, [_P, _P, C.c_size_t]),
+    "v21_comm_allgather_f32": (C.c_int, [_P, _P, C.c_size_t]),
 }
 
 _lib = None
@@ -259,12 +271,43 @@ class Context:
         check(self.lib.v21_comm_get_unique_id(self.h, buf))
         return bytes(buf)
 
+    nranks, rank = 1, 0
+
     def comm_init(self, nranks, rank, uid):
         buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(uid)
         check(self.lib.v21_comm_init(self.h, nranks, rank, buf))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_init_host(self, nranks, rank, allreduce, reduce_scatter, allgather):
+        """Collectives supplied by the host: three callables ``f(array_view, n_or_n_per) -> None`` that work IN
+        PLACE on a float32 numpy view of the library's page-locked staging buffer (see include/v21.h)."""
+        def wrap(fn, per_rank):
+            def cb(_user, ptr, n):
+                try:
+                    total = n * nranks if per_rank else n
+                    fn(np.ctypeslib.as_array(ptr, shape=(total,)), int(n))
+                    return 0
+                except Exception:  # an exception must not unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return _HOST_AR(cb)
+        self._host_ops = CommHostOps(None, wrap(allreduce, False), wrap(reduce_scatter, True), wrap(allgather, True))
+        check(self.lib.v21_comm_init_host(self.h, nranks, rank, C.byref(self._host_ops)))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_set_sharded(self, on=True):
+        check(self.lib.v21_comm_set_sharded(self.h, 1 if on else 0))
 
     def comm_destroy(self):
         check(self.lib.v21_comm_destroy(self.h))
+        self.nranks, self.rank = 1, 0
+
+    def reduce_scatter(self, dptr, n_per):
+        check(self.lib.v21_comm_reduce_scatter_f32(self.h, _P(dptr), n_per))
+
+    def allgather(self, dptr, n_per):
+        check(self.lib.v21_comm_allgather_f32(self.h, _P(dptr), n_per))
 
     def allreduce(self, dptr, n):
         check(self.lib.v21_comm_allreduce_f32(self.h, _P(dptr), n))

@@ -280,12 +280,14 @@ struct AdamArgs {
   // reduce_slabs launch is folded in here; g is rewritten with the sum, same fixed order)
   float* gw; const float* slab; int nslab; long long slab_stride;
   StepCtx sc;  // replayed step: alpha comes from the descriptor
+  long long i0;  // first element this launch works on (sharded data-parallel Adam: a rank's slice of the arena)
+  int no_pack;   // update w, m, v only: the packed copies are rebuilt in a second pass once every rank's slice is back
   AdamLayer lt[16];
 };
 __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha);
 __global__ void adam_repack_kernel(const AdamArgs a) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  const long long i = a.i0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.i0 + a.n) return;
   adam_repack_element(a, i, a.sc.desc ? a.sc.desc[*a.sc.cur].alpha : a.alpha);
 }
 // sweep form: blockIdx.y = model, argument blocks in device memory (one per model)
@@ -313,6 +315,7 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
     wi = wi - (mi * alpha) / (sqrtf(vi) + a.eps);
     a.w[i] = wi;
   }
+  if (a.no_pack) return;
   int l = 0;
   while (l + 1 < a.L && i >= a.lt[l + 1].w_off) ++l;
   const AdamLayer L = a.lt[l];

@@ -55,6 +55,9 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* v21_last_error(void) { return g_err.c_str(); }
 static inline long long p16(int d) { return (d + 15) & ~15; }  // row pitch: whole 16-float groups
+// floats behind the P parameters of an arena: the loss slot, then room to round P + 1 up to whole shards of up to
+// 64 ranks (sharded data-parallel Adam works on nranks * ceil((P + 1) / nranks) elements in place)
+constexpr size_t kArenaPad = 4 + 64;
 extern "C" int v21_version(void) { return 100; }
 extern "C" int v21_device_count(int* n) {
   if (!n) return fail(V21_ERR_ARG, "null n");
@@ -70,6 +73,8 @@ typedef void* nccl_comm;
 typedef int (*fn_GetUniqueId)(nccl_uid*);
 typedef int (*fn_CommInitRank)(nccl_comm*, int, nccl_uid, int);
 typedef int (*fn_AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
+typedef int (*fn_ReduceScatter)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
+typedef int (*fn_AllGather)(const void*, void*, size_t, int, nccl_comm, hipStream_t);
 typedef int (*fn_CommDestroy)(nccl_comm);
 typedef const char* (*fn_GetErrorString)(int);
 struct RcclApi {
@@ -77,6 +82,8 @@ struct RcclApi {
   fn_GetUniqueId GetUniqueId = nullptr;
   fn_CommInitRank CommInitRank = nullptr;
   fn_AllReduce AllReduce = nullptr;
+  fn_ReduceScatter ReduceScatter = nullptr;
+  fn_AllGather AllGather = nullptr;
   fn_CommDestroy CommDestroy = nullptr;
   fn_GetErrorString GetErrorString = nullptr;
 };
@@ -94,9 +101,12 @@ static int load_rccl() {
   g_rccl.GetUniqueId = (fn_GetUniqueId)dlsym(lib, "ncclGetUniqueId");
   g_rccl.CommInitRank = (fn_CommInitRank)dlsym(lib, "ncclCommInitRank");
   g_rccl.AllReduce = (fn_AllReduce)dlsym(lib, "ncclAllReduce");
+  g_rccl.ReduceScatter = (fn_ReduceScatter)dlsym(lib, "ncclReduceScatter");
+  g_rccl.AllGather = (fn_AllGather)dlsym(lib, "ncclAllGather");
   g_rccl.CommDestroy = (fn_CommDestroy)dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (fn_GetErrorString)dlsym(lib, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy || !g_rccl.ReduceScatter ||
+      !g_rccl.AllGather)
     return fail(V21_ERR_COMM, "librccl lacks a required symbol");
   g_rccl.lib = lib;
   return V21_OK;
@@ -111,7 +121,15 @@ struct v21_ctx {
   hipStream_t own = nullptr, stream = nullptr;
   nccl_comm comm = nullptr;
   int nranks = 1, rank = 0;
+  // host-staged collectives (v21_comm_init_host): the same data-parallel logic over any transport the host has
+  bool host_comm = false;
+  v21_comm_host_ops host{};
+  float* h_stage = nullptr;
+  size_t h_stage_n = 0;
+  int sharded = 0;  // 1: reduce-scatter -> Adam on this rank's shard -> all-gather (v21_comm_set_sharded)
 };
+// ncclDataType_t / ncclRedOp_t values of rccl.h (the library is dlopen'ed, its header is not included)
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;
 static int use(v21_ctx* c) {
   if (!c) return fail(V21_ERR_ARG, "null context");
   HIPCHK(hipSetDevice(c->device));
@@ -136,6 +154,7 @@ extern "C" int v21_ctx_destroy(v21_ctx* c) {
   if (!c) return V21_OK;
   hipSetDevice(c->device);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  if (c->h_stage) hipHostFree(c->h_stage);
   if (c->own) { hipStreamSynchronize(c->own); hipStreamDestroy(c->own); }
   delete c;
   return V21_OK;
@@ -281,9 +300,9 @@ extern "C" int v21_mlp_create(v21_ctx* ctx, int n_layers, const int* dims, const
   }
   m->nparams = (size_t)o;
   m->maxdim = *std::max_element(m->dims.begin(), m->dims.end());
-  hipError_t e = hipMalloc((void**)&m->d_w, (m->nparams + 4) * sizeof(float));
+  hipError_t e = hipMalloc((void**)&m->d_w, (m->nparams + kArenaPad) * sizeof(float));
   if (e != hipSuccess) { delete m; return fail(V21_ERR_HIP, "hipMalloc weights: %s", hipGetErrorString(e)); }
-  hipMemsetAsync(m->d_w, 0, (m->nparams + 4) * sizeof(float), ctx->stream);
+  hipMemsetAsync(m->d_w, 0, (m->nparams + kArenaPad) * sizeof(float), ctx->stream);
   for (size_t i = 0; i < sizeof(g_fused) / sizeof(g_fused[0]); ++i) {
     const FusedEntry& fe = g_fused[i];
     if (fe.L != n_layers) continue;
@@ -595,7 +614,7 @@ extern "C" int v21_comm_get_unique_id(v21_ctx* c, void* id) {
 extern "C" int v21_comm_init(v21_ctx* c, int nranks, int rank, const void* id) {
   CHK(use(c));
   if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(V21_ERR_ARG, "bad communicator arguments");
-  if (c->comm) return fail(V21_ERR_STATE, "communicator already initialised");
+  if (c->comm || c->host_comm) return fail(V21_ERR_STATE, "communicator already initialised");
   CHK(load_rccl());
   nccl_uid u;
   memcpy(&u, id, sizeof u);
@@ -605,17 +624,79 @@ extern "C" int v21_comm_init(v21_ctx* c, int nranks, int rank, const void* id) {
   c->rank = rank;
   return V21_OK;
 }
+extern "C" int v21_comm_init_host(v21_ctx* c, int nranks, int rank, const v21_comm_host_ops* ops) {
+  CHK(use(c));
+  if (!ops || !ops->allreduce_sum_f32 || !ops->reduce_scatter_sum_f32 || !ops->allgather_f32 || nranks < 1 || rank < 0 ||
+      rank >= nranks)
+    return fail(V21_ERR_ARG, "bad communicator arguments");
+  if (c->comm || c->host_comm) return fail(V21_ERR_STATE, "communicator already initialised");
+  c->host = *ops;
+  c->host_comm = true;
+  c->nranks = nranks;
+  c->rank = rank;
+  return V21_OK;
+}
 extern "C" int v21_comm_destroy(v21_ctx* c) {
   CHK(use(c));
   if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
-  c->nranks = 1; c->rank = 0;
+  c->host_comm = false;
+  c->nranks = 1; c->rank = 0; c->sharded = 0;
+  return V21_OK;
+}
+extern "C" int v21_comm_set_sharded(v21_ctx* c, int on) {
+  if (!c) return fail(V21_ERR_ARG, "null context");
+  c->sharded = on ? 1 : 0;
+  return V21_OK;
+}
+static int host_stage(v21_ctx* c, size_t n) {
+  if (c->h_stage_n >= n) return V21_OK;
+  if (c->h_stage) HIPCHK(hipHostFree(c->h_stage));
+  HIPCHK(hipHostMalloc((void**)&c->h_stage, n * sizeof(float), hipHostMallocDefault));
+  c->h_stage_n = n;
+  return V21_OK;
+}
+// device buffer -> page-locked host copy -> callback -> back (the stream is drained on both sides: the callback
+// blocks in the host's transport)
+template <class F>
+static int host_collective(v21_ctx* c, float* d_buf, size_t n, F&& call, const char* what) {
+  CHK(host_stage(c, n));
+  HIPCHK(hipMemcpyAsync(c->h_stage, d_buf, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int r = call(c->h_stage);
+  if (r != 0) return fail(V21_ERR_COMM, "host %s callback returned %d", what, r);
+  HIPCHK(hipMemcpyAsync(d_buf, c->h_stage, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return V21_OK;
 }
 extern "C" int v21_comm_allreduce_f32(v21_ctx* c, float* d_buf, size_t n) {
   CHK(use(c));
-  if (!c->comm) return V21_OK;  // single rank: identity
-  int r = g_rccl.AllReduce(d_buf, d_buf, n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->comm, c->stream);
+  if (c->nranks <= 1) return V21_OK;  // single rank: identity
+  if (c->host_comm)
+    return host_collective(c, d_buf, n, [&](float* h) { return c->host.allreduce_sum_f32(c->host.user, h, n); }, "all-reduce");
+  int r = g_rccl.AllReduce(d_buf, d_buf, n, kNcclFloat32, kNcclSum, c->comm, c->stream);
   if (r != 0) return fail(V21_ERR_COMM, "ncclAllReduce: %s", rccl_err(r));
+  return V21_OK;
+}
+// in place over nranks * n_per floats: rank r ends up with the sums of elements [r n_per, (r+1) n_per) there
+extern "C" int v21_comm_reduce_scatter_f32(v21_ctx* c, float* d_buf, size_t n_per) {
+  CHK(use(c));
+  if (c->nranks <= 1) return V21_OK;
+  if (c->host_comm)
+    return host_collective(c, d_buf, n_per * c->nranks,
+                           [&](float* h) { return c->host.reduce_scatter_sum_f32(c->host.user, h, n_per); }, "reduce-scatter");
+  int r = g_rccl.ReduceScatter(d_buf, d_buf + (size_t)c->rank * n_per, n_per, kNcclFloat32, kNcclSum, c->comm, c->stream);
+  if (r != 0) return fail(V21_ERR_COMM, "ncclReduceScatter: %s", rccl_err(r));
+  return V21_OK;
+}
+// in place over nranks * n_per floats: every rank contributes elements [r n_per, (r+1) n_per) and receives all
+extern "C" int v21_comm_allgather_f32(v21_ctx* c, float* d_buf, size_t n_per) {
+  CHK(use(c));
+  if (c->nranks <= 1) return V21_OK;
+  if (c->host_comm)
+    return host_collective(c, d_buf, n_per * c->nranks, [&](float* h) { return c->host.allgather_f32(c->host.user, h, n_per); },
+                           "all-gather");
+  int r = g_rccl.AllGather(d_buf + (size_t)c->rank * n_per, d_buf, n_per, kNcclFloat32, c->comm, c->stream);
+  if (r != 0) return fail(V21_ERR_COMM, "ncclAllGather: %s", rccl_err(r));
   return V21_OK;
 }
 
@@ -714,9 +795,9 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
   for (int l = 0; l < L; ++l)
     if (m->act[l] == V21_ACT_GAUSS) t->gl = l;
   if (t->gl == L - 1) { delete t; return fail(V21_ERR_UNSUPPORTED, "a V21_ACT_GAUSS layer cannot be the last layer of a trained stack"); }
-  CHK(zalloc(&t->d_g, t->P + 4, st));
-  CHK(zalloc(&t->d_m, t->P + 4, st));
-  CHK(zalloc(&t->d_v, t->P + 4, st));
+  CHK(zalloc(&t->d_g, t->P + kArenaPad, st));
+  CHK(zalloc(&t->d_m, t->P + kArenaPad, st));
+  CHK(zalloc(&t->d_v, t->P + kArenaPad, st));
   t->Bp = ((long long)max_batch + 31) / 32 * 32 + 32;
   t->d_h.assign(L + 1, nullptr); t->d_ht.assign(L + 1, nullptr);
   t->d_dz.assign(L + 1, nullptr); t->d_dzt.assign(L + 1, nullptr);
@@ -1017,6 +1098,46 @@ static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_n
   a.sc = step_ctx(t);
   return a;
 }
+// The end of every eager optimizer step: gradients (and the loss numerator in slot P) summed over the ranks, Adam,
+// refreshed weight copies.  Two data-parallel forms:
+//   all-reduce:  every rank receives the whole summed arena and applies the identical Adam update;
+//   sharded   :  reduce-scatter -> each rank updates ONLY its 1/R slice of (w, m, v) -> all-gather of the
+//                updated weights -> every rank rebuilds its packed copies.  Same bytes on the wire, 1/R of the
+//                Adam traffic, and on the full xGMI mesh both halves are direct exchanges.  The loss numerator
+//                rides in slot P: summed by the reduce-scatter, it is copied into the weight arena's first pad
+//                float by its owner, so that the all-gather hands it to everyone.
+// `fold` > 1 (single rank): Adam sums that many split-K slabs itself.
+static int reduce_and_update(v21_trainer* t, bool chain_copies, int fold) {
+  v21_ctx* c = t->ctx;
+  hipStream_t st = c->stream;
+  const size_t P = t->P;
+  if (c->nranks > 1 && c->sharded) {
+    const int R = c->nranks;
+    const size_t S = (P + 1 + R - 1) / R;  // elements per rank (the last ranks' tails are padding)
+    if (R > 64) return fail(V21_ERR_UNSUPPORTED, "sharded Adam: at most 64 ranks");
+    if (S * R > P + 1) HIPCHK(hipMemsetAsync(t->d_g + P + 1, 0, (S * R - P - 1) * sizeof(float), st));
+    CHK(v21_comm_reduce_scatter_f32(c, t->d_g, S));
+    t->iter += 1;
+    const size_t lo = std::min(P, (size_t)c->rank * S), hi = std::min(P, lo + S);
+    if (hi > lo) {
+      AdamArgs a = adam_args(t, true, adam_alpha(t->adam, t->iter), chain_copies);
+      a.i0 = (long long)lo; a.n = (long long)(hi - lo); a.no_pack = 1;
+      hipLaunchKernelGGL(adam_repack_kernel, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, st, a);
+      HIPCHK(hipGetLastError());
+    }
+    float* w = t->mlp->d_w;
+    if (P / S == (size_t)c->rank) HIPCHK(hipMemcpyAsync(w + P, t->d_g + P, sizeof(float), hipMemcpyDeviceToDevice, st));
+    CHK(v21_comm_allgather_f32(c, w, S));
+    HIPCHK(hipMemcpyAsync(t->d_g + P, w + P, sizeof(float), hipMemcpyDeviceToDevice, st));  // the loss slot, on every rank
+    CHK(adam_and_copies(t, false, 0.f, chain_copies));  // packed copies from the gathered arena
+    return V21_OK;
+  }
+  CHK(v21_comm_allreduce_f32(c, t->d_g, P + 1));
+  t->iter += 1;
+  CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter), chain_copies, fold));
+  return V21_OK;
+}
+
 // need_nt: the caller reads the fp32 copies (per-layer forward/backward); chain steps do not
 static int ensure_copies(v21_trainer* t, bool need_nt = true) {
   // the arena may have been rewritten behind our back (set_weights): wpad_ok doubles as the dirty flag
@@ -1139,9 +1260,7 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
     CHK(adam_and_copies(t, true, 0.f));
     return V21_OK;
   }
-  CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
-  t->iter += 1;
-  CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter)));
+  CHK(reduce_and_update(t, false, 1));
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
   invalidate_streams(m);
   m->wpad_ok = true;  // ... but our own copies were just refreshed
@@ -1331,9 +1450,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     CHK(adam_and_copies(t, true, 0.f, true, fold));
     return V21_OK;
   }
-  CHK(v21_comm_allreduce_f32(t->ctx, t->d_g, t->P + 1));
-  t->iter += 1;
-  CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter), true, fold));
+  CHK(reduce_and_update(t, true, fold));
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
   invalidate_streams(m);
   m->wpad_ok = true;
@@ -1587,6 +1704,11 @@ extern "C" int v21_trainer_get_state(v21_trainer* t, int64_t* iter, float* mm, f
   CHK(use(t->ctx));
   if (iter) *iter = t->iter;
   if ((mm || vv) && n != t->P) return fail(V21_ERR_ARG, "state size %zu != %zu", n, t->P);
+  if ((mm || vv) && t->ctx->nranks > 1 && t->ctx->sharded) {  // each rank holds its slice of the moments: a collective call
+    const size_t S = (t->P + 1 + t->ctx->nranks - 1) / t->ctx->nranks;
+    CHK(v21_comm_allgather_f32(t->ctx, t->d_m, S));
+    CHK(v21_comm_allgather_f32(t->ctx, t->d_v, S));
+  }
   if (mm) HIPCHK(hipMemcpyAsync(mm, t->d_m, n * sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
   if (vv) HIPCHK(hipMemcpyAsync(vv, t->d_v, n * sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
   HIPCHK(hipStreamSynchronize(t->ctx->stream));

@@ -154,7 +154,7 @@ class _EmulatorBase:
             setattr(self, k, v)
         self.par_labels = list(_EmulatorBase.par_labels)
 
-    def _predict_stack(self, model, params):
+    def _predict_stack(self, model, params, devices=None):
         """par_transform -> device stack -> unpreproc, squeezing a single row
         (emulator.py:401-407 / :788-795).  The parameter transform is done on the host in
         float64 exactly as the reference does; the un-preprocessing is fused into the
@@ -166,7 +166,7 @@ class _EmulatorBase:
             st.set_output_transform(ss.std, ss.mean)
             st._out_stats = ss
         from . import _native as nat
-        pred = st.forward(x, model.precision, flags=nat.FWD_OUT_TRANSFORM)
+        pred = model.predict(x, devices=devices, flags=nat.FWD_OUT_TRANSFORM)
         return pred[0, :] if pred.shape[0] == 1 else pred
 
     def save(self):
@@ -208,9 +208,10 @@ class DirectEmulator(_EmulatorBase):
                                  callbacks=callbacks, verbose=verbose)
         return hist.history["loss"], hist.history["val_loss"]
 
-    def predict(self, params):
-        """Global signal(s) for one parameter vector (-> 1-D) or an (N, 7) array (-> (N, 451))."""
-        return self._predict_stack(self.emulator, params)
+    def predict(self, params, devices=None):
+        """Global signal(s) for one parameter vector (-> 1-D) or an (N, 7) array (-> (N, 451)).
+        ``devices`` (not in the reference): GPU ordinals to spread the rows over."""
+        return self._predict_stack(self.emulator, params, devices)
 
     def test_error(self, relative=True, flow=None, fhigh=None):
         return error(self.signal_test, self.predict(self.par_test), relative=relative,
@@ -404,10 +405,10 @@ class AutoEncoderEmulator(_EmulatorBase):
         cm.precision = self.emulator.precision
         return cm
 
-    def predict(self, params):
+    def predict(self, params, devices=None):
         """emulator.predict then decoder.predict then unpreproc (emulator.py:788-795),
         evaluated as ONE fused device stack 7 -> ... -> 9 -> 32 -> 352 -> 451."""
-        return self._predict_stack(self._predict_chain(), params)
+        return self._predict_stack(self._predict_chain(), params, devices)
 
     def test_error(self, use_autoencoder=False, relative=True, flow=None, fhigh=None):
         if use_autoencoder:

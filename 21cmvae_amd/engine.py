@@ -230,16 +230,47 @@ class Model:
             self._stack = None
 
     # -- inference -----------------------------------------------------------------
-    def predict(self, x, batch_size=None, verbose=0, precision=None, **_):
+    def predict(self, x, batch_size=None, verbose=0, precision=None, devices=None, flags=0, **_):
         """numpy (n, in) -> numpy float32 (n, out).  float64 input is cast to float32 on
         the way in, as Keras does [K]; rows are independent, so ``batch_size`` is
-        accepted and ignored."""
+        accepted and ignored.  ``devices`` (not in the reference): a list of GPU ordinals
+        -- the rows are cut into contiguous blocks, one per entry, evaluated concurrently on
+        replicas of the stack (weights copied once per change) and put back in order; no
+        collective is involved."""
         x = np.asarray(x)
         if x.ndim == 1:
             x = x[None, :]
         if not self.built:
             self.build((None, x.shape[-1]))
-        return self._ensure_stack().forward(x, precision or self.precision)
+        st = self._ensure_stack()
+        if not devices or len(devices) == 1 and int(devices[0]) == st.ctx.device:
+            return st.forward(x, precision or self.precision, flags=flags)
+        return self._predict_on_devices(st, x, precision or self.precision, [int(d) for d in devices], flags)
+
+    def _predict_on_devices(self, st, x, precision, devices, flags):
+        from concurrent.futures import ThreadPoolExecutor
+        reps = self.__dict__.setdefault("_replicas", {})
+        sig = (id(st), self._stack_sig, id(getattr(st, "_out_stats", None)))
+        flat = None
+        stacks = []
+        for slot, d in enumerate(devices):  # one replica per LIST ENTRY (an ordinal may appear twice)
+            key = (slot, d)
+            ent = reps.get(key)
+            if ent is None or ent[0] != sig or self._dirty_host:
+                if flat is None:
+                    flat = st.get_weights()
+                rs = ent[1] if ent is not None and ent[1].dims == st.dims else _native.Stack(_native.Context(d), st.dims, st.act)
+                rs.set_weights(flat)
+                if getattr(st, "_out_stats", None) is not None:
+                    rs.set_output_transform(st._out_stats.std, st._out_stats.mean)
+                reps[key] = ent = (sig, rs)
+            stacks.append(ent[1])
+        n = x.shape[0]
+        cuts = [n * i // len(devices) for i in range(len(devices) + 1)]
+        with ThreadPoolExecutor(max_workers=len(devices)) as pool:  # ctypes releases the GIL during the calls
+            parts = list(pool.map(lambda a: a[0].forward(x[a[1]:a[2]], precision, flags=flags),
+                                  [(s_, cuts[i], cuts[i + 1]) for i, s_ in enumerate(stacks)]))
+        return np.concatenate(parts, axis=0)
 
     def __call__(self, x, training=False):
         return self.predict(np.asarray(x))
@@ -302,6 +333,19 @@ class Model:
             yv = np.ascontiguousarray(validation_data[1], dtype=np.float32)
             same_v = yv.shape == xv.shape and np.array_equal(xv, yv)
             tr.set_data(1, xv, None if same_v else yv, self._row_weight(yv))
+        dp = tr.ctx.nranks > 1
+        if dp:
+            # Data parallel (parallel.init_engine_comm on this context): every rank holds the whole training set and
+            # trains on its share of each global batch, so the replicas must START equal and SHUFFLE alike --
+            # rank 0's weights, optimizer state and, per epoch, permutation are broadcast over the process group.
+            from . import parallel
+            flat = parallel.broadcast_array(self._stack.get_weights())
+            self._stack.set_weights(flat)
+            it, mm, vv = tr.get_state()
+            tr.set_state(int(parallel.broadcast_array(np.array([it], np.int64))[0]), parallel.broadcast_array(mm),
+                         parallel.broadcast_array(vv))
+            if getattr(self, "_vae_seed", None) is not None:
+                self._vae_seed = int(parallel.broadcast_array(np.array([self._vae_seed], np.uint64))[0])
         history = cb_mod.History()
         cbs = cb_mod.CallbackList([history] + list(callbacks or []), self,
                                   {"epochs": epochs, "steps": -(-n // batch_size), "verbose": verbose})
@@ -314,6 +358,8 @@ class Model:
             if getattr(self, "_vae_seed", None) is not None:  # a callback may anneal kl_weight between epochs
                 tr.set_vae(self.kl_weight, self.sample_latent, self._vae_seed)
             perm = _rng.permutation(n).astype(np.int32) if shuffle else None
+            if dp and perm is not None:
+                perm = parallel.broadcast_array(perm)
             logs = {"loss": tr.run_epoch(perm, batch_size)}
             self._dirty_host = True
             if validation_data is not None:

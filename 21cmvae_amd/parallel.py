@@ -46,16 +46,62 @@ def broadcast_bytes(payload, nbytes, src=0, device=None):
     return bytes(buf.cpu().tolist())
 
 
-def init_engine_comm(ctx):
-    """Create the in-library RCCL communicator on `ctx` for the current process group."""
+def init_engine_comm(ctx, backend="auto", sharded=False):
+    """Attach a data-parallel communicator to `ctx` for the current torch.distributed process group.
+
+    backend "rccl": the in-library RCCL communicator (unique id broadcast over the process group) -- what a
+    one-process-per-GPU run uses.  "host": the library's host-staged transport driven by the process group's own
+    collectives (gloo in the CPU/1-GPU tests).  "auto": RCCL when the process group is nccl, else host.
+    sharded: reduce-scatter -> Adam on this rank's slice -> all-gather instead of one all-reduce."""
     from . import _native
     dist = _dist()
     world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return
-    uid = ctx.comm_unique_id() if rank == 0 else b""
-    uid = broadcast_bytes(uid, _native.COMM_ID_BYTES)
-    ctx.comm_init(world, rank, uid)
+    if backend == "auto":
+        backend = "rccl" if dist.get_backend() == "nccl" else "host"
+    if backend == "rccl":
+        uid = ctx.comm_unique_id() if rank == 0 else b""
+        uid = broadcast_bytes(uid, _native.COMM_ID_BYTES)
+        ctx.comm_init(world, rank, uid)
+    else:
+        import torch
+
+        def allreduce(buf, n):
+            dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM)
+
+        def reduce_scatter(buf, n_per):  # gloo has no reduce_scatter: sum everything, keep the semantics in place
+            dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM)
+
+        def allgather(buf, n_per):
+            t = torch.from_numpy(buf)
+            parts = [torch.empty(n_per, dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(parts, t[rank * n_per:(rank + 1) * n_per].clone())
+            for r, part in enumerate(parts):
+                t[r * n_per:(r + 1) * n_per] = part
+        ctx.comm_init_host(world, rank, allreduce, reduce_scatter, allgather)
+    ctx.comm_set_sharded(sharded)
+
+
+def broadcast_array(arr, src=0):
+    """Every rank returns rank `src`'s copy of the numpy array (same shape and dtype everywhere)."""
+    import torch
+    dist = _dist()
+    a = np.ascontiguousarray(arr)
+    t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy().view(a.dtype).reshape(a.shape)
+
+
+def in_group():
+    """True inside an initialised torch.distributed process group of more than one rank."""
+    try:
+        dist = _dist()
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:
+        return False
 
 
 def allreduce_flat(arr):

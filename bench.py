@@ -575,6 +575,13 @@ def main():
                 tl = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
                                args.train_batch, args.precision, args.train_steps, 5)
                 out["train"] = tl
+                if world > 1:  # the other exchange: reduce-scatter -> Adam on each rank's slice -> all-gather
+                    ctx.comm_set_sharded(True)
+                    ts = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
+                                   args.train_batch, args.precision, args.train_steps, 5)
+                    ts["collective"] = "RCCL reduce-scatter + all-gather, Adam on 1/%d of the arena per rank" % world
+                    out["train_sharded_adam"] = ts
+                    ctx.comm_set_sharded(False)
                 if world == 1 and not args.no_extras:
                     out["train_ref_batch256_f32"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
                                                               sync_all, 256, "f32", 200, 10)

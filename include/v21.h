@@ -219,13 +219,33 @@ int v21_sweep_destroy(v21_sweep* sw); /* the trainers stay alive */
 /* one Keras-style epoch of every model (same shuffle, same batches); losses[count] */
 int v21_sweep_run_epoch(v21_sweep* sw, const int32_t* perm, int batch, double* losses);
 
-/* ---- data-parallel communicator (new: the reference is single-process).  RCCL is
- * loaded at run time (librccl.so.1) so a single-GPU user needs no RCCL. --------- */
+/* ---- data-parallel communicator (new: the reference is single-process, emulator.py:369,739,756).  One
+ * process per GPU; every rank trains on its contiguous share of each global batch and the gradients are summed
+ * before Adam.  Two transports behind the same step logic:
+ *   v21_comm_init       RCCL inside the library (librccl.so.1 is dlopen'ed, so a single-GPU user needs none):
+ *                       ncclAllReduce, or ncclReduceScatter + ncclAllGather in sharded mode, on the context stream.
+ *   v21_comm_init_host  collectives supplied by the host as callbacks on page-locked HOST buffers (the library
+ *                       stages device -> host -> device around them): any transport the host has -- the test
+ *                       suite runs two ranks on one GPU over torch.distributed/gloo through it.
+ * v21_comm_set_sharded(1): reduce-scatter of the gradient arena -> each rank applies Adam to its 1/R slice of
+ * (w, m, v) only -> all-gather of the updated weights; 0 (default): one all-reduce, identical
+ * Adam on every rank.  In sharded mode v21_trainer_get_state is a collective call (it gathers m and v). -------- */
 #define V21_COMM_ID_BYTES 128
+typedef struct v21_comm_host_ops {
+  void* user;
+  /* all blocking, 0 = ok; buffers are host memory of nranks * n_per (or n) floats, results in place */
+  int (*allreduce_sum_f32)(void* user, float* buf, size_t n);
+  int (*reduce_scatter_sum_f32)(void* user, float* buf, size_t n_per); /* rank r: sums of [r n_per, (r+1) n_per) there */
+  int (*allgather_f32)(void* user, float* buf, size_t n_per);          /* rank r contributes [r n_per, (r+1) n_per) */
+} v21_comm_host_ops;
 int v21_comm_get_unique_id(v21_ctx* ctx, void* id /* V21_COMM_ID_BYTES */);
 int v21_comm_init(v21_ctx* ctx, int nranks, int rank, const void* id);
+int v21_comm_init_host(v21_ctx* ctx, int nranks, int rank, const v21_comm_host_ops* ops);
 int v21_comm_destroy(v21_ctx* ctx);
-int v21_comm_allreduce_f32(v21_ctx* ctx, float* d_buf, size_t n); /* sum, in place */
+int v21_comm_set_sharded(v21_ctx* ctx, int on);
+int v21_comm_allreduce_f32(v21_ctx* ctx, float* d_buf, size_t n);           /* sum, in place */
+int v21_comm_reduce_scatter_f32(v21_ctx* ctx, float* d_buf, size_t n_per);  /* in place over nranks * n_per floats */
+int v21_comm_allgather_f32(v21_ctx* ctx, float* d_buf, size_t n_per);       /* in place over nranks * n_per floats */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,134 @@
+"""The library's data-parallel path with MORE THAN ONE RANK: two processes, each with its own context on the one
+GPU of the test box, a gloo process group, and the library's host-staged collective transport
+(v21_comm_init_host).  Everything except the RCCL calls themselves is the production path: per-rank sharding of
+every global batch in v21_trainer_run_epoch, the 1/B_global scaling, the loss numerator riding in the gradient
+arena, all-reduce + replicated Adam or reduce-scatter + sharded Adam + all-gather, and engine.Model.fit's
+broadcast of weights / optimizer state / shuffle.  No multi-rank RCCL run has happened on hardware (the driver's
+8-GPU node is the first)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp  # noqa: E402
+
+DIMS, ACT = [451, 48, 9, 24, 451], ["relu", None, "relu", None]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _data():
+    synth = pkg("synth")
+    sig = synth.make_signals(300, seed=4)
+    sv = synth.make_signals(60, seed=5)
+    pp = pkg("preprocess")
+    return pp.preproc(sig, sig).astype(np.float32), pp.preproc(sv, sig).astype(np.float32), sig
+
+
+def _fit(prec, seed, world=1, rank=0, sharded=False, port=0):
+    import importlib
+    sys.path.insert(0, ROOT)
+    eng = importlib.import_module("21cmvae_amd.engine")
+    native = importlib.import_module("21cmvae_amd._native")
+    losses = importlib.import_module("21cmvae_amd.losses")
+    optm = importlib.import_module("21cmvae_amd.optimizers")
+    y, yv, sig = _data()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        importlib.import_module("21cmvae_amd.parallel").init_engine_comm(native.Context.default(), backend="host", sharded=sharded)
+    eng.set_random_seed(seed)  # different on every rank: rank 0's weights and shuffles must win
+    m = eng.Sequential([eng.Input((451,))] + [eng.Dense(u, a) for u, a in zip(DIMS[1:], ACT)])
+    m.precision = prec
+    m.compile(optimizer=optm.Adam(2e-3), loss=losses.relative_mse_loss(sig))
+    h = m.fit(y, y, batch_size=128, epochs=3, validation_data=(yv, yv), verbose=0)   # 128 + 128 + 44 rows per epoch
+    out = (np.concatenate([a.ravel() for a in m.get_weights()]), h.history["loss"], h.history["val_loss"],
+           m._trainer.get_state())
+    if world > 1:
+        import torch.distributed as dist
+        native.Context.default().comm_destroy()
+        dist.destroy_process_group()
+    return out
+
+
+def _worker(rank, world, port, prec, sharded, q):
+    try:
+        q.put((rank, _fit(prec, seed=100 + rank, world=world, rank=rank, sharded=sharded, port=port)))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+
+
+@pytest.mark.parametrize("prec,sharded", [("f32", False), ("f32", True), ("f16", True)])
+def test_two_ranks_on_one_gpu_equal_one_process(prec, sharded):
+    world, port = 2, _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, prec, sharded, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, out in res:
+        assert not isinstance(out, str), out
+    (w0, l0, v0, s0), (w1, l1, v1, s1) = res[0][1], res[1][1]
+    np.testing.assert_array_equal(w0, w1)                      # the replicas end identical ...
+    assert l0 == l1 and v0 == v1                               # ... and saw the same losses (callbacks decide alike)
+    assert s0[0] == s1[0] == 9
+    np.testing.assert_array_equal(s0[1], s1[1])                # gathered Adam moments
+    ws, ls, vs, ss = _fit(prec, seed=100)                      # one process, rank 0's seed
+    tol = 2e-5 if prec == "f32" else 2e-3                      # the split batch sums in another order (and in f16 operands)
+    assert max(abs(a - b) / b for a, b in zip(l0, ls)) < tol, (l0, ls)
+    assert max(abs(a - b) / b for a, b in zip(v0, vs)) < tol
+    d1, ds = w0 - _init_weights(), ws - _init_weights()
+    cos = float(d1 @ ds / (np.linalg.norm(d1) * np.linalg.norm(ds)))
+    assert cos > (0.99999 if prec == "f32" else 0.999), cos
+    np.testing.assert_allclose(s0[1], ss[1], rtol=0, atol=(1e-5 if prec == "f32" else 2e-3) * np.abs(ss[1]).max())
+
+
+def _init_weights():
+    eng = pkg("engine")
+    eng.set_random_seed(100)
+    m = eng.Sequential([eng.Input((451,))] + [eng.Dense(u, a) for u, a in zip(DIMS[1:], ACT)])
+    return np.concatenate([a.ravel() for a in m.get_weights()])
+
+
+def test_collectives_single_rank_identity(ctx):
+    """One rank: every collective of the C ABI is the identity, sharded mode included (what a 1-GPU run of the
+    data-parallel bench leg exercises)."""
+    buf = np.arange(40, dtype=np.float32)
+    d = ctx.malloc(buf.nbytes)
+    ctx.h2d(d, buf)
+    ctx.allreduce(d, 40); ctx.reduce_scatter(d, 40); ctx.allgather(d, 40)
+    out = np.empty_like(buf)
+    ctx.d2h(out, d)
+    np.testing.assert_array_equal(out, buf)
+    ctx.free(d)
+
+
+def test_predict_on_several_devices_equals_one(ctx):
+    """predict(devices=[...]): rows cut into blocks, one replica per list entry, evaluated concurrently, put back
+    in order -- bit-identical to the single-stack result (two replicas on the one GPU of the test box)."""
+    synth, emu = pkg("synth"), pkg("emulator")
+    data = synth.make_dataset(600, 80, 50)
+    em = emu.DirectEmulator(hidden_dims=[64, 96], **data)
+    par = synth.make_params(1001, seed=9)
+    one = em.predict(par)
+    two = em.predict(par, devices=[0, 0])
+    np.testing.assert_array_equal(one, two)
+    three = em.predict(par[:7], devices=[0, 0, 0])
+    np.testing.assert_array_equal(one[:7], three)
+    em.emulator.set_weights([w * 1.5 for w in em.emulator.get_weights()])   # replicas must follow weight changes
+    np.testing.assert_array_equal(em.predict(par), em.predict(par, devices=[0, 0]))
+    assert not np.array_equal(one, em.predict(par, devices=[0, 0]))
