@@ -327,6 +327,9 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
 #pragma unroll
         for (int j = 0; j < 4; ++j) wb[j] = p[j * 64];
       }
+      // (without the fence hipcc hoists the first MFMA -- and with it the wait for the CURRENT chunk -- above these
+      // loads: the next chunk would leave only after this one has landed, and the prefetch distance collapses)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bn[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 1) + j) * 16);
 #pragma unroll
@@ -336,6 +339,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
 #pragma unroll
         for (int j = 0; j < 4; ++j) wa[j] = p[j * 64];
       }
+      __builtin_amdgcn_sched_barrier(0);
       if (c + 2 < nch) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bc[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 2) + j) * 16);
@@ -346,6 +350,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     if (c < nch) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) wb[j] = nxt.w[j * 64];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = P::template mfma<false>(wa[j], bc[j], acc);
       return true;
