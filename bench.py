@@ -337,25 +337,29 @@ def accuracy_leg(native, ctx):
 
 def latency_leg():
     """Auxiliary metric: what a sampler sees -- DirectEmulator.predict() on ONE parameter vector through
-    the class surface (numpy in, numpy out; host transform, PCIe both ways, synchronisation included).
-    The reference quotes 40 ms per call (README.rst:11)."""
+    the class surface (numpy in, numpy out; host transform, PCIe both ways, synchronisation included), with a
+    training set of the reference's size (24,562 rows).  The reference quotes 40 ms per call (README.rst:11) and
+    recomputes the training-set statistics on every call; by default this package re-hashes the training
+    arrays on every call instead (exactness against in-place edits: ~6 ms for 44 MB), and `freeze_data=True`
+    (private read-only copies) removes that cost."""
     synth = importlib.import_module("21cmvae_amd.synth")
     emu = importlib.import_module("21cmvae_amd.emulator")
-    data = synth.make_dataset(4000, 400, 400)
+    data = synth.make_dataset(synth.N_TRAIN, 400, 400)
     res = {}
-    for prec in ("f32", "f16"):
-        em = emu.DirectEmulator(hidden_dims=DIMS[1:-1], precision=prec, **data)
+    for key, prec, freeze, reps in (("f32_freeze_data", "f32", True, 200), ("f16_freeze_data", "f16", True, 200),
+                                    ("f32_default_rehash", "f32", False, 10)):
+        em = emu.DirectEmulator(hidden_dims=DIMS[1:-1], precision=prec, freeze_data=freeze, **data)
         p1 = data["par_test"][0]
-        for _ in range(20):
+        for _ in range(5):
             em.predict(p1)
         lat = []
         for _ in range(5):
             t0 = time.perf_counter()
-            for _ in range(200):
+            for _ in range(reps):
                 em.predict(p1)
-            lat.append((time.perf_counter() - t0) / 200 * 1e6)
-        res[prec] = {"us_per_call_median": float(np.median(lat)), "us_per_call_min": float(min(lat))}
-    res["note"] = "f32 (default): small-batch path, one launch per layer; f16: fused one-launch kernel"
+            lat.append((time.perf_counter() - t0) / reps * 1e6)
+        res[key] = {"us_per_call_median": float(np.median(lat)), "us_per_call_min": float(min(lat))}
+    res["note"] = "f32 (default precision): small-batch path, one launch per layer; f16: fused one-launch kernel"
     return res
 
 
