@@ -290,11 +290,16 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // per lane): two transposed LDS reads and ONE fully coalesced 16-byte-per-lane store per fragment.
   // Rows past the end of the batch are written as zeros; features >= F are left alone (feature K of
   // an input operand is the constant row of ones).
-  auto flush_t = [&](const elem* act, int F, void* dst) __attribute__((always_inline)) {
+  // `tiles`: tile count of the contraction that follows.  The waves WITHOUT a tile in it do the flush while the
+  // others already stream their weights (measured: done by everyone at the head of the layer it cost 6.3 k
+  // cycles of the 67 k; `act` does not change during the layer, so there is no ordering to keep).
+  auto flush_t = [&](const elem* act, int F, void* dst, int tiles) __attribute__((always_inline)) {
     const int nfrag = 2 * ((F + 31) >> 5);
     frag* d = reinterpret_cast<frag*>(dst);
     const int g = lane >> 4, i = lane & 15;
-    for (int id = wave; id < nfrag; id += NW) {
+    const int w0 = tiles < NW ? tiles : 0;  // waves [0, w0) have a tile (every wave has one: all of them flush)
+    if (wave < w0) return;
+    for (int id = wave - w0; id < nfrag; id += NW - w0) {
       const int ft = id >> 1, q2 = id & 1;
       const int r0 = 16 * q2 + 8 * (g >> 1);
       const elem* p = act + (r0 + (i >> 2)) * PITCH + 32 * ft + 16 * (g & 1) + 4 * (i & 3);
@@ -371,7 +376,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
     const int nch = ly.KS >> 2;
-    flush_t(act, ly.K, ly.ht16);  // this layer's input -> operand of its weight gradient
+    flush_t(act, ly.K, ly.ht16, ly.NT);  // this layer's input -> operand of its weight gradient
     const float wi = rwl[li];
     for (int t = wave; t < ly.NT; t += NW) {
       const int n0 = 32 * t;
@@ -508,7 +513,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     elem* out = buf[cur ^ 1];
     const int nch = ly.NS >> 2;
     if (ly.gauss) { gauss_backward(buf[cur], ly.N >> 1, ly.NS * 16); chain_barrier(); }
-    flush_t(act, ly.N, ly.dzt16);  // gs * dZ of this layer's output -> operand of its weight gradient
+    flush_t(act, ly.N, ly.dzt16, ly.KT);  // gs * dZ of this layer's output -> operand of its weight gradient
     for (int t = wave; t < ly.KT; t += NW) {
       const int k0 = 32 * t;
       f32x16 acc;
@@ -541,7 +546,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
   if (a.lt[0].gauss) { gauss_backward(buf[cur], a.lt[0].N >> 1, a.lt[0].NS * 16); chain_barrier(); }
-  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16);
+  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
 }
 
 // ---- weight gradients from the fragment-ordered operands: [dW; db](k, n) = sum_b HT(k, b) dZT(n, b).
