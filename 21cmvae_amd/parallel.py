@@ -51,7 +51,7 @@ def init_engine_comm(ctx, backend="auto", sharded=False):
 
     backend "rccl": the in-library RCCL communicator (unique id broadcast over the process group) -- what a
     one-process-per-GPU run uses.  "host": the library's host-staged transport driven by the process group's own
-    collectives (gloo in the CPU/1-GPU tests).  "auto": RCCL when the process group is nccl, else host.
+    collectives (gloo in the CPU/1-GPU tests; under an nccl group the buffer is staged through a device tensor).  "auto": RCCL when the process group is nccl, else host.
     sharded: reduce-scatter -> Adam on this rank's slice -> all-gather instead of one all-reduce."""
     from . import _native
     dist = _dist()
@@ -66,19 +66,27 @@ def init_engine_comm(ctx, backend="auto", sharded=False):
         ctx.comm_init(world, rank, uid)
     else:
         import torch
+        on_gpu = dist.get_backend() == "nccl"  # the group's tensors live on the device: stage the host buffer through it
+
+        def _t(buf):
+            t = torch.from_numpy(buf)
+            return t.cuda() if on_gpu else t
 
         def allreduce(buf, n):
-            dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM)
+            t = _t(buf)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if on_gpu:
+                torch.from_numpy(buf).copy_(t)
 
-        def reduce_scatter(buf, n_per):  # gloo has no reduce_scatter: sum everything, keep the semantics in place
-            dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM)
+        reduce_scatter = allreduce  # gloo has no reduce_scatter: sum everything, the slices hold what they must
 
         def allgather(buf, n_per):
-            t = torch.from_numpy(buf)
-            parts = [torch.empty(n_per, dtype=torch.float32) for _ in range(world)]
+            t = _t(buf)
+            parts = [torch.empty(n_per, dtype=torch.float32, device=t.device) for _ in range(world)]
             dist.all_gather(parts, t[rank * n_per:(rank + 1) * n_per].clone())
+            out = torch.from_numpy(buf)
             for r, part in enumerate(parts):
-                t[r * n_per:(r + 1) * n_per] = part
+                out[r * n_per:(r + 1) * n_per] = part.cpu() if on_gpu else part
         ctx.comm_init_host(world, rank, allreduce, reduce_scatter, allgather)
     ctx.comm_set_sharded(sharded)
 

@@ -54,6 +54,11 @@ def glorot(dims, seed):
     return np.concatenate(flat)
 
 
+def _pg_device(dist):
+    """Where the tensors of the contract's max-over-ranks / sums live: the GPU under nccl (= RCCL), the host under gloo."""
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
 def usable_cores():
     """Cores this process may really use: the scheduler affinity and the cgroup CPU quota, not the host's
     core count (a 16-core share of a 256-core host runs 256 BLAS / torch threads many times slower than 16)."""
@@ -235,7 +240,7 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
     sync_all(); barrier(); sync_all()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=_pg_device(dist))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     loss = tr.last_step_loss() / (batch * world)
@@ -246,7 +251,7 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
             "model": ("variational " if variational else "") + "autoencoder 451-352-9-32-352-451, relative-MSE" +
                      (" + 1e-3 KL" if variational else "") + ", Adam", "steps": steps,
             "achieved_TFLOPs": sps * batch * world * AE_FLOP_PER_SAMPLE / 1e12, "final_batch_loss": loss,
-            "collective": "RCCL all-reduce of the flat gradient arena (%d floats)" % (st.num_params + 1) if world > 1 else "none"}
+            "collective": "all-reduce of the flat gradient arena (%d floats)" % (st.num_params + 1) if world > 1 else "none"}
 
 
 SWEEP_CONFIGS = [  # (latent, encoder hidden, decoder hidden): widths multiples of 32 in [32, 512] (SURVEY 8d cfg 5)
@@ -421,8 +426,15 @@ def main():
         if torch is None:
             raise SystemExit("multi-GPU bench needs torch.distributed")
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # Rehearsal switch (never set by the driver): V21_BENCH_REHEARSAL=1 runs the ranks of an N > 1 launch on
+        # ONE GPU over gloo + the library's host-staged transport, so that everything but the RCCL calls of the
+        # multi-GPU code path can be exercised on a one-GPU box.  The line says so in "config".
+        if os.environ.get("V21_BENCH_REHEARSAL") == "1":
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     native = importlib.import_module("21cmvae_amd._native")
     synth = importlib.import_module("21cmvae_amd.synth")
@@ -477,7 +489,7 @@ def main():
         ctx.sync()
         timed.per_launch_ms = [ctx.elapsed_ms(evs[i], evs[i + 1]) for i in range(steps)]
         if dist is not None:
-            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall], dtype=torch.float64, device=_pg_device(dist))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         return wall, ev_ms
@@ -515,6 +527,8 @@ def main():
                      "hbm_frac_of_8TBps": BYTES_PER_SIGNAL * B / kern_s / 1e9 / PEAK_HBM_GBS},
     }
 
+    if os.environ.get("V21_BENCH_REHEARSAL") == "1" and world > 1:
+        out["config"]["rehearsal"] = "%d ranks on ONE GPU over gloo + host-staged collectives: a code-path check, not a measurement" % world
     # HBM traffic per launch of the headline kernel: PMC counters cannot be read from inside the timed
     # process; they were collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) on
     # this same command and are kept under profiles/ (hbm_bytes = 2*FETCH*1024 + WRITE*1024 on gfx950).
@@ -567,23 +581,32 @@ def main():
         except Exception as e:
             out["sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if dist is not None:  # every rank takes part, whether its own leg failed or not
-            t = torch.tensor([out["sweep"].get("model_steps_per_s_grouped", 0.0)], dtype=torch.float64, device="cuda")
+            t = torch.tensor([out["sweep"].get("model_steps_per_s_grouped", 0.0)], dtype=torch.float64, device=_pg_device(dist))
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             out["sweep"]["model_steps_per_s_grouped_all_ranks"] = float(t.item())
 
     if not args.no_train:
         def run_train():
             try:
+                transport = "none"
                 if world > 1:
-                    importlib.import_module("21cmvae_amd.parallel").init_engine_comm(ctx)
+                    par = importlib.import_module("21cmvae_amd.parallel")
+                    transport = "RCCL (in-library)" if dist.get_backend() == "nccl" else "host-staged over gloo"
+                    try:
+                        par.init_engine_comm(ctx)
+                    except Exception as e:  # the in-library communicator did not come up: say so, use the process group's
+                        transport = "host-staged over the process group (in-library RCCL failed: %s)" % e
+                        par.init_engine_comm(ctx, backend="host")
                 tl = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
                                args.train_batch, args.precision, args.train_steps, 5)
+                tl["transport"] = transport
                 out["train"] = tl
                 if world > 1:  # the other exchange: reduce-scatter -> Adam on each rank's slice -> all-gather
                     ctx.comm_set_sharded(True)
                     ts = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
                                    args.train_batch, args.precision, args.train_steps, 5)
-                    ts["collective"] = "RCCL reduce-scatter + all-gather, Adam on 1/%d of the arena per rank" % world
+                    ts["collective"] = "reduce-scatter + all-gather, Adam on 1/%d of the arena per rank" % world
+                    ts["transport"] = transport
                     out["train_sharded_adam"] = ts
                     ctx.comm_set_sharded(False)
                 if world == 1 and not args.no_extras:
