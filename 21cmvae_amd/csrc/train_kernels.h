@@ -284,25 +284,29 @@ struct AdamArgs {
   int no_pack;   // update w, m, v only: the packed copies are rebuilt in a second pass once every rank's slice is back
   AdamLayer lt[16];
 };
-__device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha);
-__global__ void adam_repack_kernel(const AdamArgs a) {
-  const long long i = a.i0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.i0 + a.n) return;
-  adam_repack_element(a, i, a.sc.desc ? a.sc.desc[*a.sc.cur].alpha : a.alpha);
+// The layer an arena element belongs to: every block of 256 consecutive elements lies in ONE layer except the few
+// that straddle a boundary, so the block looks its layer up once with scalar compares (uniform index -> the layer
+// record comes through scalar loads) and only a straddling block falls back to the per-lane search (a chain of
+// dependent vector loads from the argument block).
+__device__ __forceinline__ int adam_layer_of(const AdamArgs& a, long long i) {
+  int l = 0;
+  for (int j = 1; j < a.L; ++j) l += i >= a.lt[j].w_off ? 1 : 0;
+  return l;
 }
-// sweep form: blockIdx.y = model, argument blocks in device memory (one per model)
-struct AlphaGroup { float a[kSweepMax]; };
-__global__ void adam_repack_group_kernel(const AdamArgs* __restrict__ tab, const AlphaGroup alpha) {
-  const AdamArgs& a = tab[blockIdx.y];
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  adam_repack_element(a, i, alpha.a[blockIdx.y]);
-}
-__device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha) {
+// one arena element: summed gradient -> (m, v, w); returns the new weight
+__device__ __forceinline__ float adam_update_element(const AdamArgs& a, long long i, float alpha) {
   float wi = a.w[i];
   if (a.do_adam) {
     float gi;
-    if (a.nslab > 1) {
+    if (a.nslab == 8) {  // the usual split: eight independent loads, summed in the same fixed order as the loop below
+      float sl[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sl[k] = a.slab[k * a.slab_stride + i];
+      gi = sl[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) gi += sl[k];
+      a.gw[i] = gi;
+    } else if (a.nslab > 1) {
       gi = a.slab[i];
       for (int k = 1; k < a.nslab; ++k) gi += a.slab[k * a.slab_stride + i];
       a.gw[i] = gi;
@@ -315,13 +319,20 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
     wi = wi - (mi * alpha) / (sqrtf(vi) + a.eps);
     a.w[i] = wi;
   }
+  return wi;
+}
+__device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha, const AdamLayer& L) {
+  const float wi = adam_update_element(a, i, alpha);
   if (a.no_pack) return;
-  int l = 0;
-  while (l + 1 < a.L && i >= a.lt[l + 1].w_off) ++l;
-  const AdamLayer L = a.lt[l];
   const long long r = i - L.w_off;
   if (r < (long long)L.K * L.N) {  // a kernel element (biases have no copies)
-    const int k = (int)(r / L.N), n = (int)(r % L.N);
+    int k, n;
+    if ((long long)L.K * L.N < (1ll << 32)) {  // (uniform) 32-bit division: a 64-bit one is ~150 instructions
+      const unsigned ru = (unsigned)r, Nu = (unsigned)L.N, q = ru / Nu;
+      k = (int)q; n = (int)(ru - q * Nu);
+    } else {
+      k = (int)(r / L.N); n = (int)(r % L.N);
+    }
     if (!a.skip_nt) {
       a.wt[L.wt_off + (long long)n * L.ldwt + k] = wi;
       a.wp[L.wp_off + (long long)k * L.ldwp + n] = wi;
@@ -340,6 +351,24 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
       }
     }
   }
+}
+__device__ __forceinline__ void adam_repack_block(const AdamArgs& a, long long b0, long long end, float alpha) {
+  const long long i = b0 + threadIdx.x;
+  const long long last = b0 + blockDim.x - 1 < end - 1 ? b0 + blockDim.x - 1 : end - 1;
+  const int l0 = adam_layer_of(a, b0), l1 = adam_layer_of(a, last);  // scalar
+  if (i >= end) return;
+  if (l0 == l1) adam_repack_element(a, i, alpha, a.lt[l0]);
+  else adam_repack_element(a, i, alpha, a.lt[adam_layer_of(a, i)]);
+}
+__global__ void adam_repack_kernel(const AdamArgs a) {
+  adam_repack_block(a, a.i0 + (long long)blockIdx.x * blockDim.x, a.i0 + a.n, a.sc.desc ? a.sc.desc[*a.sc.cur].alpha : a.alpha);
+}
+// sweep form: blockIdx.y = model, argument blocks in device memory (one per model)
+struct AlphaGroup { float a[kSweepMax]; };
+__global__ void adam_repack_group_kernel(const AdamArgs* __restrict__ tab, const AlphaGroup alpha) {
+  const AdamArgs& a = tab[blockIdx.y];
+  if ((long long)blockIdx.x * blockDim.x >= a.n) return;
+  adam_repack_block(a, (long long)blockIdx.x * blockDim.x, a.n, alpha.a[blockIdx.y]);
 }
 
 // fp32 W^T copies (rows = outputs, pitch p16(K)) of the small-batch forward path: one thread per arena element

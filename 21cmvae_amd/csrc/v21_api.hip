@@ -1919,7 +1919,7 @@ static int sweep_step(v21_sweep* s, const float* yb, long long ldy, int rows, in
 static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long long step_index) {
   v21_trainer* t0 = s->tr[0];
   hipStream_t st = s->ctx->stream;
-  const int G = (int)s->tr.size(), L = t0->mlp->L, dout = t0->mlp->dims[L], rows = cs.rows;
+  const int G = (int)s->tr.size(), rows = cs.rows;
   if (rows > t0->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t0->max_batch);
   if (rows > 0) {
     for (v21_trainer* t : s->tr) CHK(ensure_copies(t, false));
