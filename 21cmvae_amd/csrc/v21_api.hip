@@ -24,6 +24,7 @@
 #include "gemm_nt.h"
 #include "train_kernels.h"
 #include "train_chain.h"
+#include "dw_adam.h"
 
 using namespace v21;
 
@@ -1414,6 +1415,88 @@ static int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t
   return V21_OK;
 }
 
+// ---- single rank: weight gradients + Adam + packed copies in ONE launch (dw_adam.h)
+static void dw_adam_model(v21_trainer* t, DwAdamModel& md) {
+  v21_mlp* m = t->mlp;
+  memset(&md, 0, sizeof(md));  // (the device tables are compared bytewise: padding included)
+  md.L = m->L;
+  md.omb1 = 1.0f - t->adam.beta1; md.omb2 = 1.0f - t->adam.beta2; md.eps = t->adam.eps;
+  md.cprec = t->prec == V21_PREC_F16 ? 1 : 2;
+  int nb = 0;
+  for (int l = 0; l < m->L; ++l) {
+    DwAdamLayer& d = md.lt[l];
+    d.A = t->d_ht16[l]; d.B = t->d_dzt16[l + 1]; d.BS = t->BS;
+    d.w = m->d_w + m->w_off[l]; d.m = t->d_m + m->w_off[l]; d.v = t->d_v + m->w_off[l]; d.g = t->d_g + m->w_off[l];
+    d.fw = t->d_fw; d.bw = t->d_bw; d.fw_off = t->fw_off[l]; d.bw_off = t->bw_off[l];
+    d.K = m->dims[l]; d.N = m->nw(l);
+    d.KS = chain_steps(d.K); d.NS = chain_steps(d.N);
+    d.nt = (d.N + 31) / 32;
+    d.first = nb;
+    nb += ((d.K + 1 + 31) / 32) * d.nt;
+    if (l == 0) {
+      d.loss_acc = (unsigned long long*)t->d_ticket; d.loss_out = t->d_g + t->P;
+      d.loss_out2 = t->d_steploss;  // (may be null: then no step asks for a slot)
+    }
+  }
+  md.nblk = nb;
+}
+static int launch_dw_adam(v21_trainer* t, int rows, int brows, float alpha) {
+  DwAdamModel md;
+  dw_adam_model(t, md);
+  DwAdamStep st{};
+  st.steps = (rows + 15) / 16;
+  st.slot = -1;
+  st.alpha[0] = alpha;
+  st.out_scale[0] = 1.0f / grad_opscale(brows, t->mlp->dims[t->mlp->L]);
+  st.sc = step_ctx(t);
+  const dim3 grid((md.nblk + 7) / 8 * 8);
+  if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(dw16_adam_kernel<PrecF16>, grid, dim3(64 * kDwAdamWaves), 0, t->ctx->stream, md, st);
+  else hipLaunchKernelGGL(dw16_adam_kernel<PrecBF16>, grid, dim3(64 * kDwAdamWaves), 0, t->ctx->stream, md, st);
+  HIPCHK(hipGetLastError());
+  t->copies_ok = true;
+  t->nt_ok = false;
+  return V21_OK;
+}
+
+// group form (sweep, joint step): per-model blocks in a device table, refreshed when anything in them changed
+static int refresh_dw_adam_table(const std::vector<v21_trainer*>& tr, DwAdamModel** d_tab, std::vector<DwAdamModel>& h_tab,
+                                 hipStream_t st) {
+  std::vector<DwAdamModel> tab(tr.size());
+  for (size_t k = 0; k < tr.size(); ++k) dw_adam_model(tr[k], tab[k]);
+  if (!*d_tab) HIPCHK(hipMalloc((void**)d_tab, tab.size() * sizeof(DwAdamModel)));
+  if (tab.size() != h_tab.size() || memcmp(tab.data(), h_tab.data(), tab.size() * sizeof(DwAdamModel)) != 0) {
+    h_tab = tab;
+    HIPCHK(hipMemcpyAsync(*d_tab, h_tab.data(), tab.size() * sizeof(DwAdamModel), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return V21_OK;
+}
+// every model takes one Adam step (iter advanced here) on the operands its chain launch left; slot: see DwAdamStep
+static int launch_dw_adam_group(const std::vector<v21_trainer*>& tr, const DwAdamModel* d_tab,
+                                const std::vector<DwAdamModel>& h_tab, int rows, int brows, long long slot, hipStream_t st) {
+  DwAdamStep stp{};
+  stp.steps = (rows + 15) / 16;
+  stp.slot = (int)slot;
+  int maxblk = 0;
+  for (size_t k = 0; k < tr.size(); ++k) {
+    v21_trainer* t = tr[k];
+    t->iter += 1;
+    stp.alpha[k] = adam_alpha(t->adam, t->iter);
+    stp.out_scale[k] = 1.0f / grad_opscale(brows, t->mlp->dims[t->mlp->L]);
+    maxblk = std::max(maxblk, h_tab[k].nblk);
+  }
+  const dim3 grid((maxblk + 7) / 8 * 8, (unsigned)tr.size());
+  if (tr[0]->prec == V21_PREC_F16) hipLaunchKernelGGL(dw16_adam_group_kernel<PrecF16>, grid, dim3(64 * kDwAdamWaves), 0, st, d_tab, stp);
+  else hipLaunchKernelGGL(dw16_adam_group_kernel<PrecBF16>, grid, dim3(64 * kDwAdamWaves), 0, st, d_tab, stp);
+  HIPCHK(hipGetLastError());
+  for (v21_trainer* t : tr) {
+    t->copies_ok = true; t->nt_ok = false;
+    invalidate_streams(t->mlp);
+    t->mlp->wpad_ok = true;
+  }
+  return V21_OK;
+}
+
 static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out,
                         long long row0);
 // one optimizer step on rows [first, first+rows) (through d_idx when given) of (x, y, rw)
@@ -1432,6 +1515,15 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   if (rows > 0) {
     CHK(ensure_copies(t, false));
     CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
+    if (t->ctx->nranks == 1) {  // nothing to exchange: gradients, Adam and the packed copies in one launch
+      if (!t->capturing) t->iter += 1;
+      CHK(launch_dw_adam(t, rows, brows, t->capturing ? 0.f : adam_alpha(t->adam, t->iter)));
+      if (t->capturing) return V21_OK;
+      if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+      invalidate_streams(m);
+      m->wpad_ok = true;
+      return V21_OK;
+    }
     int nslice = 1;
     std::vector<Dw16Args> probs;
     dw16_problems(t, rows, brows, &nslice, probs);  // every weight gradient in one launch: [dW; db] = [H^T; 1^T] dZ
@@ -1750,6 +1842,8 @@ struct v21_sweep {
   bool chain = false;            // every member runs the chain kernel: one grouped launch of it per step
   ChainModel* d_chain = nullptr;
   std::vector<ChainModel> h_chain;
+  DwAdamModel* d_dwadam = nullptr;  // single rank: gradients + Adam in one grouped launch (dw_adam.h)
+  std::vector<DwAdamModel> h_dwadam;
 };
 
 extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** out) {
@@ -1791,6 +1885,7 @@ extern "C" int v21_sweep_destroy(v21_sweep* s) {
   hipStreamSynchronize(s->ctx->stream);
   hipFree(s->d_adam);
   if (s->d_chain) hipFree(s->d_chain);
+  if (s->d_dwadam) hipFree(s->d_dwadam);
   delete s;
   return V21_OK;
 }
@@ -1930,6 +2025,8 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long l
     else
       hipLaunchKernelGGL(train_chain_group_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, cs);
     HIPCHK(hipGetLastError());
+    if (s->ctx->nranks == 1)  // nothing to exchange: all gradients, all Adam updates, all packed copies in one launch
+      return launch_dw_adam_group(s->tr, s->d_dwadam, s->h_dwadam, rows, brows, step_index, st);
     int nslice = 1;
     std::vector<Dw16Args> probs;
     for (v21_trainer* t : s->tr)
@@ -2013,6 +2110,7 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
       HIPCHK(hipMemcpyAsync(s->d_chain, s->h_chain.data(), tab.size() * sizeof(ChainModel), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
     }
+    if (R == 1) CHK(refresh_dw_adam_table(s->tr, &s->d_dwadam, s->h_dwadam, st));
   }
   for (long long sidx = 0; sidx < steps; ++sidx) {
     const long long first = sidx * batch;
@@ -2057,6 +2155,8 @@ struct v21_joint {
   int latent_layer = 0;
   ChainModel* d_tab = nullptr;
   std::vector<ChainModel> h_tab;
+  DwAdamModel* d_dwadam = nullptr;  // gradients + Adam of both models in one grouped launch (dw_adam.h)
+  std::vector<DwAdamModel> h_dwadam;
 };
 extern "C" int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_layer, v21_joint** out) {
   if (!ae || !em || !out) return fail(V21_ERR_ARG, "null argument");
@@ -2085,6 +2185,7 @@ extern "C" int v21_joint_destroy(v21_joint* j) {
   hipSetDevice(j->ae->ctx->device);
   hipStreamSynchronize(j->ae->ctx->stream);
   hipFree(j->d_tab);
+  if (j->d_dwadam) hipFree(j->d_dwadam);
   delete j;
   return V21_OK;
 }
@@ -2129,6 +2230,7 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
       HIPCHK(hipStreamSynchronize(st));
     }
   }
+  CHK(refresh_dw_adam_table({ta, te}, &j->d_dwadam, j->h_dwadam, st));
   CHK(chain_attr(ta->prec));
   const int dsig = ta->mlp->dims[0], dpar = te->mlp->dims[0], dlat = te->mlp->dims[te->mlp->L];
   for (long long s = 0; s < steps; ++s) {
@@ -2144,17 +2246,7 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
     else
       hipLaunchKernelGGL(train_chain_joint_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
     HIPCHK(hipGetLastError());
-    int nslice = 1;
-    std::vector<Dw16Args> probs;
-    dw16_problems(ta, rows, rows, &nslice, probs, ta->d_steploss + s);
-    dw16_problems(te, rows, rows, &nslice, probs, te->d_steploss + s);
-    CHK(launch_dw16(ta->prec, probs, st));
-    for (v21_trainer* t : {ta, te}) {
-      t->iter += 1;
-      CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter), true, nslice));  // Adam sums the slabs itself
-      invalidate_streams(t->mlp);
-      t->mlp->wpad_ok = true;
-    }
+    CHK(launch_dw_adam_group({ta, te}, j->d_dwadam, j->h_dwadam, rows, rows, s, st));
   }
   std::vector<float> h((size_t)steps * 2);
   HIPCHK(hipMemcpyAsync(h.data(), ta->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
