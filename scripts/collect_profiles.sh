@@ -29,7 +29,10 @@ cp $OUT/t256h/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f16.csv
 for c in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $c --kernel-trace -d $OUT/tpmc_$c -o p --output-format csv -- $PY $ROOT/scripts/train_probe.py 4096 f16 30 > /dev/null 2>&1
 done
-$PY $ROOT/scripts/pmc_summary.py "train_chain|gemm_dw16|adam_repack" $OUT/tpmc_*/p_counter_collection.csv > $OUT/pmc_train_b4096_f16.json
+$PY $ROOT/scripts/pmc_summary.py "train_chain|gemm_dw16|adam_repack|dw16_adam" $OUT/tpmc_*/p_counter_collection.csv > $OUT/pmc_train_b4096_f16.json
+# 3b. is the headline kernel clock-bound?  the same launches on random and on all-zero operands
+cd $ROOT
+$PY scripts/power_probe.py > $OUT/power_probe_fused_random_vs_zero_operands.txt 2>&1
 # 4. in-kernel cycle stamps of the SHIPPED headline kernel (diagnostic build: not a benchmark)
 cd $ROOT
 V21_LIB=$ROOT/21cmvae_amd/libv21_stamp.so $PY scripts/diag_stamps.py f16 > $OUT/stamps_fused_f16x2sp_block_tile_cycles.txt 2>&1
