@@ -796,6 +796,10 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
   for (int l = 0; l < L; ++l)
     if (m->act[l] == V21_ACT_GAUSS) t->gl = l;
   if (t->gl == L - 1) { delete t; return fail(V21_ERR_UNSUPPORTED, "a V21_ACT_GAUSS layer cannot be the last layer of a trained stack"); }
+  if (m->act[L - 1] != V21_ACT_LINEAR) {  // (the loss gradient is taken w.r.t. the Dense output: no output non-linearity is differentiated)
+    delete t;
+    return fail(V21_ERR_UNSUPPORTED, "the output layer of a trained stack must be linear (the reference's output Dense has no activation, emulator.py:44)");
+  }
   CHK(zalloc(&t->d_g, t->P + kArenaPad, st));
   CHK(zalloc(&t->d_m, t->P + kArenaPad, st));
   CHK(zalloc(&t->d_v, t->P + kArenaPad, st));

@@ -146,6 +146,8 @@ typedef struct {
   float lr, beta1, beta2, eps; /* Keras Adam: 1e-3, 0.9, 0.999, 1e-7 */
 } v21_adam;
 
+/* The stack's output layer must be linear (V21_ERR_UNSUPPORTED otherwise): the reference's output Dense has no
+ * activation (emulator.py:44), and the loss gradient is taken with respect to the Dense output. */
 int v21_trainer_create(v21_mlp* mlp, int precision, int max_batch, v21_trainer** out);
 int v21_trainer_destroy(v21_trainer* tr);
 int v21_trainer_set_adam(v21_trainer* tr, const v21_adam* cfg);

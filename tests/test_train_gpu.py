@@ -186,6 +186,9 @@ def test_trainer_argument_errors(ctx):
         tr.run_epoch(None, 64)  # exceeds max_batch
     with pytest.raises(native.EngineError):
         tr.set_data(0, x, None, w)  # y = x needs in_dim == out_dim
+    for prec in ("f32", "f16"):  # an output non-linearity would not be differentiated: refused, not mis-trained
+        with pytest.raises(native.EngineError, match="output layer"):
+            native.Trainer(native.Stack(ctx, [7, 8, 3], [1, 1]), prec, 16)
 
 
 def test_rccl_single_rank_communicator_is_identity():
@@ -480,6 +483,55 @@ def test_chain_kernel_odd_shapes(ctx, dims, act, n):
     assert abs(lc - lo) / lo < 3e-3, (lc, lo)
     assert _cos(gc, go) > 0.9995, _cos(gc, go)
     assert abs(np.linalg.norm(gc) / np.linalg.norm(go) - 1) < 5e-3
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("dims,act,n", [
+    ([64, 32, 96, 64], [1, 1, 0], 48),      # K = 64: exactly ceil(K/16) k-steps, the bias row opens a tile of its own
+    ([128, 9, 40, 128], [0, 1, 0], 33),     # a 9-wide latent: one partly filled n-tile, 16-row batch step + 1
+    ([33, 500, 17], [1, 0], 130),           # nothing is a multiple of 16
+])
+def test_one_launch_gradient_adam_kernel_state_and_packed_copies(ctx, prec, dims, act, n):
+    """csrc/dw_adam.h (single-rank chain steps): after each of three steps (m, v, w) follow the float64 oracle's
+    Adam driven by the DEVICE's own gradient, and the loss the NEXT step reports -- computed by the chain kernel from
+    the packed 16-bit weight copies this kernel rebuilt -- is the float64 forward loss of the arena weights.  A stale,
+    misplaced or missing fragment of the packed copies shows up as a loss that is off by far more than the
+    precision's tolerance."""
+    native = pkg("_native")
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(n, dims[0])).astype(np.float32)
+    y = None if dims[0] == dims[-1] else rng.normal(size=(n, dims[-1])).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, size=n).astype(np.float32) / dims[-1]
+    Ws, bs = ora.init_mlp(dims, seed=7)
+    st = native.Stack(ctx, dims, act); st.set_weights(ora.flatten_params(Ws, bs))
+    tr = native.Trainer(st, prec, n)
+    tr.set_adam(lr=5e-3); tr.set_data(0, x, y, w)
+    ostate = ora.AdamState(st.num_params, dtype=np.float64, lr=5e-3)
+    flat = ora.flatten_params(Ws, bs).astype(np.float64)
+    tol = 3e-3 if prec == "f16" else 3e-2
+
+    def oracle_loss(flat64):
+        W, b = ora.unflatten_params(flat64, dims)
+        h = x.astype(np.float64)
+        for W_, b_, a_ in zip(W, b, act):
+            h = h @ W_ + b_
+            h = np.maximum(h, 0) if a_ else h
+        t = x.astype(np.float64) if y is None else y.astype(np.float64)
+        return float(np.mean(ora.per_sample_loss(h, t, w.astype(np.float64))))
+
+    for step in range(3):
+        expect = oracle_loss(st.get_weights().astype(np.float64))
+        loss = tr.run_epoch(None, n)
+        assert abs(loss - expect) / expect < tol, (step, loss, expect)
+        g = tr.get_grad().astype(np.float64)
+        flat = ora.adam_step(flat, g, ostate)
+        it, m, v = tr.get_state()
+        assert it == step + 1
+        np.testing.assert_allclose(m, ostate.m, rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(v, ostate.v, rtol=1e-4, atol=1e-12)
+        np.testing.assert_allclose(st.get_weights(), flat, rtol=1e-4, atol=2e-6)
+        flat = st.get_weights().astype(np.float64)  # (keep following the device: differences must not accumulate)
+        ostate.m[:] = m; ostate.v[:] = v
 
 
 def test_chain_path_is_actually_used(ctx):
