@@ -72,6 +72,7 @@ struct ChainModel {
   int L;
   ChainLayer lt[16];
   const void* fw; const void* bw;  // packed weight streams
+  long long fw_bytes, bw_bytes;    // their sizes (the prefetcher workgroups touch every line once)
   const float* w;                  // arena (biases)
   long long BS;                    // batch steps of 16 per feature tile of the transposed buffers
   // batch loss: every workgroup adds its rows' losses as 2^-32 fixed point (an integer sum does not
@@ -101,6 +102,9 @@ struct ChainStep {
   unsigned long long step_off;     // steps since the per-model `step` was stored (a sweep stores it once per epoch)
   StepCtx sc;                      // replayed step (hipGraph): `first` comes from the step descriptor
   int y_from_lds;                  // joint step: the targets are the rows the previous model left in LDS (zcap_layer)
+  // workgroups [0, ncons) carry row blocks; workgroups ncons + 8 p + x (p < npref) are PREFETCHERS of XCD x: they
+  // touch every 128-byte line of the model's weight streams once and leave (see chain_prefetch)
+  int ncons, npref;
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
@@ -114,15 +118,36 @@ __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
 template <class P>
 __device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st);
 
+// Every row-block workgroup streams the model's whole packed weight set, and the Adam kernel has just rewritten it:
+// the lines are in no L2.  All workgroups of an XCD ask for the same line at about the same time, so each of them
+// waits for the miss (~700 ns against ~300 for a hit), once per chunk of its rolling prefetch -- and a CU pulls only
+// ~55 GB/s of lines that miss its L2.  A batch leaves CUs idle (4,096 rows: 128 of 256; 256 rows: 248): workgroups
+// placed there touch every line of the streams once, npref of them per XCD in parallel, while the row-block
+// workgroups are still gathering their rows.  (The same touches issued by the row-block workgroups themselves were
+// measured useless in r2: they queue in the very miss path they are meant to relieve.)  Measured: chain 66.5 k ->
+// 62.4 k cycles at 4,096 rows, 68.3 k -> 61.3 k at 256 rows; 4 prefetchers per XCD do as well as 16.
+__device__ __forceinline__ void chain_prefetch(const ChainModel& a, const ChainStep& st) {
+  const int p = ((int)blockIdx.x - st.ncons) >> 3;
+  const long long nf = (a.fw_bytes + 127) >> 7, nb = (a.bw_bytes + 127) >> 7;
+  for (long long i = (long long)p * blockDim.x + threadIdx.x; i < nf + nb; i += (long long)st.npref * blockDim.x) {
+    const char* ptr = i < nf ? reinterpret_cast<const char*>(a.fw) + (i << 7) : reinterpret_cast<const char*>(a.bw) + ((i - nf) << 7);
+    unsigned v;
+    // (waited for inside the statement: the destination register must not be reused while the load is in flight)
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+  }
+}
+
 // one model: everything in the kernel-argument block
 template <class P>
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const ChainArgs a) {
+  if ((int)blockIdx.x >= a.ncons) { chain_prefetch(a, a); return; }
   train_chain_body<P>(a, a);
 }
 // a sweep: blockIdx.y = model, the per-model blocks in device memory
 template <class P>
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_group_kernel(const ChainModel* __restrict__ tab,
                                                                              const ChainStep st) {
+  if ((int)blockIdx.x >= st.ncons) { chain_prefetch(tab[blockIdx.y], st); return; }
   train_chain_body<P>(tab[blockIdx.y], st);
 }
 
@@ -132,6 +157,7 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_group_kernel(con
 template <class P>
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_joint_kernel(const ChainModel* __restrict__ tab /* [2], device */,
                                                                              const ChainStep sa, const ChainStep sb) {
+  if ((int)blockIdx.x >= sa.ncons) { chain_prefetch(tab[0], sa); chain_prefetch(tab[1], sa); return; }
   train_chain_body<P>(tab[0], sa);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // model A's last LDS reads precede model B's gather
   train_chain_body<P>(tab[1], sb);

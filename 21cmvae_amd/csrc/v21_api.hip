@@ -750,6 +750,7 @@ struct v21_trainer {
   // one-kernel forward + activation-gradient chain (train_chain.h; f16 / bf16 stacks up to 512 wide)
   bool chain = false;
   void *d_fw = nullptr, *d_bw = nullptr;
+  long long fw_bytes = 0, bw_bytes = 0;
   std::vector<long long> fw_off, bw_off;  // element offsets per layer
   float* d_partial = nullptr;
   unsigned* d_ticket = nullptr;
@@ -853,6 +854,7 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
         t->fw_off.push_back(of); of += (long long)((N + 31) / 32) * chain_steps(K) * 512;
         t->bw_off.push_back(ob); ob += (long long)((K + 31) / 32) * chain_steps(N) * 512;
       }
+      t->fw_bytes = of * 2; t->bw_bytes = ob * 2;
       HIPCHK(hipMalloc(&t->d_fw, (size_t)of * 2 + 64)); HIPCHK(hipMemsetAsync(t->d_fw, 0, (size_t)of * 2 + 64, st));
       HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 2 + 64)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 2 + 64, st));
       CHK(zalloc(&t->d_partial, (size_t)(max_batch + 31) / 32 + 4, st));
@@ -1296,6 +1298,7 @@ static ChainModel chain_model(v21_trainer* t) {
     c.ht16 = t->d_ht16[l]; c.dzt16 = t->d_dzt16[l + 1];
   }
   a.fw = t->d_fw; a.bw = t->d_bw; a.w = m->d_w;
+  a.fw_bytes = t->fw_bytes; a.bw_bytes = t->bw_bytes;
   a.BS = t->BS;
   a.loss_acc = (unsigned long long*)t->d_ticket;
   a.stamps = t->d_stamps;
@@ -1334,13 +1337,21 @@ static int chain_attr(int prec) {
   done[prec] = true;
   return V21_OK;
 }
+// prefetcher workgroups per XCD for a launch of `models` x `ncons` row-block workgroups: the CUs the row blocks leave idle
+static int chain_prefetchers(int ncons, int models) {
+  if (models > 1) return 0;  // a sweep: measured slower with them (8 models, 24 prefetchers each: 106 k -> 95 k model-steps/s)
+  const int idle = 256 - ncons;
+  return idle >= 8 ? std::min(8, idle / 8) : 0;
+}
 static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
                         const int* d_idx, long long first, int rows, int brows, long long row0) {
   ChainArgs a{};
   static_cast<ChainModel&>(a) = chain_model(t);
   static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, t->mlp->dims[t->mlp->L], t, row0);
   CHK(chain_attr(t->prec));
-  const dim3 grid(((rows + 31) / 32 + 7) / 8 * 8), block(64 * kChainWaves);  // whole rounds of the 8 XCDs
+  a.ncons = ((rows + 31) / 32 + 7) / 8 * 8;  // whole rounds of the 8 XCDs
+  a.npref = chain_prefetchers(a.ncons, 1);
+  const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
   if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
   else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
   HIPCHK(hipGetLastError());
@@ -2023,11 +2034,14 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long l
   if (rows > 0) {
     for (v21_trainer* t : s->tr) CHK(ensure_copies(t, false));
     CHK(chain_attr(t0->prec));
-    const dim3 grid(((rows + 31) / 32 + 7) / 8 * 8, G), block(64 * kChainWaves);
+    ChainStep csp = cs;
+    csp.ncons = ((rows + 31) / 32 + 7) / 8 * 8;
+    csp.npref = chain_prefetchers(csp.ncons, G);
+    const dim3 grid(csp.ncons + 8 * csp.npref, G), block(64 * kChainWaves);
     if (t0->prec == V21_PREC_F16)
-      hipLaunchKernelGGL(train_chain_group_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, cs);
+      hipLaunchKernelGGL(train_chain_group_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
     else
-      hipLaunchKernelGGL(train_chain_group_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, cs);
+      hipLaunchKernelGGL(train_chain_group_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
     HIPCHK(hipGetLastError());
     if (s->ctx->nranks == 1)  // nothing to exchange: all gradients, all Adam updates, all packed copies in one launch
       return launch_dw_adam_group(s->tr, s->d_dwadam, s->h_dwadam, rows, brows, step_index, st);
@@ -2152,7 +2166,7 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
 // encoder produces for those rows in that very step (stop-gradient) instead of the reference's
 // encoder.predict() of the finished autoencoder (:753-754).  With the autoencoder frozen (lr = 0) it is
 // exactly the reference's phase 2.  One launch carries a row block through both models
-// (train_chain_joint_kernel), one grouped launch forms all weight gradients, two Adam launches.
+// (train_chain_joint_kernel), one grouped launch forms all weight gradients and applies Adam to both models (dw_adam.h).
 // ---------------------------------------------------------------------------------
 struct v21_joint {
   v21_trainer *ae = nullptr, *em = nullptr;
@@ -2244,7 +2258,9 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
     ChainStep sa = chain_step(ta->d_x[0], dsig, nullptr, dsig, ta->d_rw[0], d_idx, first, rows, rows, dsig);
     ChainStep sb = chain_step(te->d_x[0], dpar, nullptr, dlat, te->d_rw[0], d_idx, first, rows, rows, dlat);
     sb.y_from_lds = 1;
-    const dim3 grid(((rows + 31) / 32 + 7) / 8 * 8), block(64 * kChainWaves);
+    sa.ncons = sb.ncons = ((rows + 31) / 32 + 7) / 8 * 8;
+    sa.npref = sb.npref = chain_prefetchers(sa.ncons, 1);
+    const dim3 grid(sa.ncons + 8 * sa.npref), block(64 * kChainWaves);
     if (ta->prec == V21_PREC_F16)
       hipLaunchKernelGGL(train_chain_joint_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
     else
