@@ -339,13 +339,15 @@ class Model:
             # trains on its share of each global batch, so the replicas must START equal and SHUFFLE alike --
             # rank 0's weights, optimizer state and, per epoch, permutation are broadcast over the process group.
             from . import parallel
-            flat = parallel.broadcast_array(self._stack.get_weights())
-            self._stack.set_weights(flat)
+
+            def bcast(a):  # (the context's GPU, not torch's per-thread current device)
+                return parallel.broadcast_array(a, device=tr.ctx.device)
+
+            self._stack.set_weights(bcast(self._stack.get_weights()))
             it, mm, vv = tr.get_state()
-            tr.set_state(int(parallel.broadcast_array(np.array([it], np.int64))[0]), parallel.broadcast_array(mm),
-                         parallel.broadcast_array(vv))
+            tr.set_state(int(bcast(np.array([it], np.int64))[0]), bcast(mm), bcast(vv))
             if getattr(self, "_vae_seed", None) is not None:
-                self._vae_seed = int(parallel.broadcast_array(np.array([self._vae_seed], np.uint64))[0])
+                self._vae_seed = int(bcast(np.array([self._vae_seed], np.uint64))[0])
         history = cb_mod.History()
         cbs = cb_mod.CallbackList([history] + list(callbacks or []), self,
                                   {"epochs": epochs, "steps": -(-n // batch_size), "verbose": verbose})
@@ -359,7 +361,7 @@ class Model:
                 tr.set_vae(self.kl_weight, self.sample_latent, self._vae_seed)
             perm = _rng.permutation(n).astype(np.int32) if shuffle else None
             if dp and perm is not None:
-                perm = parallel.broadcast_array(perm)
+                perm = bcast(perm)
             logs = {"loss": tr.run_epoch(perm, batch_size)}
             self._dirty_host = True
             if validation_data is not None:

@@ -33,13 +33,21 @@ def _dist():
     return dist
 
 
+def _pg_device(device=None):
+    """Where a tensor handed to the process group must live: the host under gloo; under nccl (= RCCL) the GPU with
+    index `device` -- torch's current device is per THREAD, a worker thread starts on GPU 0 whatever the rank's GPU is,
+    so callers that know their context pass its device index."""
+    import torch
+    if _dist().get_backend() != "nccl":
+        return torch.device("cpu")
+    return torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+
+
 def broadcast_bytes(payload, nbytes, src=0, device=None):
     """Rank `src` passes `payload` (bytes); every rank gets the same bytes back."""
     import torch
     dist = _dist()
-    if device is None:
-        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=_pg_device(device))
     if dist.get_rank() == src:
         buf.copy_(torch.tensor(list(payload), dtype=torch.uint8))
     dist.broadcast(buf, src=src)
@@ -62,15 +70,16 @@ def init_engine_comm(ctx, backend="auto", sharded=False):
         backend = "rccl" if dist.get_backend() == "nccl" else "host"
     if backend == "rccl":
         uid = ctx.comm_unique_id() if rank == 0 else b""
-        uid = broadcast_bytes(uid, _native.COMM_ID_BYTES)
+        uid = broadcast_bytes(uid, _native.COMM_ID_BYTES, device=ctx.device)
         ctx.comm_init(world, rank, uid)
     else:
         import torch
         on_gpu = dist.get_backend() == "nccl"  # the group's tensors live on the device: stage the host buffer through it
+        dev = _pg_device(ctx.device)
 
         def _t(buf):
             t = torch.from_numpy(buf)
-            return t.cuda() if on_gpu else t
+            return t.to(dev) if on_gpu else t
 
         def allreduce(buf, n):
             t = _t(buf)
@@ -91,14 +100,12 @@ def init_engine_comm(ctx, backend="auto", sharded=False):
     ctx.comm_set_sharded(sharded)
 
 
-def broadcast_array(arr, src=0):
+def broadcast_array(arr, src=0, device=None):
     """Every rank returns rank `src`'s copy of the numpy array (same shape and dtype everywhere)."""
     import torch
     dist = _dist()
     a = np.ascontiguousarray(arr)
-    t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
-    if dist.get_backend() == "nccl":
-        t = t.cuda()
+    t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(_pg_device(device))
     dist.broadcast(t, src=src)
     return t.cpu().numpy().view(a.dtype).reshape(a.shape)
 
@@ -112,13 +119,11 @@ def in_group():
         return False
 
 
-def allreduce_flat(arr):
+def allreduce_flat(arr, device=None):
     """Sum a flat float32 numpy buffer over the process group (CPU tests / Python-driven
     loops); returns a new array."""
     import torch
     dist = _dist()
-    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).copy())
-    if dist.get_backend() == "nccl":
-        t = t.cuda()
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).copy()).to(_pg_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()

@@ -55,8 +55,9 @@ def glorot(dims, seed):
 
 
 def _pg_device(dist):
-    """Where the tensors of the contract's max-over-ranks / sums live: the GPU under nccl (= RCCL), the host under gloo."""
-    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+    """Where the tensors of the contract's max-over-ranks / sums live: this rank's GPU under nccl (= RCCL), the host
+    under gloo.  The index is explicit: torch's current device is per thread, and the training leg runs in one."""
+    return "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if dist.get_backend() == "nccl" else "cpu"
 
 
 def usable_cores():
@@ -588,6 +589,8 @@ def main():
     if not args.no_train:
         def run_train():
             try:
+                if dist is not None and dist.get_backend() == "nccl":
+                    torch.cuda.set_device(local_rank)  # (a new thread starts on GPU 0)
                 transport = "none"
                 if world > 1:
                     par = importlib.import_module("21cmvae_amd.parallel")
