@@ -232,6 +232,11 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       if (wave < a.lt[l].NT) return fwd_job(l, wave);
     return bwd_from(a.L - 1);
   };
+  // the wave's row indices first: their load is the oldest in flight, so the gather below waits for it alone and not
+  // for the (cold) weight fragments requested next
+  const int mq = m0 + RPW * wave + (lane & (RPW - 1));
+  long long srow = mq < st.rows ? first + mq : first + m0;  // clamped: always a valid position
+  if (st.idx) srow = st.idx[srow];
   frag wa[4], wb[4];  // chunk in use / chunk in flight (the roles alternate)
   float bnext;        // bias values of the wave's next forward tile (in flight with its first chunk)
   {
@@ -249,9 +254,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
      // a valid address and replaced by 0, and every lane writes its whole strip of the LDS images (columns
      // >= K are the zero padding the first contraction reads).
     const int K0 = a.lt[0].K, DO = a.lt[a.L - 1].N;
-    const int mq = m0 + RPW * wave + (lane & (RPW - 1));
-    long long srow = mq < st.rows ? first + mq : first + m0;  // clamped: always a valid position
-    if (st.idx) srow = st.idx[srow];
     const float rwv = st.rw[srow];
     long long sr[RPW];
 #pragma unroll
