@@ -399,7 +399,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=100)  # ~6 ms: lets the clocks settle before the timed steps
+    ap.add_argument("--warmup", type=int, default=100)
+    # The shader clock needs ~50 ms of load to come up from idle (scripts/clock_settle_probe.py: 101, 69, 61, 58 ... us per
+    # launch over the first 25 ms, 52.0 +- 0.3 from 50 ms on): an untimed run of the same launches precedes the W warm-up
+    # steps, so that the K timed steps measure the sustained rate whatever K and W are.
+    ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed launches before the warm-up steps")
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -468,6 +472,11 @@ def main():
             dist.barrier()
 
     def timed(prec, steps, warmup):
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < args.settle:
+            for _ in range(100):
+                stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
+            ctx.sync()
         for _ in range(warmup):
             stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
         sync_all(); barrier(); sync_all()
@@ -506,6 +515,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "clock_settle_s": args.settle,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
