@@ -105,6 +105,9 @@ struct ChainStep {
   // workgroups [0, ncons) carry row blocks; workgroups ncons + 8 p + x (p < npref) are PREFETCHERS of XCD x: they
   // touch every 128-byte line of the model's weight streams once and leave (see chain_prefetch)
   int ncons, npref;
+  // validation pass: gather, forward and loss only -- nothing is written but the loss accumulator, so the launch may
+  // cover ANY number of rows (the weight-gradient operands, sized for max_batch, are not touched)
+  int fwd_only;
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
@@ -326,7 +329,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     frag* d = reinterpret_cast<frag*>(dst);
     const int g = lane >> 4, i = lane & 15;
     const int w0 = tiles < NW ? tiles : 0;  // waves [0, w0) have a tile (every wave has one: all of them flush)
-    if (wave < w0) return;
+    if (wave < w0 || st.fwd_only) return;
     for (int id = wave - w0; id < nfrag; id += NW - w0) {
       const int ft = id >> 1, q2 = id & 1;
       const int r0 = 16 * q2 + 8 * (g >> 1);
@@ -516,6 +519,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   }
 
   chain_stamp(a, 2 + a.L);
+  if (st.fwd_only) return;
   // gs * dL/dz (latent wide, in `b`) -> gs * dL/d[mu | lv] in place:  d mu = dz + beta mu,
   // d lv = dz eps exp(lv/2)/2 + beta (exp lv - 1)/2, beta = kl_weight / B (the KL term's own gradient)
   auto gauss_backward = [&](elem* b, int LAT, int pad) __attribute__((always_inline)) {

@@ -1735,6 +1735,31 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
   const long long n = t->n[which];
   const int din = m->dims[0], dout = m->dims[m->L];
   if (batch < 1) return fail(V21_ERR_ARG, "batch must be >= 1");
+  if (t->chain) {
+    // ONE forward-only launch of the chain kernel over all n rows (csrc/train_chain.h: fwd_only) instead of 8 launches
+    // per batch of the per-layer path: the same arithmetic as the training loss of this precision, no noise drawn
+    if (n > (1ll << 30)) return fail(V21_ERR_ARG, "too many rows for one validation launch");
+    CHK(ensure_copies(t, false));
+    ChainArgs a{};
+    static_cast<ChainModel&>(a) = chain_model(t);
+    a.sample = 0;
+    static_cast<ChainStep&>(a) = chain_step(t->d_x[which], din, t->y_is_x[which] ? nullptr : t->d_y[which], dout,
+                                            t->d_rw[which], nullptr, 0, (int)n, (int)n, dout);
+    a.fwd_only = 1;
+    a.ncons = (int)(((n + 31) / 32 + 7) / 8 * 8);
+    a.npref = chain_prefetchers(a.ncons, 1);
+    CHK(chain_attr(t->prec));
+    const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
+    if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, st, a);
+    else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, a);
+    HIPCHK(hipGetLastError());
+    long long acc = 0;  // 2^-32 fixed point (order-independent sum over the workgroups)
+    HIPCHK(hipMemcpyAsync(&acc, t->d_ticket, sizeof acc, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(t->d_ticket, 0, sizeof acc, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *loss = (double)acc * (1.0 / 4294967296.0) / (double)n;
+    return V21_OK;
+  }
   const int b = std::min(batch, t->max_batch);
   CHK(ensure_copies(t));
   HIPCHK(hipMemsetAsync(t->d_evalsum, 0, 16, st));

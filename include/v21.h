@@ -163,7 +163,9 @@ int v21_trainer_set_data(v21_trainer* tr, int which /*0 train, 1 val*/, const fl
  * sum(batch_loss * n_b) / N.  With a communicator attached each rank takes its
  * slice of every global batch and gradients are all-reduced (sum) before Adam. */
 int v21_trainer_run_epoch(v21_trainer* tr, const int32_t* perm, int batch, double* loss);
-/* validation pass (which = 1) or loss over the training set (which = 0) */
+/* validation pass (which = 1) or loss over the training set (which = 0).  f16 / bf16 trainers on the chain kernel
+ * evaluate the whole split in ONE forward-only launch (`batch` is then only validated); f32 trainers walk it in
+ * batches of min(batch, max_batch). */
 int v21_trainer_eval(v21_trainer* tr, int which, int batch, double* loss);
 /* single optimizer step on caller-provided device batch (bench / custom loops) */
 int v21_trainer_step_dev(v21_trainer* tr, const float* d_x, const float* d_y,

@@ -453,6 +453,39 @@ def test_chain_kernel_trains_and_validates(ctx):
     np.testing.assert_allclose(st.forward(y[:50], "f32"), p, atol=5e-4, rtol=1e-3)
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_validation_pass_is_one_forward_only_chain_launch(ctx, prec):
+    """v21_trainer_eval on the chain path: one forward-only launch over ALL rows of the split (more than max_batch,
+    not a multiple of 32), against the float64 oracle's loss of the same weights; training state is left alone (the
+    next epoch's loss and weights are those of a trainer that never validated)."""
+    native = pkg("_native")
+    synth = pkg("synth")
+    dims, act = [451, 64, 9, 32, 451], [1, 0, 1, 0]
+    Ws, bs = ora.init_mlp(dims, seed=9)
+    sig = synth.make_signals(1500, seed=5)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    res = []
+    for validate in (True, False):
+        st = native.Stack(ctx, dims, act); st.set_weights(ora.flatten_params(Ws, bs))
+        tr = native.Trainer(st, prec, 128)
+        tr.set_adam(lr=1e-3); tr.set_data(0, y[:500], None, w[:500]); tr.set_data(1, y[500:1477], None, w[500:1477])
+        tr.run_epoch(None, 128)
+        if validate:
+            v = tr.evaluate(1, 128)
+            W, b = ora.unflatten_params(st.get_weights().astype(np.float64), dims)
+            h = y[500:1477].astype(np.float64)
+            for W_, b_, a_ in zip(W, b, act):
+                h = h @ W_ + b_
+                h = np.maximum(h, 0) if a_ else h
+            expect = float(np.mean(ora.per_sample_loss(h, y[500:1477].astype(np.float64), w[500:1477].astype(np.float64))))
+            assert abs(v - expect) / expect < (3e-3 if prec == "f16" else 3e-2), (v, expect)
+            assert abs(tr.evaluate(1, 64) - v) == 0.0  # the batch argument no longer cuts the pass: same launch, same sum
+        res.append((tr.run_epoch(None, 128), st.get_weights()))
+    assert res[0][0] == res[1][0]
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("dims,act,n", [
     ([451, 451], [0], 70),                         # one layer: the loss epilogue is also the first layer
     ([33, 500, 512, 17], [1, 1, 0], 45),           # widths that are not multiples of 16/32, the 512 limit
