@@ -1455,12 +1455,12 @@ static void dw_adam_model(v21_trainer* t, DwAdamModel& md) {
   }
   md.nblk = nb;
 }
-static int launch_dw_adam(v21_trainer* t, int rows, int brows, float alpha) {
+static int launch_dw_adam(v21_trainer* t, int rows, int brows, float alpha, int slot = -1) {
   DwAdamModel md;
   dw_adam_model(t, md);
   DwAdamStep st{};
   st.steps = (rows + 15) / 16;
-  st.slot = -1;
+  st.slot = slot;
   st.alpha[0] = alpha;
   st.out_scale[0] = 1.0f / grad_opscale(brows, t->mlp->dims[t->mlp->L]);
   st.sc = step_ctx(t);
@@ -1532,9 +1532,12 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
     if (t->ctx->nranks == 1) {  // nothing to exchange: gradients, Adam and the packed copies in one launch
       if (!t->capturing) t->iter += 1;
-      CHK(launch_dw_adam(t, rows, brows, t->capturing ? 0.f : adam_alpha(t->adam, t->iter)));
+      // an epoch's per-step loss slot is written by the kernel itself (a device-to-device copy per step is a launch)
+      const bool in_table = loss_out && t->d_steploss && loss_out >= t->d_steploss && loss_out < t->d_steploss + t->steploss_cap;
+      CHK(launch_dw_adam(t, rows, brows, t->capturing ? 0.f : adam_alpha(t->adam, t->iter),
+                         in_table ? (int)(loss_out - t->d_steploss) : -1));
       if (t->capturing) return V21_OK;
-      if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (loss_out && !in_table) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
       invalidate_streams(m);
       m->wpad_ok = true;
       return V21_OK;

@@ -369,12 +369,13 @@ def latency_leg():
     return res
 
 
-def fit_leg(precision, epochs=12, n_train=None, joint=False):
+def fit_leg(precision, epochs=30, n_train=None, joint=False):
     """Auxiliary metric (BASELINE configs[2]): the reference's whole training recipe through the class
     surface -- AutoEncoderEmulator.train(): autoencoder fit x -> x, encode, latent emulator fit, each
     with a validation pass per epoch -- on a synthetic data set of the reference's size (24,562 / 2,730
     rows, batch 256; n_train = 30,000 honours configs[2] literally).  joint=True: both models step on the
-    same rows of every batch (v21_joint_*).  Wall clock of the call, Python and callbacks included."""
+    same rows of every batch (v21_joint_*).  Wall clock of the call, Python and callbacks included -- also the ~40 ms a
+    train() call spends once on the row weights and the pre-processing of the data set (scripts/fit_pyprofile.py)."""
     synth = importlib.import_module("21cmvae_amd.synth")
     emu = importlib.import_module("21cmvae_amd.emulator")
     optm = importlib.import_module("21cmvae_amd.optimizers")
