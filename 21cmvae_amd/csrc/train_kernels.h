@@ -46,7 +46,7 @@ __global__ void loss_grad_kernel(const float* __restrict__ p, long long ldp,
 
 // deterministic sum of n floats by ONE workgroup -> out[0] (n <= a few 10^5)
 __global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out, int accumulate,
-                           float* __restrict__ slots = nullptr, StepCtx sc = StepCtx{nullptr, nullptr}) {
+                           float* __restrict__ slots = nullptr, StepCtx sc = StepCtx{nullptr, nullptr}, int slot = -1) {
   __shared__ double part[16];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)v[i];
@@ -58,7 +58,8 @@ __global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict
     double t = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
     out[0] = accumulate ? out[0] + (float)t : (float)t;
-    if (slots && sc.desc) slots[sc.desc[*sc.cur].slot] = (float)t;  // the step's loss, where run_epoch collects it
+    // the step's loss, where run_epoch collects it: the replayed step's descriptor names the slot, an eager epoch passes it
+    if (slots && (sc.desc || slot >= 0)) slots[sc.desc ? sc.desc[*sc.cur].slot : slot] = (float)t;
   }
 }
 

@@ -1204,6 +1204,9 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
   hipStream_t st = t->ctx->stream;
   const int L = m->L, dout = m->dims[L];
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
+  // single rank, an epoch's per-step slot: the sum kernel writes it itself (a device-to-device copy per step is a launch)
+  const bool in_table = t->ctx->nranks == 1 && rows > 0 && loss_out && t->d_steploss && loss_out >= t->d_steploss &&
+                        loss_out < t->d_steploss + t->steploss_cap;
   if (rows > 0) {
     CHK(ensure_copies(t));
     CHK(trainer_forward(t, rows, true, true, row0));
@@ -1213,7 +1216,7 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
                        2.0f / (float)brows, (const float*)t->d_klrow);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, t->d_rowloss, rows, t->d_g + t->P, 0, t->d_steploss,
-                       step_ctx(t));
+                       step_ctx(t), in_table ? (int)(loss_out - t->d_steploss) : -1);
     HIPCHK(hipGetLastError());
     // weight gradients contract over the batch: slices of <= kNtMaxKPerWg rows -> slabs
     int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
@@ -1268,7 +1271,7 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
     return V21_OK;
   }
   CHK(reduce_and_update(t, false, 1));
-  if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (loss_out && !in_table) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
   invalidate_streams(m);
   m->wpad_ok = true;  // ... but our own copies were just refreshed
   return V21_OK;
