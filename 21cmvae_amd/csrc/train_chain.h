@@ -346,6 +346,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     }
   };
 
+  // columns [c0, c1) of all 32 rows of an image <- 0: wave w owns rows RPW w ..., a row's lanes run along the columns
+  // (no index division: measured, the i / (c1 - c0), i % (c1 - c0) form was a quarter of the kernel's VALU instructions)
+  auto zero_cols = [&](elem* img, int c0, int c1) __attribute__((always_inline)) {
+    constexpr int LPR = 64 / RPW;  // lanes per row
+    elem* row = img + (RPW * wave + lane / LPR) * PITCH;
+    for (int c = c0 + lane % LPR; c < c1; c += LPR) row[c] = (elem)0.f;
+  };
   // One 32-wide tile: acc(rows = features of the tile, col = batch row li) over `nch` chunks of four
   // k-steps.  On entry chunk 0 of `wsrc` is in `wa` (in flight or landed); on exit chunk 0 of `nxt` --
   // the wave's next tile -- is in flight in `wa` (returns false) or in `wb` (returns true: nch was odd;
@@ -494,10 +501,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     // columns the tiles did not cover, up to the next contraction's padded range: zero
     {
       const int c0 = 32 * ly.NT, c1 = last ? ly.NS * 16 : a.lt[l + 1].KS * 16;
-      for (int i = tid; i < 32 * (c1 - c0); i += 64 * NW) {
-        const int m = i / (c1 - c0), c = c0 + i % (c1 - c0);
-        out[m * PITCH + c] = (elem)0.f;
-      }
+      zero_cols(out, c0, c1);
     }
     chain_barrier();
     cur ^= 1;
@@ -568,10 +572,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     }
     {
       const int c0 = 32 * ly.KT, c1 = below.NS * 16;
-      for (int i = tid; i < 32 * (c1 - c0); i += 64 * NW) {
-        const int m = i / (c1 - c0), c = c0 + i % (c1 - c0);
-        out[m * PITCH + c] = (elem)0.f;
-      }
+      zero_cols(out, c0, c1);
     }
     chain_barrier();
     cur ^= 1;
