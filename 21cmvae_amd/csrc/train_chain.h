@@ -419,15 +419,15 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     for (int t = wave; t < ly.NT; t += NW) {
       const int n0 = 32 * t;
       f32x16 acc;
-      {  // accumulator = bias: register r of lane half lh is feature n0 + (r & 3) + 8 (r >> 2) + 4 lh
+      {  // accumulator = bias: register r of lane half lh is feature n0 + (r & 3) + 8 (r >> 2) + 4 lh, which lane
+         // (r & 3) + 8 (r >> 2) + 4 lh of `bnext` holds (lanes past the layer's width hold 0).  Sixteen lane permutes
+         // through the LDS crossbar (one address register, immediate offsets): the readlane / select form was 80
+         // VALU instructions per tile, a third of the kernel's.
         const int bbits = __builtin_bit_cast(int, bnext);
+        const int pbase = 16 * lh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {  // (lanes past the layer's width hold 0)
-          const int il = (r & 3) + 8 * (r >> 2), ih = il + 4;
-          const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bbits, il));
-          const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bbits, ih));
-          acc[r] = lh ? b1 : b0;
-        }
+        for (int r = 0; r < 16; ++r)
+          acc[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pbase + 4 * ((r & 3) + 8 * (r >> 2)), bbits));
       }
       const Job nxt = t + NW < ly.NT ? fwd_job(l, t + NW) : fwd_from(l + 1);
       const bool odd = contract(fw + ly.fw_off + ((long long)t * ly.KS) * 64 + lane, act, nch, acc, nxt);
@@ -445,14 +445,16 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
             if (n < ZP) *reinterpret_cast<f32x4*>(zs + li * ZP + n) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
           }
         }
-        unsigned bits = 0;
         if (ly.relu) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
-        }
+          if (ly.mask_tile >= 0) {
+            unsigned bits = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bits |= (acc[r] > 0.f ? 1u : 0u) << r;
-        if (ly.mask_tile >= 0) masks[ly.mask_tile + t][lane] = (unsigned short)bits;
+            for (int r = 0; r < 16; ++r) bits |= (acc[r] > 0.f ? 1u : 0u) << r;
+            masks[ly.mask_tile + t][lane] = (unsigned short)bits;
+          }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + 8 * g + 4 * lh;
@@ -560,7 +562,10 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       if (below.relu) {
         const unsigned bits = masks[below.mask_tile + t][lane];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = (bits >> r) & 1u ? acc[r] : 0.f;
+        for (int r = 0; r < 16; ++r) {  // (a sign-extended one-bit field is the AND mask; the element goes through a
+          const float v = acc[r];        //  scalar: __builtin_bit_cast applied to `acc[r]` itself read element 0)
+          acc[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & (((int)(bits << (31 - r))) >> 31));
+        }
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
