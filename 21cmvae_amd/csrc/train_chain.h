@@ -250,6 +250,12 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   }
 
   chain_stamp(a, 0);
+  // buf[1] <- 0, once.  A contraction reads its operand image up to the padded k range; the columns past a layer's last
+  // 32-wide tile are never written again, and whatever finite value they hold meets a zero weight.  What must not be
+  // there is the NaN / Inf bit patterns another kernel may have left in LDS: hence this clear (buf[0] is written in
+  // full by the gather).  It replaces a zero-fill per layer (~250 cycles each, ten layers).
+  for (int i = tid; i < 32 * PITCH * (int)sizeof(elem) / 16; i += 64 * NW)
+    reinterpret_cast<uint4*>(buf[1])[i] = uint4{0u, 0u, 0u, 0u};
   // ---- gather: x[idx] -> buf[0] (compute type) and the fp32 target rows
   {  // wave w moves rows RPW w .. RPW w + RPW - 1, lanes run along the row (256-byte segments); targets stay in LDS as fp32.
      // Two dependent round trips: the wave's row indices (one vector load, broadcast by readlane), then
@@ -346,13 +352,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     }
   };
 
-  // columns [c0, c1) of all 32 rows of an image <- 0: wave w owns rows RPW w ..., a row's lanes run along the columns
-  // (no index division: measured, the i / (c1 - c0), i % (c1 - c0) form was a quarter of the kernel's VALU instructions)
-  auto zero_cols = [&](elem* img, int c0, int c1) __attribute__((always_inline)) {
-    constexpr int LPR = 64 / RPW;  // lanes per row
-    elem* row = img + (RPW * wave + lane / LPR) * PITCH;
-    for (int c = c0 + lane % LPR; c < c1; c += LPR) row[c] = (elem)0.f;
-  };
   // One 32-wide tile: acc(rows = features of the tile, col = batch row li) over `nch` chunks of four
   // k-steps.  On entry chunk 0 of `wsrc` is in `wa` (in flight or landed); on exit chunk 0 of `nxt` --
   // the wave's next tile -- is in flight in `wa` (returns false) or in `wb` (returns true: nch was odd;
@@ -499,12 +498,9 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
         }
         klb[tid] = ok ? a.kl_weight * kl : 0.f;
       }
-    } else
-    // columns the tiles did not cover, up to the next contraction's padded range: zero
-    {
-      const int c0 = 32 * ly.NT, c1 = last ? ly.NS * 16 : a.lt[l + 1].KS * 16;
-      zero_cols(out, c0, c1);
     }
+    // (Columns the tiles did not cover, up to the next contraction's padded range, keep what they held: the weights of
+    // those k-steps are zero, and every 16-bit value an image ever holds is finite -- see the one-time clear above.)
     chain_barrier();
     cur ^= 1;
     chain_stamp(a, 2 + l);
@@ -574,10 +570,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
         *reinterpret_cast<uint2*>(out + li * PITCH + k) = pk;
       }
       settle(odd);
-    }
-    {
-      const int c0 = 32 * ly.KT, c1 = below.NS * 16;
-      zero_cols(out, c0, c1);
     }
     chain_barrier();
     cur ^= 1;
