@@ -501,15 +501,17 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     }
     // (Columns the tiles did not cover, up to the next contraction's padded range, keep what they held: the weights of
     // those k-steps are zero, and every 16-bit value an image ever holds is finite -- see the one-time clear above.)
+    if (last) {  // this lane's share of the row losses joins the other waves' behind the same barrier
+      lsum += __shfl_xor(lsum, 32, 64);
+      if (lh == 0) red[wave][li] = lsum * rwl[li];
+    }
     chain_barrier();
     cur ^= 1;
     chain_stamp(a, 2 + l);
   }
 
-  // ---- loss: lanes -> rows -> workgroup (fixed order) -> one fixed-point atomic per workgroup
-  lsum += __shfl_xor(lsum, 32, 64);
-  if (lh == 0) red[wave][li] = lsum * rwl[li];
-  chain_barrier();
+  // ---- loss: lanes -> rows (written before the last layer's barrier, above) -> workgroup (fixed order) -> one
+  // fixed-point atomic per workgroup
   if (tid < 32) {
     float s = 0.f;
 #pragma unroll
