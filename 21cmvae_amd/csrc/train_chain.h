@@ -481,23 +481,22 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     }
     if (ly.gauss) {  // z = mu + exp(lv/2) eps -> the next layer's operand image; KL_i -> the row's loss
       chain_barrier();
+      // one (batch row, latent dimension) per thread (latent <= 32 = 1,024 / 32): the draw of eps -- a hash, a logarithm,
+      // a cosine -- was a serial loop over the latent dimensions in 32 threads (5 us of a 58-us step, forward + backward)
       const int LAT = ly.N >> 1, c1 = a.lt[l + 1].KS * 16;
-      if (tid < 32) {
-        const bool ok = m0 + tid < st.rows;
-        float kl = 0.f;
-        for (int d = 0; d < c1; ++d) {
-          float z = 0.f;
-          if (d < LAT) {
-            const float mu = zs[tid * ZP + d], lv = zs[tid * ZP + LAT + d];
-            const float sd = expf(0.5f * lv);
-            const float e = a.sample ? gauss_eps(a.seed, a.step + st.step_off, st.row0 + m0 + tid, d) : 0.f;
-            z = mu + sd * e;
-            kl += -0.5f * (1.0f + lv - mu * mu - sd * sd);
-          }
-          out[tid * PITCH + d] = (elem)z;
-        }
-        klb[tid] = ok ? a.kl_weight * kl : 0.f;
+      const int row = tid & 31, d = tid >> 5;
+      float klt = 0.f;
+      if (d < LAT) {
+        const float mu = zs[row * ZP + d], lv = zs[row * ZP + LAT + d];
+        const float sd = expf(0.5f * lv);
+        const float e = a.sample ? gauss_eps(a.seed, a.step + st.step_off, st.row0 + m0 + row, d) : 0.f;
+        out[row * PITCH + d] = (elem)(mu + sd * e);
+        klt = -0.5f * (1.0f + lv - mu * mu - sd * sd);
       }
+      for (int dd = LAT + d; dd < c1; dd += 32) out[row * PITCH + dd] = (elem)0.f;
+      // KL_i: dimensions 2 w and 2 w + 1 meet in wave w, the waves in a fixed order after the layer's barrier
+      klt += __shfl_xor(klt, 32, 64);
+      if (lh == 0) red[wave][li] = klt;
     }
     // (Columns the tiles did not cover, up to the next contraction's padded range, keep what they held: the weights of
     // those k-steps are zero, and every 16-bit value an image ever holds is finite -- see the one-time clear above.)
@@ -506,6 +505,12 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       if (lh == 0) red[wave][li] = lsum * rwl[li];
     }
     chain_barrier();
+    if (ly.gauss && tid < 32) {
+      float kl = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) kl += red[w][tid];
+      klb[tid] = m0 + tid < st.rows ? a.kl_weight * kl : 0.f;
+    }
     cur ^= 1;
     chain_stamp(a, 2 + l);
   }
@@ -527,19 +532,17 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // gs * dL/dz (latent wide, in `b`) -> gs * dL/d[mu | lv] in place:  d mu = dz + beta mu,
   // d lv = dz eps exp(lv/2)/2 + beta (exp lv - 1)/2, beta = kl_weight / B (the KL term's own gradient)
   auto gauss_backward = [&](elem* b, int LAT, int pad) __attribute__((always_inline)) {
-    if (tid < 32) {
-      for (int d = 0; d < LAT; ++d) {
-        const float mu = zs[tid * ZP + d], lv = zs[tid * ZP + LAT + d];
-        const float sd = expf(0.5f * lv);
-        const float e = a.sample ? gauss_eps(a.seed, a.step + st.step_off, st.row0 + m0 + tid, d) : 0.f;
-        const float g = (float)b[tid * PITCH + d];
-        const bool ok = m0 + tid < st.rows;
-        const float kb = ok ? st.gs * a.kl_weight * st.inv_b : 0.f;
-        b[tid * PITCH + d] = (elem)(g + kb * mu);                                          // d mu (in place)
-        b[tid * PITCH + LAT + d] = (elem)(g * e * 0.5f * sd + kb * 0.5f * (sd * sd - 1.0f));  // d lv (columns past dz)
-      }
-      for (int d = 2 * LAT; d < pad; ++d) b[tid * PITCH + d] = (elem)0.f;
+    const int row = tid & 31, d = tid >> 5;  // one (batch row, latent dimension) per thread, as in the forward pass
+    if (d < LAT) {
+      const float mu = zs[row * ZP + d], lv = zs[row * ZP + LAT + d];
+      const float sd = expf(0.5f * lv);
+      const float e = a.sample ? gauss_eps(a.seed, a.step + st.step_off, st.row0 + m0 + row, d) : 0.f;
+      const float g = (float)b[row * PITCH + d];
+      const float kb = m0 + row < st.rows ? st.gs * a.kl_weight * st.inv_b : 0.f;
+      b[row * PITCH + d] = (elem)(g + kb * mu);                                          // d mu (in place)
+      b[row * PITCH + LAT + d] = (elem)(g * e * 0.5f * sd + kb * 0.5f * (sd * sd - 1.0f));  // d lv (columns past dz)
     }
+    for (int dd = 2 * LAT + d; dd < pad; dd += 32) b[row * PITCH + dd] = (elem)0.f;
   };
   // ---- backward: layer l consumes dZ_l (gs-scaled, in buf[cur]) and produces dZ_{l-1}
   for (int l = a.L - 1; l >= 1; --l) {
