@@ -484,7 +484,10 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       // one (batch row, latent dimension) per thread (latent <= 32 = 1,024 / 32): the draw of eps -- a hash, a logarithm,
       // a cosine -- was a serial loop over the latent dimensions in 32 threads (5 us of a 58-us step, forward + backward)
       const int LAT = ly.N >> 1, c1 = a.lt[l + 1].KS * 16;
-      const int row = tid & 31, d = tid >> 5;
+      const int row = tid & 31;
+      int d = tid >> 5;
+      asm volatile("" : "+v"(d));  // (keeps the draw below inside this branch: it is loop-invariant, and hoisted out of the
+                                   //  layer loop every model paid for it, variational or not: +35 % VALU instructions)
       float klt = 0.f;
       if (d < LAT) {
         const float mu = zs[row * ZP + d], lv = zs[row * ZP + LAT + d];
@@ -532,7 +535,9 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // gs * dL/dz (latent wide, in `b`) -> gs * dL/d[mu | lv] in place:  d mu = dz + beta mu,
   // d lv = dz eps exp(lv/2)/2 + beta (exp lv - 1)/2, beta = kl_weight / B (the KL term's own gradient)
   auto gauss_backward = [&](elem* b, int LAT, int pad) __attribute__((always_inline)) {
-    const int row = tid & 31, d = tid >> 5;  // one (batch row, latent dimension) per thread, as in the forward pass
+    const int row = tid & 31;  // one (batch row, latent dimension) per thread, as in the forward pass
+    int d = tid >> 5;
+    asm volatile("" : "+v"(d));  // (see the forward pass: keeps the draw out of the models that have no such layer)
     if (d < LAT) {
       const float mu = zs[row * ZP + d], lv = zs[row * ZP + LAT + d];
       const float sd = expf(0.5f * lv);
