@@ -96,6 +96,7 @@ SIGNATURES = {
     "v21_trainer_set_state": (C.c_int, [_P, C.c_int64, _F, _F, C.c_size_t]),
     "v21_trainer_get_grad": (C.c_int, [_P, _F, C.c_size_t]),
     "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
+    "v21_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
     "v21_trainer_chain_stamps": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     "v21_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
@@ -189,6 +190,13 @@ class Context:
 
     def set_stream(self, hip_stream):
         check(self.lib.v21_ctx_set_stream(self.h, _P(hip_stream)))
+
+    def poison_lds(self, pattern=0xFFFFFFFF):
+        """Diagnostics: fill every CU's LDS with ``pattern`` (NaN by default) before the next launch."""
+        check(self.lib.v21_debug_poison_lds(self.h, pattern))
+
+    def memset(self, dptr, byte, nbytes):
+        check(self.lib.v21_memset(self.h, _P(dptr), int(byte), int(nbytes)))
 
     def malloc(self, nbytes):
         p = _P()

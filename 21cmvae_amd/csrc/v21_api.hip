@@ -1622,6 +1622,10 @@ static int step_graph(v21_trainer* t, const float* x, long long ldx, const float
   *out = nullptr;
   for (auto& g : t->graphs)
     if (g.rows == rows && g.brows == brows && g.x == x && g.y == y && g.rw == rw && g.idx == d_idx && g.row0 == row0) {
+      // The lazy refresh of the packed weight copies is NOT part of the captured step (it was a no-op while the
+      // step was recorded): an arena rewritten between two replays (v21_mlp_set_weights, a loaded file) must reach
+      // the copies before the replayed kernels read them.
+      CHK(ensure_copies(t, !t->chain));
       *out = g.exec;
       return V21_OK;
     }
@@ -1700,6 +1704,7 @@ extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int ba
   bool replay = graph_eligible(t);
   if (replay) {  // one descriptor per step of this epoch
     CHK(ensure_desc(t, std::max<long long>(steps, kDescRing)));
+    HIPCHK(hipStreamSynchronize(st));  // a preceding step_dev's copy of the staging table may still be in flight
     for (long long s = 0; s < steps; ++s) t->h_desc[s] = StepDesc{s * batch, adam_alpha(t->adam, t->iter + s + 1), (int)s};
     CHK(publish_desc(t, steps));
     t->desc_epoch = true;
@@ -2138,6 +2143,8 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
   const long long steps = (n + batch - 1) / batch;
   for (v21_trainer* t : s->tr)
     if (t->steploss_cap < steps) {
+      HIPCHK(hipStreamSynchronize(st));
+      destroy_graphs(t);  // captured steps of this trainer hold the old pointer (as v21_trainer_run_epoch does)
       if (t->d_steploss) HIPCHK(hipFree(t->d_steploss));
       HIPCHK(hipMalloc((void**)&t->d_steploss, (size_t)steps * sizeof(float)));
       t->steploss_cap = steps;
@@ -2327,6 +2334,46 @@ extern "C" int v21_trainer_chain_stamps(v21_trainer* t, uint64_t* out, int n) {
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
   return V21_OK;
 }
+// ---- diagnostics: every CU's LDS filled with a bit pattern (tests/test_poison_gpu.py).  A fresh process finds LDS
+// benign; a kernel that relies on what LDS holds before it writes it (an uncleared padding column, a stale mask
+// tile) only shows when the previous tenant left NaN / Inf patterns there.  Each workgroup takes the whole 160 KB of
+// a CU (so at most one is resident per CU), writes the pattern, and idles for a while so that the dispatcher has to
+// spread the grid over all CUs instead of recycling the first ones that finish.
+__global__ void __launch_bounds__(256) lds_poison_kernel(unsigned pattern, int words, int spin, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned poison_smem[];
+  for (int i = threadIdx.x; i < words; i += 256) poison_smem[i] = pattern;
+  __syncthreads();
+  for (int k = 0; k < spin; ++k) __builtin_amdgcn_s_sleep(32);
+  // (read back, so that the stores cannot be dropped as dead)
+  if (poison_smem[(threadIdx.x * 37) % words] != pattern) atomicAdd(sink, 1u);
+}
+extern "C" int v21_debug_poison_lds(v21_ctx* c, uint32_t pattern) {
+  CHK(use(c));
+  constexpr int kBytes = 160 * 1024;
+  static bool attr_dev[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_dev[dev & 63]) {
+    HIPCHK(hipFuncSetAttribute((const void*)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
+    attr_dev[dev & 63] = true;
+  }
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, dev));
+  unsigned* sink = nullptr;
+  HIPCHK(hipMalloc((void**)&sink, 16));
+  HIPCHK(hipMemsetAsync(sink, 0, 16, c->stream));
+  // two workgroups per CU's worth of grid; each lingers ~2 us after its writes
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(2 * prop.multiProcessorCount), dim3(256), kBytes, c->stream, pattern,
+                     kBytes / 4, 64, sink);
+  HIPCHK(hipGetLastError());
+  unsigned bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, sink, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(sink));
+  if (bad) return fail(V21_ERR_HIP, "LDS read-back mismatch in %u threads", bad);
+  return V21_OK;
+}
+
 extern "C" int v21_trainer_use_graph(v21_trainer* t, int enable) {
   if (!t) return fail(V21_ERR_ARG, "null trainer");
   CHK(use(t->ctx));

@@ -193,8 +193,10 @@ class DirectEmulator(_EmulatorBase):
         self.emulator = h5lite.load_model(model_path)
         self.emulator.precision = prec
 
-    def train(self, epochs, callbacks=[], verbose="tqdm"):
-        """Train the emulator; returns (loss, val_loss) lists, one entry per epoch."""
+    def train(self, epochs, callbacks=[], verbose="tqdm", batch_size=256):
+        """Train the emulator; returns (loss, val_loss) lists, one entry per epoch.
+        ``batch_size`` (not in the reference, which hard-codes 256 at emulator.py:372): rows per optimizer
+        step, e.g. 4,096 per GPU for BASELINE configs[3]; the default is the reference's."""
         X_train = pp.par_transform(self.par_train, self.par_train)
         X_val = pp.par_transform(self.par_val, self.par_train)
         y_train = pp.preproc(self.signal_train, self.signal_train)
@@ -203,8 +205,8 @@ class DirectEmulator(_EmulatorBase):
         if verbose == "tqdm":
             callbacks.append(TqdmCallback())
             verbose = 0
-        hist = self.emulator.fit(x=X_train, y=y_train, batch_size=256, epochs=epochs,
-                                 validation_data=(X_val, y_val), validation_batch_size=256,
+        hist = self.emulator.fit(x=X_train, y=y_train, batch_size=batch_size, epochs=epochs,
+                                 validation_data=(X_val, y_val), validation_batch_size=batch_size,
                                  callbacks=callbacks, verbose=verbose)
         return hist.history["loss"], hist.history["val_loss"]
 
@@ -287,16 +289,18 @@ class AutoEncoderEmulator(_EmulatorBase):
         self.autoencoder = autoencoder
         self._chain_model = None
 
-    def train(self, epochs, ae_callbacks=[], em_callbacks=[], verbose="tqdm", joint=False):
+    def train(self, epochs, ae_callbacks=[], em_callbacks=[], verbose="tqdm", joint=False, batch_size=256):
         """Sequential two-phase recipe of the reference (emulator.py:701-768): fit the
         autoencoder x -> x, encode the signals with the frozen encoder, fit the emulator
         parameters -> latent.  Returns (ae_loss, ae_val_loss, loss, val_loss).
 
         ``joint=True`` (not in the reference; BASELINE configs[2]): both models take one optimizer step
         per batch on the SAME rows, the emulator's targets being the latents the encoder produces for those
-        rows in that step -- see ``_train_joint``."""
+        rows in that step -- see ``_train_joint``.
+        ``batch_size`` (not in the reference, which hard-codes 256 at emulator.py:742,759): rows per optimizer step."""
+        batch_size = int(batch_size)
         if joint:
-            return self._train_joint(epochs, ae_callbacks, em_callbacks, verbose)
+            return self._train_joint(epochs, ae_callbacks, em_callbacks, verbose, batch_size)
         y_train = pp.preproc(self.signal_train, self.signal_train)
         y_val = pp.preproc(self.signal_val, self.signal_train)
         ae_callbacks, em_callbacks = list(ae_callbacks), list(em_callbacks)
@@ -304,14 +308,14 @@ class AutoEncoderEmulator(_EmulatorBase):
             ae_callbacks.append(TqdmCallback())
             em_callbacks.append(TqdmCallback())
             verbose = 0
-        hist = self.autoencoder.fit(x=y_train, y=y_train, batch_size=256, epochs=epochs,
+        hist = self.autoencoder.fit(x=y_train, y=y_train, batch_size=batch_size, epochs=epochs,
                                     validation_data=(y_val, y_val), callbacks=ae_callbacks, verbose=verbose)
         ae_loss, ae_val_loss = hist.history["loss"], hist.history["val_loss"]
         X_train = pp.par_transform(self.par_train, self.par_train)
         X_val = pp.par_transform(self.par_val, self.par_train)
         z_train = self.autoencoder.encoder.predict(y_train)
         z_val = self.autoencoder.encoder.predict(y_val)
-        hist = self.emulator.fit(x=X_train, y=z_train, batch_size=256, epochs=epochs,
+        hist = self.emulator.fit(x=X_train, y=z_train, batch_size=batch_size, epochs=epochs,
                                  validation_data=(X_val, z_val), callbacks=em_callbacks, verbose=verbose)
         self._chain_model = None
         return ae_loss, ae_val_loss, hist.history["loss"], hist.history["val_loss"]

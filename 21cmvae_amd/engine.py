@@ -250,16 +250,20 @@ class Model:
     def _predict_on_devices(self, st, x, precision, devices, flags):
         from concurrent.futures import ThreadPoolExecutor
         reps = self.__dict__.setdefault("_replicas", {})
+        # trained weights newer than the host copies: pulled back ONCE (that bumps the layer versions, hence the
+        # signature below), so the replicas are refreshed once per change and not on every call after a fit()
+        self._sync_host()
         sig = (id(st), self._stack_sig, id(getattr(st, "_out_stats", None)))
         flat = None
         stacks = []
         for slot, d in enumerate(devices):  # one replica per LIST ENTRY (an ordinal may appear twice)
             key = (slot, d)
             ent = reps.get(key)
-            if ent is None or ent[0] != sig or self._dirty_host:
+            if ent is None or ent[0] != sig:
                 if flat is None:
                     flat = st.get_weights()
-                rs = ent[1] if ent is not None and ent[1].dims == st.dims else _native.Stack(_native.Context(d), st.dims, st.act)
+                same = ent is not None and ent[1].dims == st.dims and ent[1].act == st.act
+                rs = ent[1] if same else _native.Stack(_native.Context(d), st.dims, st.act)
                 rs.set_weights(flat)
                 if getattr(st, "_out_stats", None) is not None:
                     rs.set_output_transform(st._out_stats.std, st._out_stats.mean)

@@ -202,6 +202,61 @@ def cpu_baseline(weights_flat, x_f32, budget_s=6.0):
     return out
 
 
+PROFILE_TAG = "r3"  # profiles/<tag>/: the rocprofv3 summaries of this round (scripts/collect_profiles.sh)
+
+
+def _profile_kernels(name):
+    """(kernel name, calls, average ns) rows of a committed `rocprofv3 --kernel-trace --stats` summary, or None."""
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG, name)
+    if not os.path.exists(path):
+        return None
+    import csv
+    rows = []
+    for r in csv.DictReader(open(path)):
+        try:
+            rows.append((r["Name"], int(r["Calls"]), float(r["AverageNs"])))
+        except Exception:
+            pass
+    return rows
+
+
+def train_roofline(leg, flop_per_sample, params, din, dout, stats_csv, pmc_json):
+    """`roofline` object of a training leg: algorithmic FLOP per step over the measured step time against
+    the dense MFMA peak of the operand type; beside it the dominant kernels of the committed profile of the same
+    step (profiles/<tag>/<stats_csv>: average launch durations) and the HBM-side bytes per step from the PMC passes
+    (profiles/<tag>/<pmc_json>) against the algorithmic bytes of SURVEY 8d (batch rows in, 7 passes over the
+    parameter arena for Adam, one read of the packed weights)."""
+    B = leg["batch_per_gpu"]
+    prec = leg["precision"]
+    step_s = leg["ms_per_step"] * 1e-3
+    flop = flop_per_sample * B
+    alg_bytes = B * 4 * (din + (dout if dout != din else 0)) + 7 * 4 * params + (2 if prec != "f32" else 4) * params
+    rf = {"bound": "mfma", "achieved": flop / step_s / 1e12, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+          "frac": flop / step_s / 1e12 / PEAK_TFLOPS[prec], "algorithmic_flop_per_step": flop,
+          "algorithmic_bytes_per_step": alg_bytes, "traffic": None,
+          "time_base": "wall clock over the timed steps of this leg (whole step: every launch and the gaps between them)"}
+    rows = _profile_kernels(stats_csv)
+    if rows:
+        ks = [r for r in rows if "v21::" in r[0] and r[1] >= 10]
+        ks.sort(key=lambda r: -r[1] * r[2])
+        rf["kernels"] = [{"kernel": k[0][:90], "calls": k[1], "avg_us": k[2] / 1e3} for k in ks[:4]]
+        if ks:
+            rf["kernel"] = ks[0][0][:90]
+            rf["kernel_ms"] = ks[0][2] / 1e6
+        rf["kernel_source"] = "profiles/%s/%s (rocprofv3 --kernel-trace --stats of scripts/train_probe.py at this batch)" % (PROFILE_TAG, stats_csv)
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG, pmc_json)
+    if os.path.exists(path):
+        try:
+            pm = json.load(open(path))
+            tot = sum(v.get("hbm_bytes_per_launch", 0.0) for k, v in pm.items()
+                      if isinstance(v, dict) and v.get("FETCH_SIZE", {}).get("dispatches", 0) >= 10)
+            rf["traffic"] = tot
+            rf["traffic_source"] = "profiles/%s/%s: sum over the step's kernels of 2*FETCH_SIZE*1024 + WRITE_SIZE*1024" % (PROFILE_TAG, pmc_json)
+        except Exception:
+            pass
+    return rf
+
+
 AE_DIMS = [451, 352, 9, 32, 352, 451]   # encoder 451->352->9, decoder 9->32->352->451 (emulator.py:522-524)
 AE_ACT = [1, 0, 1, 1, 0]
 AE_FLOP_PER_SAMPLE = 1675840             # SURVEY 8d: 6 x 332,224 - 2 x 158,752
@@ -380,6 +435,7 @@ def fit_leg(precision, epochs=30, n_train=None, joint=False):
     emu = importlib.import_module("21cmvae_amd.emulator")
     optm = importlib.import_module("21cmvae_amd.optimizers")
     data = synth.make_dataset(n_train) if n_train else synth.make_dataset()
+    importlib.import_module("21cmvae_amd.engine").set_random_seed(1234)  # same initial weights and shuffles in every leg and run
     ae = emu.AutoEncoderEmulator(precision=precision, **data)
     ae.autoencoder.compile(optimizer=optm.Adam(1e-3), loss=emu.relative_mse_loss(ae.signal_train))
     ae.emulator.compile(optimizer=optm.Adam(1e-3), loss=emu.mean_squared_error)
@@ -577,6 +633,40 @@ def main():
             except Exception as e:  # pragma: no cover
                 modes[prec] = {"error": str(e)}
         out["other_precisions_1gpu"] = modes
+        # Stacks WITHOUT a compiled fused kernel (csrc/archs.h holds four): what a custom `hidden_dims`
+        # (emulator.py:12-48) or a sweep member's predict() gets.  `predict_generic_S1`: the headline stack forced
+        # down that route (V21_FWD_FORCE_GENERIC), same 65,536 rows; `predict_custom`: the sample notebook's
+        # 7 -> [64, 128] -> 451 model (notebooks/sample_notebook.ipynb cell 9) on its default route.
+        def fwd_rate(stk, dims, prec, fl, n=10):
+            for _ in range(2):
+                stk.forward_dev(d_x, dims[0], B, d_y, dims[-1], prec, fl)
+            ctx.sync()
+            a, b = ctx.event(), ctx.event()
+            ctx.record(a)
+            for _ in range(n):
+                stk.forward_dev(d_x, dims[0], B, d_y, dims[-1], prec, fl)
+            ctx.record(b)
+            ctx.sync()
+            ms = ctx.elapsed_ms(a, b) / n
+            flop = 2 * sum(p * q for p, q in zip(dims[:-1], dims[1:])) * B
+            return {"signals_per_s": B / (ms * 1e-3), "ms_per_launch_set": ms, "precision": prec,
+                    "frac_of_peak": flop / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[prec],
+                    "hbm_frac_of_8TBps": 4 * (dims[0] + dims[-1]) * B / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        try:
+            gen = {}
+            for prec in ("f16", "f32"):
+                gen[prec] = fwd_rate(stack, DIMS, prec, flags | native.FWD_FORCE_GENERIC)
+                gen[prec]["slowdown_vs_fused"] = (out["value"] if prec == args.precision else modes.get(prec, {}).get("signals_per_s", 0.0)) / gen[prec]["signals_per_s"]
+            out["predict_generic_S1"] = gen
+            cdims = [7, 64, 128, 451]
+            cst = native.Stack(ctx, cdims, [1, 1, 0])
+            cst.set_weights(glorot(cdims, seed=5))
+            cst.set_input_transform(ps.log_mask, ps.zero_floor, ps.lo, ps.hi)
+            cst.set_output_transform(ss.std, ss.mean)
+            out["predict_custom"] = {prec: fwd_rate(cst, cdims, prec, flags) for prec in ("f16", "f32")}
+            out["predict_custom"]["model"] = "7->[64,128]->451 (notebooks/sample_notebook.ipynb), %d rows, device-resident" % B
+        except Exception as e:
+            out["predict_generic_S1"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # host numpy -> numpy predict (PCIe-inclusive); never the headline value
         for _ in range(2):  # first calls pin the pooled result buffers
             yk = stack.forward(params, args.precision, flags)
@@ -614,6 +704,10 @@ def main():
                 tl = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
                                args.train_batch, args.precision, args.train_steps, 5)
                 tl["transport"] = transport
+                ae_params = sum(k * n + n for k, n in zip(AE_DIMS[:-1], AE_DIMS[1:]))
+                tl["roofline"] = train_roofline(tl, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
+                                                "kernel_stats_train_b%d_%s.csv" % (args.train_batch, args.precision),
+                                                "pmc_train_b%d_%s.json" % (args.train_batch, args.precision))
                 out["train"] = tl
                 if world > 1:  # the other exchange: reduce-scatter -> Adam on each rank's slice -> all-gather
                     ctx.comm_set_sharded(True)
@@ -624,8 +718,17 @@ def main():
                     out["train_sharded_adam"] = ts
                     ctx.comm_set_sharded(False)
                 if world == 1 and not args.no_extras:
-                    out["train_ref_batch256_f32"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
-                                                              sync_all, 256, "f32", 200, 10)
+                    t32 = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier, sync_all, 256, "f32", 200, 10)
+                    t32["roofline"] = train_roofline(t32, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
+                                                     "kernel_stats_train_b256_f32.csv", "pmc_train_b256_f32.json")
+                    out["train_ref_batch256_f32"] = t32
+                    # does the step scale with the batch?  (the MFMA fraction must RISE with the batch)
+                    t16k = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier, sync_all, 16384,
+                                     args.precision, max(10, args.train_steps // 2), 5)
+                    t16k["roofline"] = train_roofline(t16k, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
+                                                      "kernel_stats_train_b16384_%s.csv" % args.precision,
+                                                      "pmc_train_b16384_%s.json" % args.precision)
+                    out["train_b16384"] = t16k
                     out["train_variational"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
                                                          sync_all, args.train_batch, args.precision, args.train_steps, 5,
                                                          variational=True)

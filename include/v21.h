@@ -195,6 +195,11 @@ int v21_joint_run_epoch(v21_joint* j, const int32_t* perm /* nullable */, int ba
  * the host thread, it does not shorten a step); V21_ERR_UNSUPPORTED with a communicator or a
  * V21_ACT_GAUSS layer.  Replaces nothing in the reference (Keras fit, emulator.py:369-378, has no analogue). */
 int v21_trainer_use_graph(v21_trainer* tr, int enable);
+/* diagnostics ("race detection / sanitizers": GPU AddressSanitizer is not available on this
+ * pool): fills the whole LDS of every CU with `pattern` (e.g. 0xFFFFFFFF = NaN as fp32, f16 and bf16) and returns
+ * when that is done.  The poison tests launch it immediately before each kernel that keeps activations in LDS, so
+ * that a column or mask tile read before it is written meets NaN instead of a fresh process's zeros. */
+int v21_debug_poison_lds(v21_ctx* ctx, uint32_t pattern);
 /* diagnostics: s_memtime stamps of workgroup 0 of the last chain-kernel launch (train_chain.h):
  * [0] start, [1] batch gathered, [2..L+1] after forward layer l, [L+2] loss reduced,
  * [L+3..] after each backward layer (top down).  V21_ERR_STATE when the trainer runs the

@@ -135,3 +135,19 @@ def test_losses_row_weights_and_identity():
     np.testing.assert_allclose(losses.row_weight_fn("mse")(y_true), 1 / 451)
     with pytest.raises(ValueError):
         losses.row_weight_fn(lambda a, b: a - b)
+
+
+def test_shipped_models_learning_rates_are_members_of_the_float32_plateau_sequence():
+    """A free pin of the [K] ReduceLROnPlateau state machine on the reference's own artefacts: the learning rates
+    stored in the `training_config` of the shipped models/autoencoder_based_emulator/{ae_emulator,autoencoder}.h5
+    (tests/golden/ae_path_weights.npz, written by make_weights_fixture.py) are, BIT FOR BIT as float32, what the
+    callback produces from Adam(0.01) after 34 and 20 reductions by 0.9 -- i.e. new = float64(float32(lr)) * factor,
+    stored back as float32 -- and are no member of the sequences a float64 learning rate would produce."""
+    import os
+    from conftest import GOLDEN
+    d = np.load(os.path.join(GOLDEN, "ae_path_weights.npz"))
+    for stem, k in (("ae_emulator", 34), ("autoencoder", 20)):
+        shipped = np.float32(d[stem + "/adam_learning_rate"])
+        _, lrs = _plateau_lrs(0.01, 0.9, 0.0, k)
+        assert np.float32(lrs[-1]) == shipped, (stem, lrs[-1], float(shipped))
+        assert shipped not in np.float32(lrs[:-1])

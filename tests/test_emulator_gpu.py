@@ -89,6 +89,53 @@ def test_direct_emulator_train_returns_keras_history(data):
         emulator.DirectEmulator(hidden_dims=[8], **data).train(epochs=1, verbose=0)  # not compiled
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_train_batch_size_4096_through_the_class_surface(precision):
+    """``train(..., batch_size=)`` (the reference hard-codes 256, emulator.py:372): BASELINE configs[3]'s per-GPU
+    batch of 4,096 rows through DirectEmulator.train -- two full batches and a partial one per epoch -- against the
+    float64 oracle driven with the same initial weights and the same shuffles: epoch loss, validation loss,
+    optimizer step count."""
+    import copy
+    emulator, optm, eng, synth = pkg("emulator"), pkg("optimizers"), pkg("engine"), pkg("synth")
+    data = synth.make_dataset(n_train=9000, n_val=500, n_test=50, seed=4)
+    eng.set_random_seed(11)
+    direm = emulator.DirectEmulator(hidden_dims=[64, 128], precision=precision, **data)
+    direm.emulator.compile(optimizer=optm.Adam(2e-3), loss=emulator.relative_mse_loss(direm.signal_train))
+    W = [a.astype(np.float64) for a in direm.emulator.get_weights()[0::2]]
+    b = [a.astype(np.float64) for a in direm.emulator.get_weights()[1::2]]
+    rng = copy.deepcopy(eng._rng)  # the shuffles train() is about to draw
+    loss, val_loss = direm.train(epochs=2, verbose=0, batch_size=4096)
+    assert direm.emulator.optimizer.iterations == 2 * 3
+    X = ora.par_transform(data["par_train"], data["par_train"])
+    Xv = ora.par_transform(data["par_val"], data["par_train"])
+    Y = ora.preproc(data["signal_train"], data["signal_train"]).astype(np.float64)
+    Yv = ora.preproc(data["signal_val"], data["signal_train"]).astype(np.float64)
+    w = ora.relative_mse_row_weight(Y, data["signal_train"]).astype(np.float64)
+    wv = ora.relative_mse_row_weight(Yv, data["signal_train"]).astype(np.float64)
+    X, Xv = X.astype(np.float32).astype(np.float64), Xv.astype(np.float32).astype(np.float64)  # Keras casts x to float32 [K]
+    sto = ora.AdamState(sum(a.size for a in W) + sum(a.size for a in b), dtype=np.float64, lr=2e-3)
+    tol = 5e-5 if precision == "f32" else 5e-3
+    for ep in range(2):
+        perm = rng.permutation(9000)
+        tot = 0.0
+        for s0 in range(0, 9000, 4096):
+            idx = perm[s0:s0 + 4096]
+            W, b, l, _ = ora.train_step(W, b, sto, X[idx], Y[idx], w[idx], np.float64)
+            tot += l * len(idx)
+        lo = tot / 9000
+        vo = ora.evaluate(W, b, Xv, Yv, wv, 4096, np.float64)
+        assert abs(loss[ep] - lo) / lo < tol, (ep, loss[ep], lo)
+        assert abs(val_loss[ep] - vo) / vo < tol, (ep, val_loss[ep], vo)
+    # the autoencoder-based emulator takes the same keyword on both recipes
+    aee = emulator.AutoEncoderEmulator(precision="f16", enc_hidden_dims=[64], dec_hidden_dims=[32, 64], em_hidden_dims=[64], **data)
+    aee.autoencoder.compile(optimizer=optm.Adam(1e-3), loss=emulator.relative_mse_loss(aee.signal_train))
+    aee.emulator.compile(optimizer=optm.Adam(1e-3), loss=emulator.mean_squared_error)
+    for joint in (False, True):
+        out = aee.train(epochs=1, verbose=0, joint=joint, batch_size=4096)
+        assert all(len(h) == 1 and np.isfinite(h[0]) for h in out)
+    assert aee.autoencoder.optimizer.iterations == aee.emulator.optimizer.iterations == 2 * 3
+
+
 def test_autoencoder_emulator_load_predict_shipped_weights(data, shipped):
     """AutoEncoderEmulator.load_model default paths (packaged conversions of the reference's
     files) + predict through the fused chain; reference tests/test_emulator.py:88-102."""

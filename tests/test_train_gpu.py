@@ -735,6 +735,41 @@ def test_replayed_steps_follow_data_and_state_changes(ctx):
     trv.use_graph(False)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_replayed_steps_see_weights_set_between_replays(ctx, prec):
+    """the lazy refresh of the packed weight copies is not part of a captured step.  An epoch
+    with captured steps, then Stack.set_weights(new), then another epoch: the replayed steps must run on the NEW
+    weights -- identical, bit for bit, to the same sequence executed eagerly."""
+    native, synth = pkg("_native"), pkg("synth")
+    dims, act = [451, 40, 9, 24, 451], [1, 0, 1, 0]
+    sig = synth.make_signals(256, seed=19)
+    y = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    W2, b2 = ora.init_mlp(dims, seed=77)
+    res = {}
+    for graph in (True, False):
+        Ws, bs = ora.init_mlp(dims, seed=21)
+        st = native.Stack(ctx, dims, act)
+        st.set_weights(ora.flatten_params(Ws, bs))
+        tr = native.Trainer(st, prec, 128)
+        tr.use_graph(graph)
+        tr.set_adam(lr=2e-3)
+        tr.set_data(0, y, None, w)
+        losses = [tr.run_epoch(None, 128)]
+        st.set_weights(ora.flatten_params(W2, b2))      # the arena is rewritten behind the captured steps
+        losses.append(tr.run_epoch(None, 128))
+        res[graph] = (np.array(losses), st.get_weights())
+    np.testing.assert_array_equal(res[True][0], res[False][0])
+    np.testing.assert_array_equal(res[True][1], res[False][1])
+    # and the second epoch really started from the new weights: its first-batch loss level is the new model's
+    h = y[:128].astype(np.float64)
+    for W_, b_, a_ in zip(W2, b2, act):
+        h = h @ W_.astype(np.float64) + b_.astype(np.float64)
+        h = np.maximum(h, 0) if a_ else h
+    l0 = float(np.mean(ora.per_sample_loss(h, y[:128].astype(np.float64), w[:128].astype(np.float64))))
+    assert abs(res[True][0][1] - l0) / l0 < 0.2, (res[True][0][1], l0)   # (epoch mean of two nearby batches vs batch 1)
+
+
 # ---- BASELINE configs[2]: latent emulator at full width, and the joint enc + dec + emulator step ----------------
 @pytest.mark.parametrize("prec", ["f32", "f16"])
 def test_latent_emulator_full_width_mse_matches_oracle(ctx, prec):
