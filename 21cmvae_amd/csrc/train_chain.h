@@ -108,6 +108,10 @@ struct ChainStep {
   // validation pass: gather, forward and loss only -- nothing is written but the loss accumulator, so the launch may
   // cover ANY number of rows (the weight-gradient operands, sized for max_batch, are not touched)
   int fwd_only;
+  // one-launch step (train_step.h): after the stores of a layer's weight-gradient operand have left the wave, the
+  // number of fragments it wrote is added to ready[layer] (release at agent scope: the consumers run on other XCDs).
+  // nullptr: no signalling (two-launch steps, sweeps, the joint step, validation)
+  unsigned* ready;
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
@@ -330,13 +334,17 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // `tiles`: tile count of the contraction that follows.  The waves WITHOUT a tile in it do the flush while the
   // others already stream their weights (measured: done by everyone at the head of the layer it cost 6.3 k
   // cycles of the 67 k; `act` does not change during the layer, so there is no ordering to keep).
-  auto flush_t = [&](const elem* act, int F, void* dst, int tiles) __attribute__((always_inline)) {
+  auto flush_t = [&](const elem* act, int F, void* dst, int tiles, int layer) __attribute__((always_inline)) {
     const int nfrag = 2 * ((F + 31) >> 5);
     frag* d = reinterpret_cast<frag*>(dst);
     const int g = lane >> 4, i = lane & 15;
     const int w0 = tiles < NW ? tiles : 0;  // waves [0, w0) have a tile (every wave has one: all of them flush)
+    // (Ended waves leave the barrier count on gfx950: a wave that returns here -- or a prefetcher / loader wave that
+    //  returns before the compute waves' last s_barrier elsewhere in this file -- does not hold the others up.)
     if (wave < w0 || st.fwd_only) return;
+    int mine = 0;
     for (int id = wave - w0; id < nfrag; id += NW - w0) {
+      ++mine;
       const int ft = id >> 1, q2 = id & 1;
       const int r0 = 16 * q2 + 8 * (g >> 1);
       const elem* p = act + (r0 + (i >> 2)) * PITCH + 32 * ft + 16 * (g & 1) + 4 * (i & 3);
@@ -349,6 +357,12 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       }
       if (32 * ft + (lane & 31) < F)
         d[((long long)ft * a.BS + (m0 >> 4) + q2) * 64 + lane] = __builtin_bit_cast(frag, v);
+    }
+    if (st.ready && mine > 0) {
+      // release at agent scope (this XCD's L2 written back: the weight-gradient workgroups of train_step.h read
+      // these fragments on other XCDs), then the count.  The wave has no tile in this layer, or it is the last flush.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0) __hip_atomic_fetch_add(st.ready + layer, (unsigned)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
 
@@ -413,7 +427,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
     const int nch = ly.KS >> 2;
-    flush_t(act, ly.K, ly.ht16, ly.NT);  // this layer's input -> operand of its weight gradient
+    flush_t(act, ly.K, ly.ht16, ly.NT, l);  // this layer's input -> operand of its weight gradient
     const float wi = rwl[li];
     for (int t = wave; t < ly.NT; t += NW) {
       const int n0 = 32 * t;
@@ -557,7 +571,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     elem* out = buf[cur ^ 1];
     const int nch = ly.NS >> 2;
     if (ly.gauss) { gauss_backward(buf[cur], ly.N >> 1, ly.NS * 16); chain_barrier(); }
-    flush_t(act, ly.N, ly.dzt16, ly.KT);  // gs * dZ of this layer's output -> operand of its weight gradient
+    flush_t(act, ly.N, ly.dzt16, ly.KT, l);  // gs * dZ of this layer's output -> operand of its weight gradient
     for (int t = wave; t < ly.KT; t += NW) {
       const int k0 = 32 * t;
       f32x16 acc;
@@ -586,7 +600,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
   if (a.lt[0].gauss) { gauss_backward(buf[cur], a.lt[0].N >> 1, a.lt[0].NS * 16); chain_barrier(); }
-  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
+  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0, 0);
 }
 
 // ---- weight gradients from the fragment-ordered operands: [dW; db](k, n) = sum_b HT(k, b) dZT(n, b).

@@ -25,6 +25,7 @@
 #include "train_kernels.h"
 #include "train_chain.h"
 #include "dw_adam.h"
+#include "train_step.h"
 
 using namespace v21;
 
@@ -128,6 +129,7 @@ struct v21_ctx {
   float* h_stage = nullptr;
   size_t h_stage_n = 0;
   int sharded = 0;  // 1: reduce-scatter -> Adam on this rank's shard -> all-gather (v21_comm_set_sharded)
+  int ncu = 0;      // compute units of the device (the one-launch step never launches more workgroups than that)
 };
 // ncclDataType_t / ncclRedOp_t values of rccl.h (the library is dlopen'ed, its header is not included)
 constexpr int kNcclFloat32 = 7, kNcclSum = 0;
@@ -148,6 +150,11 @@ extern "C" int v21_ctx_create(int device, v21_ctx** out) {
   hipError_t e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail(V21_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
   c->stream = c->own;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->ncu = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+  }
   *out = c;
   return V21_OK;
 }
@@ -757,6 +764,13 @@ struct v21_trainer {
   std::vector<void*> d_ht16, d_dzt16;  // fragment-ordered weight-gradient operands (train_chain.h)
   long long BS = 0;                    // batch steps of 16 per feature tile
   unsigned long long* d_stamps = nullptr;
+  // one-launch step (train_step.h): counters, tile queues, device copy of the gradient / Adam block
+  bool fused_step = false;
+  StepSync* d_sync = nullptr;
+  int* d_order = nullptr;
+  int qfirst[kStepQueues + 1] = {};
+  DwAdamModel* d_dwtab = nullptr;
+  std::vector<DwAdamModel> h_dwtab;
   // ---- replayed steps (hipGraph).  One optimizer step is captured once per (rows, global rows, data pointers)
   // and replayed; what differs between steps comes from a device table of StepDesc (train_kernels.h) that the
   // host fills for the steps ahead: an epoch's steps in run_epoch, the next kDescRing steps in step_dev.
@@ -877,6 +891,29 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
         HIPCHK(hipStreamSynchronize(st));
       }
       t->chain = true;
+      {  // tile queues of the one-launch step: queue x = its eighth of every layer's tiles (row-major runs: the tiles
+         // of a run share their A rows), top layer first -- the order in which the operands become complete
+        const char* envf = getenv("V21_STEP_FUSED");
+        std::vector<int> first(L + 1, 0), ntile(L, 0);
+        for (int l = 0; l < L; ++l) {
+          ntile[l] = ((m->dims[l] + 1 + 31) / 32) * ((m->nw(l) + 31) / 32);
+          first[l + 1] = first[l] + ntile[l];
+        }
+        std::vector<int> order;
+        for (int x = 0; x < kStepQueues; ++x) {
+          t->qfirst[x] = (int)order.size();
+          for (int l = L - 1; l >= 0; --l)
+            for (int i = (int)((long long)ntile[l] * x / kStepQueues); i < (int)((long long)ntile[l] * (x + 1) / kStepQueues); ++i)
+              order.push_back(first[l] + i);
+        }
+        t->qfirst[kStepQueues] = (int)order.size();
+        HIPCHK(hipMalloc((void**)&t->d_order, order.size() * sizeof(int) + 16));
+        HIPCHK(hipMemcpyAsync(t->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMalloc((void**)&t->d_sync, sizeof(StepSync)));
+        HIPCHK(hipMemsetAsync(t->d_sync, 0, sizeof(StepSync), st));
+        HIPCHK(hipStreamSynchronize(st));  // `order` is a host temporary
+        t->fused_step = !(envf && envf[0] == '0') && t->ctx->ncu >= 16;
+      }
     }
   }
   t->max_slices = std::max(1, (max_batch + 127) / 128);  // weight-gradient slices down to 8 batch steps
@@ -906,6 +943,9 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   if (t->d_steploss) hipFree(t->d_steploss);
   if (t->d_slab) hipFree(t->d_slab);
   if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
+  if (t->d_sync) hipFree(t->d_sync);
+  if (t->d_order) hipFree(t->d_order);
+  if (t->d_dwtab) hipFree(t->d_dwtab);
   if (t->chain) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_partial); hipFree(t->d_ticket); hipFree(t->d_stamps);
     for (void* p : t->d_ht16) if (p) hipFree(p);
     for (void* p : t->d_dzt16) if (p) hipFree(p); }
@@ -1332,7 +1372,9 @@ static int chain_attr(int prec) {
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_joint_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)train_step_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
   } else {
+    HIPCHK(hipFuncSetAttribute((const void*)train_step_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_joint_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
@@ -1341,9 +1383,9 @@ static int chain_attr(int prec) {
   return V21_OK;
 }
 // prefetcher workgroups per XCD for a launch of `models` x `ncons` row-block workgroups: the CUs the row blocks leave idle
-static int chain_prefetchers(int ncons, int models) {
+static int chain_prefetchers(int ncons, int models, int ncu = 256) {
   if (models > 1) return 0;  // a sweep: measured slower with them (8 models, 24 prefetchers each: 106 k -> 95 k model-steps/s)
-  const int idle = 256 - ncons;
+  const int idle = ncu - ncons;
   return idle >= 8 ? std::min(8, idle / 8) : 0;
 }
 static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
@@ -1515,6 +1557,55 @@ static int launch_dw_adam_group(const std::vector<v21_trainer*>& tr, const DwAda
   return V21_OK;
 }
 
+// ---- single rank, the step fits one workgroup per CU: the whole step in ONE launch (train_step.h)
+static bool step_fused_eligible(const v21_trainer* t, int rows) {
+  const int ncons = ((rows + 31) / 32 + 7) / 8 * 8;
+  return t->fused_step && t->chain && t->ctx->nranks == 1 && rows > 0 && ncons + 8 <= t->ctx->ncu;
+}
+static int launch_step_fused(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
+                             const int* d_idx, long long first, int rows, int brows, long long row0, float alpha, int slot) {
+  v21_mlp* m = t->mlp;
+  hipStream_t st = t->ctx->stream;
+  CHK(chain_attr(t->prec));
+  if (!t->capturing) CHK(refresh_dw_adam_table({t}, &t->d_dwtab, t->h_dwtab, st));  // (captured steps: refreshed by step_graph)
+  ChainArgs a{};
+  static_cast<ChainModel&>(a) = chain_model(t);
+  static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, m->dims[m->L], t, row0);
+  const int nrb = (rows + 31) / 32;
+  a.ncons = (nrb + 7) / 8 * 8;
+  a.npref = chain_prefetchers(a.ncons, 1, t->ctx->ncu);
+  a.ready = t->d_sync->ready;
+  DwAdamStep ds{};
+  ds.steps = (rows + 15) / 16;
+  ds.slot = slot;
+  ds.alpha[0] = alpha;
+  ds.out_scale[0] = 1.0f / grad_opscale(brows, m->dims[m->L]);
+  ds.sc = step_ctx(t);
+  StepPlan pl{};
+  pl.sync = t->d_sync; pl.order = t->d_order; pl.model = t->d_dwtab;
+  for (int x = 0; x <= kStepQueues; ++x) pl.qfirst[x] = t->qfirst[x];
+  for (int l = 0; l < m->L; ++l)
+    pl.expect[l] = (unsigned)nrb * (unsigned)(2 * ((m->dims[l] + 31) / 32) + 2 * ((m->nw(l) + 31) / 32));
+  // one workgroup per CU at most (158 KB of LDS each): the row blocks first, every CU beyond them a worker from the start
+  const int total = std::min(t->ctx->ncu, std::max(a.ncons + 8 * a.npref, t->qfirst[kStepQueues] + a.ncons));
+  const dim3 grid(total), block(64 * kChainWaves);
+  if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_step_kernel<PrecF16>, grid, block, kChainLdsBytes, st, a, ds, pl);
+  else hipLaunchKernelGGL(train_step_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, a, ds, pl);
+  HIPCHK(hipGetLastError());
+  t->copies_ok = true;
+  t->nt_ok = false;
+  return V21_OK;
+}
+// a wait of the one-launch step that ran into its limit (train_step.h: step_wait) -- reported at the next synchronising call
+static int step_sync_check(v21_trainer* t) {
+  if (!t->d_sync) return V21_OK;
+  unsigned err = 0;
+  HIPCHK(hipMemcpyAsync(&err, &t->d_sync->error, sizeof err, hipMemcpyDeviceToHost, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  if (err) return fail(V21_ERR_HIP, "one-launch training step: a weight-gradient workgroup waited for operands that never became complete");
+  return V21_OK;
+}
+
 static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out,
                         long long row0);
 // one optimizer step on rows [first, first+rows) (through d_idx when given) of (x, y, rw)
@@ -1532,13 +1623,16 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
     CHK(ensure_copies(t, false));
-    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
+    const bool one_launch = step_fused_eligible(t, rows);
+    if (!one_launch) CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
     if (t->ctx->nranks == 1) {  // nothing to exchange: gradients, Adam and the packed copies in one launch
       if (!t->capturing) t->iter += 1;
       // an epoch's per-step loss slot is written by the kernel itself (a device-to-device copy per step is a launch)
       const bool in_table = loss_out && t->d_steploss && loss_out >= t->d_steploss && loss_out < t->d_steploss + t->steploss_cap;
-      CHK(launch_dw_adam(t, rows, brows, t->capturing ? 0.f : adam_alpha(t->adam, t->iter),
-                         in_table ? (int)(loss_out - t->d_steploss) : -1));
+      const float alpha = t->capturing ? 0.f : adam_alpha(t->adam, t->iter);
+      const int slot = in_table ? (int)(loss_out - t->d_steploss) : -1;
+      if (one_launch) CHK(launch_step_fused(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, alpha, slot));
+      else CHK(launch_dw_adam(t, rows, brows, alpha, slot));
       if (t->capturing) return V21_OK;
       if (loss_out && !in_table) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
       invalidate_streams(m);
@@ -1638,6 +1732,7 @@ static int step_graph(v21_trainer* t, const float* x, long long ldx, const float
   // everything that may not happen inside a capture: lazy refreshes, function attributes
   CHK(ensure_copies(t, !t->chain));
   if (t->chain) { CHK(chain_attr(t->prec)); CHK(dw16_attr(t->prec)); }
+  if (step_fused_eligible(t, rows)) CHK(refresh_dw_adam_table({t}, &t->d_dwtab, t->h_dwtab, st));
   hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { (void)hipGetLastError(); t->graph_mode = 0; return V21_OK; }  // e.g. the legacy stream: run eagerly
   t->capturing = true;
@@ -1731,6 +1826,7 @@ extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int ba
   std::vector<float> h(steps);
   HIPCHK(hipMemcpyAsync(h.data(), t->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  CHK(step_sync_check(t));
   double tot = 0.0;
   for (float v : h) tot += (double)v;  // each entry = batch_loss * n_b  ([K] epoch loss)
   *loss = tot / (double)n;
@@ -1839,6 +1935,7 @@ extern "C" int v21_trainer_last_step_loss(v21_trainer* t, double* loss) {
   float s = 0.f;
   HIPCHK(hipMemcpyAsync(&s, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  CHK(step_sync_check(t));
   *loss = (double)s;  // sum_i w_i sum_j (p-y)^2 over the global batch
   return V21_OK;
 }

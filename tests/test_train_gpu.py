@@ -567,6 +567,84 @@ def test_one_launch_gradient_adam_kernel_state_and_packed_copies(ctx, prec, dims
         ostate.m[:] = m; ostate.v[:] = v
 
 
+def _fit_steps(ctx, dims, act, prec, x, y, w, batch, epochs, fused, seed=31, vae=None):
+    import os
+    native = pkg("_native")
+    Ws, bs = ora.init_mlp(dims, seed=seed)
+    old = os.environ.get("V21_STEP_FUSED")
+    os.environ["V21_STEP_FUSED"] = "1" if fused else "0"
+    try:
+        st = native.Stack(ctx, dims, act)
+        if vae:
+            st.set_weights((np.random.default_rng(seed).normal(size=st.num_params) * 0.05).astype(np.float32))
+        else:
+            st.set_weights(ora.flatten_params(Ws, bs))
+        tr = native.Trainer(st, prec, batch)  # the switch is read when the trainer is created
+    finally:
+        if old is None:
+            os.environ.pop("V21_STEP_FUSED")
+        else:
+            os.environ["V21_STEP_FUSED"] = old
+    tr.set_adam(lr=1e-3)
+    if vae:
+        tr.set_vae(*vae)
+    tr.set_data(0, x, y, w)
+    n = x.shape[0]
+    losses, grads = [], []
+    for ep in range(epochs):
+        losses.append(tr.run_epoch(ora.epoch_permutation(n, 3, ep), batch))
+        grads.append(tr.get_grad().astype(np.float64))
+    it, m, v = tr.get_state()
+    return np.array(losses), grads, st.get_weights(), m, v, it
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("case", ["ae_b4096", "ae_b256_ragged", "direct_b1000", "vae_b512"])
+def test_one_launch_step_equals_two_launch_step(ctx, prec, case):
+    """csrc/train_step.h: the whole step in one launch (row blocks + weight-gradient workers signalling through
+    agent-scope counters) against the two-launch step (V21_STEP_FUSED=0: train_chain_kernel, then dw16_adam_kernel):
+    same chain arithmetic, the partial tiles summed over 16 waves instead of 8 -- so the first step's loss is
+    IDENTICAL and everything after agrees to fp32 summation order.  Several steps per epoch on different rows of every
+    batch: an operand fragment read before it was complete, or a stale copy of the previous step's fragment in another
+    XCD's L2, shows up as a gradient that is off by far more than that.  Run twice: the result must not depend on
+    which workgroup happened to take which tile."""
+    synth, native = pkg("synth"), pkg("_native")
+    vae = None
+    if case == "direct_b1000":
+        dims, act, n, batch = [7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0], 3000, 1000
+        par = synth.make_params(n, seed=3)
+        x = ora.par_transform(par, par).astype(np.float32)
+        sig = synth.signals_from_params(par)
+        y = ora.preproc(sig, sig)
+        w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    else:
+        dims, act = [451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0]
+        n, batch = {"ae_b4096": (3 * 4096 + 100, 4096), "ae_b256_ragged": (1000, 256), "vae_b512": (1536, 512)}[case]
+        if case == "vae_b512":
+            act = [1, native.ACT_GAUSS, 1, 1, 0]
+            vae = (1e-3, True, 7)
+        sig = synth.make_signals(n, seed=13)
+        x = ora.preproc(sig, sig); y = None
+        w = ora.relative_mse_row_weight(x, sig).astype(np.float32)
+    one = _fit_steps(ctx, dims, act, prec, x, y, w, batch, 2, fused=True, vae=vae)
+    again = _fit_steps(ctx, dims, act, prec, x, y, w, batch, 2, fused=True, vae=vae)
+    two = _fit_steps(ctx, dims, act, prec, x, y, w, batch, 2, fused=False, vae=vae)
+    for a, b in zip(one[:1] + one[2:5], again[:1] + again[2:5]):
+        np.testing.assert_array_equal(a, b)          # deterministic, whatever the tile-to-workgroup assignment
+    assert one[5] == two[5] == 2 * -(-n // batch)
+    np.testing.assert_allclose(one[0], two[0], rtol=2e-4)
+    for g1, g2 in zip(one[1], two[1]):
+        assert _cos(g1, g2) > 0.99999, _cos(g1, g2)
+        assert abs(np.linalg.norm(g1) / np.linalg.norm(g2) - 1) < 1e-4
+    # Adam amplifies summation-order differences of tiny gradients (m / sqrt(v)): compare the MOVEMENT of the weights
+    w0 = ora.flatten_params(*ora.init_mlp(dims, seed=31)).astype(np.float64) if vae is None else None
+    if w0 is not None:
+        d1, d2 = one[2] - w0, two[2] - w0
+        assert _cos(d1, d2) > 0.999, _cos(d1, d2)
+    np.testing.assert_allclose(one[3], two[3], rtol=0, atol=1e-3 * np.abs(two[3]).max())
+    np.testing.assert_allclose(one[4], two[4], rtol=0, atol=1e-3 * np.abs(two[4]).max())
+
+
 def test_chain_path_is_actually_used(ctx):
     """f16/bf16 trainers of stacks up to 512 wide (variational heads up to 32 latent dimensions) run the
     chain kernel (its stamps exist); f32, wider stacks and wider latents take the per-layer path."""
