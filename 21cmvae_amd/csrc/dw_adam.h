@@ -45,20 +45,13 @@ struct DwAdamStep {
 };
 constexpr int kDwAdamWaves = 8, kDwAdamInFlight = 8, kDwAdamPitch = 40;
 
-// LDS of one tile: NW partial accumulator tiles + the tile as 16-bit values
-template <int NW> constexpr int dw_adam_lds_bytes() { return NW * 16 * 64 * 4 + 32 * kDwAdamPitch * 2; }
-
-// NW waves (the whole workgroup) on one tile.  `smem`: dw_adam_lds_bytes<NW>() bytes, 16-byte aligned.
-// `before_packed`: called by every thread after the arena update and before the stores into the packed streams
-// (the one-launch step waits there until no row block reads this layer's backward fragments any more).
-template <class P, int NW, class BeforePacked>
-__device__ __forceinline__ void dw16_adam_tile(const DwAdamModel& md, const int lb, const float alpha, const float out_scale,
-                                               const int steps, const int slot, const StepCtx& sc, unsigned char* smem,
-                                               const bool do_loss, BeforePacked&& before_packed) {
+template <class P>
+__device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int lb, const float alpha, const float out_scale,
+                                               const int steps, const int slot, const StepCtx& sc) {
   using frag = typename P::frag;
-  constexpr int U = kDwAdamInFlight;
-  float(*part)[16][64] = reinterpret_cast<float(*)[16][64]>(smem);
-  unsigned short* pk = reinterpret_cast<unsigned short*>(smem + NW * 16 * 64 * 4);
+  constexpr int NW = kDwAdamWaves, U = kDwAdamInFlight;
+  __shared__ __attribute__((aligned(16))) float part[NW][16][64];
+  __shared__ __attribute__((aligned(16))) unsigned short pk[32 * kDwAdamPitch];
   int pi = 0;
   while (pi + 1 < md.L && lb >= md.lt[pi + 1].first) ++pi;  // scalar
   const DwAdamLayer& g = md.lt[pi];
@@ -66,7 +59,7 @@ __device__ __forceinline__ void dw16_adam_tile(const DwAdamModel& md, const int 
   const int ti = q / g.nt, tj = q - ti * g.nt;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (do_loss && g.loss_acc && q == 0 && tid == 0) {
+  if (g.loss_acc && q == 0 && tid == 0) {
     const float f = (float)((double)(long long)*g.loss_acc * (1.0 / 4294967296.0));
     *g.loss_out = f;
     if (g.loss_out2 && (sc.desc || slot >= 0)) g.loss_out2[sc.desc ? sc.desc[*sc.cur].slot : slot] = f;
@@ -74,16 +67,14 @@ __device__ __forceinline__ void dw16_adam_tile(const DwAdamModel& md, const int 
   }
   // this thread's two arena elements (tile rows tid/32 and tid/32 + 16, column tid%32): requested now, used
   // after the contraction.  Elements past the edge of [W; b] are clamped to a valid one and never stored.
-  constexpr int RPT = 1024 / (64 * NW);  // tile elements per thread: 2 (8 waves) or 1 (16 waves)
-  constexpr int RSTEP = 2 * NW;                                    // tile rows covered by one pass of the workgroup
   const int mrow0 = tid >> 5, ncol = tid & 31;
   const int n = 32 * tj + ncol;
-  long long idx[RPT];
-  bool ok[RPT];
-  float w0[RPT], m0[RPT], v0[RPT];
+  long long idx[2];
+  bool ok[2];
+  float w0[2], m0[2], v0[2];
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    const int k = 32 * ti + mrow0 + RSTEP * r;
+  for (int r = 0; r < 2; ++r) {
+    const int k = 32 * ti + mrow0 + 16 * r;
     ok[r] = k <= g.K && n < g.N;
     idx[r] = (long long)(k <= g.K ? k : g.K) * g.N + (n < g.N ? n : g.N - 1);
     w0[r] = g.w[idx[r]]; m0[r] = g.m[idx[r]]; v0[r] = g.v[idx[r]];
@@ -126,8 +117,8 @@ __device__ __forceinline__ void dw16_adam_tile(const DwAdamModel& md, const int 
   // ---- the eight partial tiles in a fixed order, Adam, the tile as 16-bit values for the packed copies.
   // element (row m, column c) of a 32 x 32 accumulator tile: lane c + 32 ((m % 8) / 4), register 4 (m / 8) + m % 4
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    const int mrow = mrow0 + RSTEP * r;
+  for (int r = 0; r < 2; ++r) {
+    const int mrow = mrow0 + 16 * r;
     const int reg = 4 * (mrow >> 3) + (mrow & 3), pl = ncol + 32 * ((mrow & 7) >> 2);
     float gi = part[0][reg][pl];
 #pragma unroll
@@ -143,7 +134,6 @@ __device__ __forceinline__ void dw16_adam_tile(const DwAdamModel& md, const int 
     else bits = __builtin_bit_cast(unsigned short, (__bf16)pv);
     pk[mrow * kDwAdamPitch + ncol] = bits;
   }
-  before_packed(pi);
   __syncthreads();
   typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
   if (wave < 2) {
@@ -179,9 +169,7 @@ template <class P>
 __global__ void __launch_bounds__(64 * kDwAdamWaves) dw16_adam_kernel(const DwAdamModel md, const DwAdamStep st) {
   const int lb = dw_adam_logical_block(md.nblk);
   if (lb >= md.nblk) return;
-  __shared__ __attribute__((aligned(16))) unsigned char dw_smem[dw_adam_lds_bytes<kDwAdamWaves>()];
-  dw16_adam_tile<P, kDwAdamWaves>(md, lb, st.sc.desc ? st.sc.desc[*st.sc.cur].alpha : st.alpha[0], st.out_scale[0], st.steps,
-                                  st.slot, st.sc, dw_smem, true, [](int) {});
+  dw16_adam_body<P>(md, lb, st.sc.desc ? st.sc.desc[*st.sc.cur].alpha : st.alpha[0], st.out_scale[0], st.steps, st.slot, st.sc);
 }
 // a group (sweep, joint step): blockIdx.y = model, the per-model blocks in device memory
 template <class P>
@@ -189,9 +177,7 @@ __global__ void __launch_bounds__(64 * kDwAdamWaves) dw16_adam_group_kernel(cons
   const DwAdamModel& md = tab[blockIdx.y];
   const int lb = dw_adam_logical_block(md.nblk);
   if (lb >= md.nblk) return;
-  __shared__ __attribute__((aligned(16))) unsigned char dw_smem[dw_adam_lds_bytes<kDwAdamWaves>()];
-  dw16_adam_tile<P, kDwAdamWaves>(md, lb, st.alpha[blockIdx.y], st.out_scale[blockIdx.y], st.steps, st.slot, st.sc, dw_smem,
-                                  true, [](int) {});
+  dw16_adam_body<P>(md, lb, st.alpha[blockIdx.y], st.out_scale[blockIdx.y], st.steps, st.slot, st.sc);
 }
 
 }  // namespace v21

@@ -108,14 +108,14 @@ struct ChainStep {
   // validation pass: gather, forward and loss only -- nothing is written but the loss accumulator, so the launch may
   // cover ANY number of rows (the weight-gradient operands, sized for max_batch, are not touched)
   int fwd_only;
-  // one-launch step (train_step.h): after the stores of a layer's weight-gradient operand have left the wave, the
-  // number of fragments it wrote is added to ready[layer] (release at agent scope: the consumers run on other XCDs).
-  // nullptr: no signalling (two-launch steps, sweeps, the joint step, validation)
-  unsigned* ready;
+  // joint step: the emulator's workgroups first run the ENCODER alone (forward layers [0, nfwd) of the autoencoder,
+  // nothing written but the captured latents) -- nfwd = 0: the whole stack
+  int nfwd;
+  int blk0;  // physical block blk0 is logical block 0 of this body (the joint kernel runs two families of row blocks)
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (physical block 0 is row block 0)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.stamps) {  // (physical block 0 is row block 0)
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     a.stamps[i] = t;
@@ -158,15 +158,31 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_group_kernel(con
   train_chain_body<P>(tab[blockIdx.y], st);
 }
 
-// joint step: the SAME workgroup carries its 32 rows through model A (the autoencoder, signals -> signals) and then
-// through model B (the latent emulator, parameters -> latent), whose targets are the rows model A's latent layer
-// left in LDS: the reference's frozen-encoder targets (emulator.py:753-754) without leaving the chip.
+// joint step (BASELINE configs[2]): the autoencoder (signals -> signals) and the latent emulator (parameters -> latent)
+// take one optimizer step each on the same rows, and the emulator's targets are the latents the encoder produces for
+// those rows in this very step: the reference's frozen-encoder targets (emulator.py:753-754) without leaving the chip.
+// TWO families of row-block workgroups run side by side (r2 ran both models one after the other in ONE workgroup: the
+// step lasted as long as the two chains together):
+//   blocks [0, ncons)          autoencoder: the plain chain body;
+//   blocks [ncons, 2 ncons)    emulator: first the ENCODER alone on these rows (forward layers [0, zcap_layer], ~2 of the
+//                              autoencoder's layers; the latents stay in LDS as fp32), then the emulator's chain body
+//                              with those latents as targets.  Recomputing the encoder costs ~1/6 of an autoencoder
+//                              pass and removes every dependence between the two families;
+//   blocks [2 ncons, ...)      prefetchers of both models' weight streams.
 template <class P>
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_joint_kernel(const ChainModel* __restrict__ tab /* [2], device */,
                                                                              const ChainStep sa, const ChainStep sb) {
-  if ((int)blockIdx.x >= sa.ncons) { chain_prefetch(tab[0], sa); chain_prefetch(tab[1], sa); return; }
-  train_chain_body<P>(tab[0], sa);
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // model A's last LDS reads precede model B's gather
+  if ((int)blockIdx.x >= 2 * sa.ncons) {
+    ChainStep sp = sa;
+    sp.ncons = 2 * sa.ncons;
+    chain_prefetch(tab[0], sp); chain_prefetch(tab[1], sp);
+    return;
+  }
+  if ((int)blockIdx.x < sa.ncons) { train_chain_body<P>(tab[0], sa); return; }
+  ChainStep se = sa;  // the encoder alone, for the emulator's rows
+  se.fwd_only = 1; se.nfwd = tab[0].zcap_layer + 1; se.blk0 = sa.ncons;
+  train_chain_body<P>(tab[0], se);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the encoder's last LDS accesses precede the emulator's gather
   train_chain_body<P>(tab[1], sb);
 }
 
@@ -206,7 +222,8 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // XCD x carries the CONSECUTIVE row blocks x * ceil(nb / 8) ...: the batch slice whose weight-gradient tiles
   // gemm_dw16* then runs on the same XCD, so that it finds the operands this kernel wrote in its own L2.
   const int nrb = (st.rows + 31) >> 5;
-  const int rb = (int)(blockIdx.x & 7) * ((nrb + 7) >> 3) + (int)(blockIdx.x >> 3);
+  const int bidx = (int)blockIdx.x - st.blk0;
+  const int rb = (bidx & 7) * ((nrb + 7) >> 3) + (bidx >> 3);
   if (rb >= nrb) return;  // (the grid is rounded up to a multiple of 8)
   const int m0 = rb * 32;
   const int vrows = st.rows - m0;  // valid rows of this block (>= 1; < 32 only in the last block)
@@ -334,17 +351,16 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // `tiles`: tile count of the contraction that follows.  The waves WITHOUT a tile in it do the flush while the
   // others already stream their weights (measured: done by everyone at the head of the layer it cost 6.3 k
   // cycles of the 67 k; `act` does not change during the layer, so there is no ordering to keep).
-  auto flush_t = [&](const elem* act, int F, void* dst, int tiles, int layer) __attribute__((always_inline)) {
+  auto flush_t = [&](const elem* act, int F, void* dst, int tiles) __attribute__((always_inline)) {
     const int nfrag = 2 * ((F + 31) >> 5);
     frag* d = reinterpret_cast<frag*>(dst);
     const int g = lane >> 4, i = lane & 15;
     const int w0 = tiles < NW ? tiles : 0;  // waves [0, w0) have a tile (every wave has one: all of them flush)
-    // (Ended waves leave the barrier count on gfx950: a wave that returns here -- or a prefetcher / loader wave that
-    //  returns before the compute waves' last s_barrier elsewhere in this file -- does not hold the others up.)
+    // (A wave that has ENDED leaves the barrier count on gfx950 -- the loader waves of gemm_dw16_lds_kernel below rely
+    //  on that when they return before the compute waves' last s_barrier.  Here nothing ends: this `return` leaves the
+    //  lambda, and every wave of the workgroup goes on to the layer's barrier.)
     if (wave < w0 || st.fwd_only) return;
-    int mine = 0;
     for (int id = wave - w0; id < nfrag; id += NW - w0) {
-      ++mine;
       const int ft = id >> 1, q2 = id & 1;
       const int r0 = 16 * q2 + 8 * (g >> 1);
       const elem* p = act + (r0 + (i >> 2)) * PITCH + 32 * ft + 16 * (g & 1) + 4 * (i & 3);
@@ -357,12 +373,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       }
       if (32 * ft + (lane & 31) < F)
         d[((long long)ft * a.BS + (m0 >> 4) + q2) * 64 + lane] = __builtin_bit_cast(frag, v);
-    }
-    if (st.ready && mine > 0) {
-      // release at agent scope (this XCD's L2 written back: the weight-gradient workgroups of train_step.h read
-      // these fragments on other XCDs), then the count.  The wave has no tile in this layer, or it is the last flush.
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (lane == 0) __hip_atomic_fetch_add(st.ready + layer, (unsigned)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
 
@@ -421,13 +431,14 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   };
 
   // ---- forward
-  for (int l = 0; l < a.L; ++l) {
+  const int LF = st.nfwd > 0 ? st.nfwd : a.L;
+  for (int l = 0; l < LF; ++l) {
     const ChainLayer& ly = a.lt[l];
     const bool last = l == a.L - 1;
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
     const int nch = ly.KS >> 2;
-    flush_t(act, ly.K, ly.ht16, ly.NT, l);  // this layer's input -> operand of its weight gradient
+    flush_t(act, ly.K, ly.ht16, ly.NT);  // this layer's input -> operand of its weight gradient
     const float wi = rwl[li];
     for (int t = wave; t < ly.NT; t += NW) {
       const int n0 = 32 * t;
@@ -532,6 +543,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     chain_stamp(a, 2 + l);
   }
 
+  if (LF < a.L) return;  // the encoder alone (joint step): its latents are in `zs`, nothing else is wanted
   // ---- loss: lanes -> rows (written before the last layer's barrier, above) -> workgroup (fixed order) -> one
   // fixed-point atomic per workgroup
   if (tid < 32) {
@@ -571,7 +583,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     elem* out = buf[cur ^ 1];
     const int nch = ly.NS >> 2;
     if (ly.gauss) { gauss_backward(buf[cur], ly.N >> 1, ly.NS * 16); chain_barrier(); }
-    flush_t(act, ly.N, ly.dzt16, ly.KT, l);  // gs * dZ of this layer's output -> operand of its weight gradient
+    flush_t(act, ly.N, ly.dzt16, ly.KT);  // gs * dZ of this layer's output -> operand of its weight gradient
     for (int t = wave; t < ly.KT; t += NW) {
       const int k0 = 32 * t;
       f32x16 acc;
@@ -600,7 +612,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
   if (a.lt[0].gauss) { gauss_backward(buf[cur], a.lt[0].N >> 1, a.lt[0].NS * 16); chain_barrier(); }
-  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0, 0);
+  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
 }
 
 // ---- weight gradients from the fragment-ordered operands: [dW; db](k, n) = sum_b HT(k, b) dZT(n, b).
@@ -781,6 +793,9 @@ __global__ void __launch_bounds__(kDwThreads) gemm_dw16_lds_kernel(const Dw16Gro
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       if (st + 2 < nst) issue(st + 2);
     }
+    // The loader waves END here, before the compute waves' last s_barrier (the epilogue's): on gfx950 an ended wave no
+    // longer counts towards its workgroup's barrier, so the compute waves meet among themselves.  (Do not add a barrier
+    // after this point that the loaders are meant to attend.)
     return;
   }
   // ---- compute wave (wi, wj): quadrant rows 64 wi .., columns 64 wj ..

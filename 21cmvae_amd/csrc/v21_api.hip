@@ -25,7 +25,6 @@
 #include "train_kernels.h"
 #include "train_chain.h"
 #include "dw_adam.h"
-#include "train_step.h"
 
 using namespace v21;
 
@@ -129,7 +128,6 @@ struct v21_ctx {
   float* h_stage = nullptr;
   size_t h_stage_n = 0;
   int sharded = 0;  // 1: reduce-scatter -> Adam on this rank's shard -> all-gather (v21_comm_set_sharded)
-  int ncu = 0;      // compute units of the device (the one-launch step never launches more workgroups than that)
 };
 // ncclDataType_t / ncclRedOp_t values of rccl.h (the library is dlopen'ed, its header is not included)
 constexpr int kNcclFloat32 = 7, kNcclSum = 0;
@@ -150,11 +148,6 @@ extern "C" int v21_ctx_create(int device, v21_ctx** out) {
   hipError_t e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail(V21_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
   c->stream = c->own;
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->ncu = prop.multiProcessorCount;
-    else (void)hipGetLastError();
-  }
   *out = c;
   return V21_OK;
 }
@@ -764,13 +757,6 @@ struct v21_trainer {
   std::vector<void*> d_ht16, d_dzt16;  // fragment-ordered weight-gradient operands (train_chain.h)
   long long BS = 0;                    // batch steps of 16 per feature tile
   unsigned long long* d_stamps = nullptr;
-  // one-launch step (train_step.h): counters, tile queues, device copy of the gradient / Adam block
-  bool fused_step = false;
-  StepSync* d_sync = nullptr;
-  int* d_order = nullptr;
-  int qfirst[kStepQueues + 1] = {};
-  DwAdamModel* d_dwtab = nullptr;
-  std::vector<DwAdamModel> h_dwtab;
   // ---- replayed steps (hipGraph).  One optimizer step is captured once per (rows, global rows, data pointers)
   // and replayed; what differs between steps comes from a device table of StepDesc (train_kernels.h) that the
   // host fills for the steps ahead: an epoch's steps in run_epoch, the next kDescRing steps in step_dev.
@@ -891,29 +877,6 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
         HIPCHK(hipStreamSynchronize(st));
       }
       t->chain = true;
-      {  // tile queues of the one-launch step: queue x = its eighth of every layer's tiles (row-major runs: the tiles
-         // of a run share their A rows), top layer first -- the order in which the operands become complete
-        const char* envf = getenv("V21_STEP_FUSED");
-        std::vector<int> first(L + 1, 0), ntile(L, 0);
-        for (int l = 0; l < L; ++l) {
-          ntile[l] = ((m->dims[l] + 1 + 31) / 32) * ((m->nw(l) + 31) / 32);
-          first[l + 1] = first[l] + ntile[l];
-        }
-        std::vector<int> order;
-        for (int x = 0; x < kStepQueues; ++x) {
-          t->qfirst[x] = (int)order.size();
-          for (int l = L - 1; l >= 0; --l)
-            for (int i = (int)((long long)ntile[l] * x / kStepQueues); i < (int)((long long)ntile[l] * (x + 1) / kStepQueues); ++i)
-              order.push_back(first[l] + i);
-        }
-        t->qfirst[kStepQueues] = (int)order.size();
-        HIPCHK(hipMalloc((void**)&t->d_order, order.size() * sizeof(int) + 16));
-        HIPCHK(hipMemcpyAsync(t->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMalloc((void**)&t->d_sync, sizeof(StepSync)));
-        HIPCHK(hipMemsetAsync(t->d_sync, 0, sizeof(StepSync), st));
-        HIPCHK(hipStreamSynchronize(st));  // `order` is a host temporary
-        t->fused_step = !(envf && envf[0] == '0') && t->ctx->ncu >= 16;
-      }
     }
   }
   t->max_slices = std::max(1, (max_batch + 127) / 128);  // weight-gradient slices down to 8 batch steps
@@ -943,9 +906,6 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   if (t->d_steploss) hipFree(t->d_steploss);
   if (t->d_slab) hipFree(t->d_slab);
   if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
-  if (t->d_sync) hipFree(t->d_sync);
-  if (t->d_order) hipFree(t->d_order);
-  if (t->d_dwtab) hipFree(t->d_dwtab);
   if (t->chain) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_partial); hipFree(t->d_ticket); hipFree(t->d_stamps);
     for (void* p : t->d_ht16) if (p) hipFree(p);
     for (void* p : t->d_dzt16) if (p) hipFree(p); }
@@ -1372,9 +1332,7 @@ static int chain_attr(int prec) {
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_joint_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
-    HIPCHK(hipFuncSetAttribute((const void*)train_step_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
   } else {
-    HIPCHK(hipFuncSetAttribute((const void*)train_step_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_joint_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
@@ -1383,9 +1341,9 @@ static int chain_attr(int prec) {
   return V21_OK;
 }
 // prefetcher workgroups per XCD for a launch of `models` x `ncons` row-block workgroups: the CUs the row blocks leave idle
-static int chain_prefetchers(int ncons, int models, int ncu = 256) {
+static int chain_prefetchers(int ncons, int models) {
   if (models > 1) return 0;  // a sweep: measured slower with them (8 models, 24 prefetchers each: 106 k -> 95 k model-steps/s)
-  const int idle = ncu - ncons;
+  const int idle = 256 - ncons;
   return idle >= 8 ? std::min(8, idle / 8) : 0;
 }
 static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
@@ -1557,55 +1515,6 @@ static int launch_dw_adam_group(const std::vector<v21_trainer*>& tr, const DwAda
   return V21_OK;
 }
 
-// ---- single rank, the step fits one workgroup per CU: the whole step in ONE launch (train_step.h)
-static bool step_fused_eligible(const v21_trainer* t, int rows) {
-  const int ncons = ((rows + 31) / 32 + 7) / 8 * 8;
-  return t->fused_step && t->chain && t->ctx->nranks == 1 && rows > 0 && ncons + 8 <= t->ctx->ncu;
-}
-static int launch_step_fused(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
-                             const int* d_idx, long long first, int rows, int brows, long long row0, float alpha, int slot) {
-  v21_mlp* m = t->mlp;
-  hipStream_t st = t->ctx->stream;
-  CHK(chain_attr(t->prec));
-  if (!t->capturing) CHK(refresh_dw_adam_table({t}, &t->d_dwtab, t->h_dwtab, st));  // (captured steps: refreshed by step_graph)
-  ChainArgs a{};
-  static_cast<ChainModel&>(a) = chain_model(t);
-  static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, m->dims[m->L], t, row0);
-  const int nrb = (rows + 31) / 32;
-  a.ncons = (nrb + 7) / 8 * 8;
-  a.npref = chain_prefetchers(a.ncons, 1, t->ctx->ncu);
-  a.ready = t->d_sync->ready;
-  DwAdamStep ds{};
-  ds.steps = (rows + 15) / 16;
-  ds.slot = slot;
-  ds.alpha[0] = alpha;
-  ds.out_scale[0] = 1.0f / grad_opscale(brows, m->dims[m->L]);
-  ds.sc = step_ctx(t);
-  StepPlan pl{};
-  pl.sync = t->d_sync; pl.order = t->d_order; pl.model = t->d_dwtab;
-  for (int x = 0; x <= kStepQueues; ++x) pl.qfirst[x] = t->qfirst[x];
-  for (int l = 0; l < m->L; ++l)
-    pl.expect[l] = (unsigned)nrb * (unsigned)(2 * ((m->dims[l] + 31) / 32) + 2 * ((m->nw(l) + 31) / 32));
-  // one workgroup per CU at most (158 KB of LDS each): the row blocks first, every CU beyond them a worker from the start
-  const int total = std::min(t->ctx->ncu, std::max(a.ncons + 8 * a.npref, t->qfirst[kStepQueues] + a.ncons));
-  const dim3 grid(total), block(64 * kChainWaves);
-  if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_step_kernel<PrecF16>, grid, block, kChainLdsBytes, st, a, ds, pl);
-  else hipLaunchKernelGGL(train_step_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, a, ds, pl);
-  HIPCHK(hipGetLastError());
-  t->copies_ok = true;
-  t->nt_ok = false;
-  return V21_OK;
-}
-// a wait of the one-launch step that ran into its limit (train_step.h: step_wait) -- reported at the next synchronising call
-static int step_sync_check(v21_trainer* t) {
-  if (!t->d_sync) return V21_OK;
-  unsigned err = 0;
-  HIPCHK(hipMemcpyAsync(&err, &t->d_sync->error, sizeof err, hipMemcpyDeviceToHost, t->ctx->stream));
-  HIPCHK(hipStreamSynchronize(t->ctx->stream));
-  if (err) return fail(V21_ERR_HIP, "one-launch training step: a weight-gradient workgroup waited for operands that never became complete");
-  return V21_OK;
-}
-
 static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out,
                         long long row0);
 // one optimizer step on rows [first, first+rows) (through d_idx when given) of (x, y, rw)
@@ -1623,16 +1532,18 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
     CHK(ensure_copies(t, false));
-    const bool one_launch = step_fused_eligible(t, rows);
-    if (!one_launch) CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
-    if (t->ctx->nranks == 1) {  // nothing to exchange: gradients, Adam and the packed copies in one launch
+    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
+    // Single rank, nothing to exchange: gradients, Adam and the packed copies in one launch (dw_adam.h) -- up to the
+    // batch where its 32 x 32 tiles, each pulling its operands over the WHOLE batch through one CU, lose to the
+    // 128 x 128 LDS-staged split-K kernel + an Adam launch that sums the slabs (V21_DW_SPLIT_ROWS overrides the
+    // threshold; measured r3, autoencoder stack, f16: see DESIGN.md section 3)
+    static const int split_rows = getenv("V21_DW_SPLIT_ROWS") ? atoi(getenv("V21_DW_SPLIT_ROWS")) : 8192;
+    if (t->ctx->nranks == 1 && (rows < split_rows || t->capturing)) {
       if (!t->capturing) t->iter += 1;
       // an epoch's per-step loss slot is written by the kernel itself (a device-to-device copy per step is a launch)
       const bool in_table = loss_out && t->d_steploss && loss_out >= t->d_steploss && loss_out < t->d_steploss + t->steploss_cap;
-      const float alpha = t->capturing ? 0.f : adam_alpha(t->adam, t->iter);
-      const int slot = in_table ? (int)(loss_out - t->d_steploss) : -1;
-      if (one_launch) CHK(launch_step_fused(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, alpha, slot));
-      else CHK(launch_dw_adam(t, rows, brows, alpha, slot));
+      CHK(launch_dw_adam(t, rows, brows, t->capturing ? 0.f : adam_alpha(t->adam, t->iter),
+                         in_table ? (int)(loss_out - t->d_steploss) : -1));
       if (t->capturing) return V21_OK;
       if (loss_out && !in_table) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
       invalidate_streams(m);
@@ -1732,7 +1643,6 @@ static int step_graph(v21_trainer* t, const float* x, long long ldx, const float
   // everything that may not happen inside a capture: lazy refreshes, function attributes
   CHK(ensure_copies(t, !t->chain));
   if (t->chain) { CHK(chain_attr(t->prec)); CHK(dw16_attr(t->prec)); }
-  if (step_fused_eligible(t, rows)) CHK(refresh_dw_adam_table({t}, &t->d_dwtab, t->h_dwtab, st));
   hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { (void)hipGetLastError(); t->graph_mode = 0; return V21_OK; }  // e.g. the legacy stream: run eagerly
   t->capturing = true;
@@ -1826,7 +1736,6 @@ extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int ba
   std::vector<float> h(steps);
   HIPCHK(hipMemcpyAsync(h.data(), t->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  CHK(step_sync_check(t));
   double tot = 0.0;
   for (float v : h) tot += (double)v;  // each entry = batch_loss * n_b  ([K] epoch loss)
   *loss = tot / (double)n;
@@ -1935,7 +1844,6 @@ extern "C" int v21_trainer_last_step_loss(v21_trainer* t, double* loss) {
   float s = 0.f;
   HIPCHK(hipMemcpyAsync(&s, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToHost, t->ctx->stream));
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
-  CHK(step_sync_check(t));
   *loss = (double)s;  // sum_i w_i sum_j (p-y)^2 over the global batch
   return V21_OK;
 }
@@ -2315,12 +2223,14 @@ extern "C" int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_lay
   if (!ae || !em || !out) return fail(V21_ERR_ARG, "null argument");
   if (ae == em || ae->ctx != em->ctx || ae->prec != em->prec || ae->max_batch != em->max_batch)
     return fail(V21_ERR_ARG, "the two trainers must be distinct and share context, precision and max_batch");
-  if (!ae->chain || !em->chain || ae->gl >= 0 || em->gl >= 0)
-    return fail(V21_ERR_UNSUPPORTED, "the joint step runs on the chain kernel: f16 / bf16, widths <= %d, no variational layer", kChainMaxDim);
+  if (!ae->chain || !em->chain || em->gl >= 0)
+    return fail(V21_ERR_UNSUPPORTED, "the joint step runs on the chain kernel: f16 / bf16, widths <= %d, no variational layer in the emulator", kChainMaxDim);
   const v21_mlp* ma = ae->mlp;
   const v21_mlp* me = em->mlp;
-  if (latent_layer < 0 || latent_layer >= ma->L - 1 || ma->act[latent_layer] != V21_ACT_LINEAR)
-    return fail(V21_ERR_ARG, "latent_layer %d must be a linear layer below the autoencoder's output", latent_layer);
+  // the latent layer: linear, or the variational head (V21_ACT_GAUSS) -- the emulator then learns z_mean, what
+  // encoder.predict returns (emulator.py:753-754)
+  if (latent_layer < 0 || latent_layer >= ma->L - 1 || ma->act[latent_layer] == V21_ACT_RELU || (ae->gl >= 0 && ae->gl != latent_layer))
+    return fail(V21_ERR_ARG, "latent_layer %d must be the linear (or variational) layer below the autoencoder's output", latent_layer);
   if (ma->dims[latent_layer + 1] != me->dims[me->L] || ma->dims[latent_layer + 1] > 2 * kChainMaxLatent)
     return fail(V21_ERR_ARG, "latent width %d (autoencoder) vs emulator output %d (at most %d)", ma->dims[latent_layer + 1],
                 me->dims[me->L], 2 * kChainMaxLatent);
@@ -2350,11 +2260,11 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
   v21_trainer *ta = j->ae, *te = j->em;
   if (ta->n[0] < 1 || te->n[0] != ta->n[0]) return fail(V21_ERR_STATE, "both trainers need training sets of the same row count");
   if (!ta->y_is_x[0]) return fail(V21_ERR_STATE, "the autoencoder's targets must be its inputs (y == NULL)");
-  if (ta->ctx->nranks > 1) return fail(V21_ERR_UNSUPPORTED, "the joint step is single-rank");
   CHK(use(ta->ctx));
   hipStream_t st = ta->ctx->stream;
   const long long n = ta->n[0];
-  if (batch < 1 || batch > ta->max_batch) return fail(V21_ERR_ARG, "batch %d not in [1, max_batch %d]", batch, ta->max_batch);
+  const int R = ta->ctx->nranks, rk = ta->ctx->rank;
+  if (batch < 1 || (batch + R - 1) / R > ta->max_batch) return fail(V21_ERR_ARG, "per-rank batch %d not in [1, max_batch %d]", (batch + R - 1) / R, ta->max_batch);
   const int* d_idx = nullptr;
   if (perm) {
     if (ta->perm_cap < n) {
@@ -2383,25 +2293,57 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
       HIPCHK(hipStreamSynchronize(st));
     }
   }
-  CHK(refresh_dw_adam_table({ta, te}, &j->d_dwadam, j->h_dwadam, st));
+  if (R == 1) CHK(refresh_dw_adam_table({ta, te}, &j->d_dwadam, j->h_dwadam, st));
   CHK(chain_attr(ta->prec));
   const int dsig = ta->mlp->dims[0], dpar = te->mlp->dims[0], dlat = te->mlp->dims[te->mlp->L];
   for (long long s = 0; s < steps; ++s) {
     const long long first = s * batch;
-    const int rows = (int)std::min<long long>(batch, n - first);
+    const int brows = (int)std::min<long long>(batch, n - first);  // rows of the global batch
+    const long long lo = first + (long long)brows * rk / R, hi = first + (long long)brows * (rk + 1) / R;
+    const int rows = (int)(hi - lo);                                // this rank's share (data parallel: SURVEY 8e)
     for (v21_trainer* t : {ta, te}) CHK(ensure_copies(t, false));
-    ChainStep sa = chain_step(ta->d_x[0], dsig, nullptr, dsig, ta->d_rw[0], d_idx, first, rows, rows, dsig);
-    ChainStep sb = chain_step(te->d_x[0], dpar, nullptr, dlat, te->d_rw[0], d_idx, first, rows, rows, dlat);
-    sb.y_from_lds = 1;
-    sa.ncons = sb.ncons = ((rows + 31) / 32 + 7) / 8 * 8;
-    sa.npref = sb.npref = chain_prefetchers(sa.ncons, 1);
-    const dim3 grid(sa.ncons + 8 * sa.npref), block(64 * kChainWaves);
-    if (ta->prec == V21_PREC_F16)
-      hipLaunchKernelGGL(train_chain_joint_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
-    else
-      hipLaunchKernelGGL(train_chain_joint_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
-    HIPCHK(hipGetLastError());
-    CHK(launch_dw_adam_group({ta, te}, j->d_dwadam, j->h_dwadam, rows, rows, s, st));
+    if (rows > 0) {
+      ChainStep sa = chain_step(ta->d_x[0], dsig, nullptr, dsig, ta->d_rw[0], d_idx, lo, rows, brows, dsig, nullptr, lo - first);
+      ChainStep sb = chain_step(te->d_x[0], dpar, nullptr, dlat, te->d_rw[0], d_idx, lo, rows, brows, dlat, nullptr, lo - first);
+      sa.step_off = (unsigned long long)s;  // the table holds the autoencoder's step counter as of the epoch's start (noise key)
+      sb.y_from_lds = 1;
+      sa.ncons = sb.ncons = ((rows + 31) / 32 + 7) / 8 * 8;
+      sb.blk0 = sa.ncons;                   // the emulator's row blocks follow the autoencoder's in the grid
+      sa.npref = sb.npref = chain_prefetchers(2 * sa.ncons, 1);
+      const dim3 grid(2 * sa.ncons + 8 * sa.npref), block(64 * kChainWaves);
+      if (ta->prec == V21_PREC_F16)
+        hipLaunchKernelGGL(train_chain_joint_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+      else
+        hipLaunchKernelGGL(train_chain_joint_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+      HIPCHK(hipGetLastError());
+    }
+    if (R == 1) {
+      CHK(launch_dw_adam_group({ta, te}, j->d_dwadam, j->h_dwadam, rows, brows, s, st));
+      continue;
+    }
+    // data parallel: each model's weight gradients (this rank's rows), summed over the ranks, then Adam -- the same
+    // exchange as a plain step (reduce_and_update: all-reduce, or reduce-scatter + sharded Adam + all-gather)
+    for (v21_trainer* t : {ta, te}) {
+      int fold = 1;
+      if (rows > 0) {
+        int nslice = 1;
+        std::vector<Dw16Args> probs;
+        dw16_problems(t, rows, brows, &nslice, probs);
+        CHK(launch_dw16(t->prec, probs, st));
+        if (nslice > 1) {
+          const long long n4 = ((long long)t->P + 3) / 4;
+          hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
+                             (const float*)t->d_slab, nslice, (long long)t->P + 4, (long long)t->P);
+          HIPCHK(hipGetLastError());
+        }
+      } else {
+        HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
+      }
+      CHK(reduce_and_update(t, true, fold));
+      HIPCHK(hipMemcpyAsync(t->d_steploss + s, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+      invalidate_streams(t->mlp);
+      t->mlp->wpad_ok = true;
+    }
   }
   std::vector<float> h((size_t)steps * 2);
   HIPCHK(hipMemcpyAsync(h.data(), ta->d_steploss, (size_t)steps * sizeof(float), hipMemcpyDeviceToHost, st));

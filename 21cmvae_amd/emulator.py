@@ -328,7 +328,9 @@ class AutoEncoderEmulator(_EmulatorBase):
         autoencoder's callbacks stop it, it is frozen (learning rate 0) and the remaining epochs ARE the
         reference's second phase.  Keras bookkeeping per model (History, callbacks, epoch losses, validation
         after every epoch -- the emulator's against the current encoder's latents of the validation set).
-        Needs precision f16 / bf16 and mean_squared_error on the emulator."""
+        Needs precision f16 / bf16 and mean_squared_error on the emulator.  A variational autoencoder
+        (``AutoEncoder(variational=True)``) is fine: the emulator learns z_mean, what ``encoder.predict`` returns.
+        With a data-parallel communicator on the context every rank trains on its share of every batch."""
         from . import _native as nat, callbacks as cb_mod, engine
         ae, em = self.autoencoder, self.emulator
         for m in (ae, em):
@@ -353,6 +355,19 @@ class AutoEncoderEmulator(_EmulatorBase):
         zdummy = np.zeros((n, lat), np.float32)
         tre.set_data(0, X_train, zdummy, em._row_weight(zdummy))
         joint = nat.Joint(tra, tre, latent_layer=len(ae.encoder.layers) - 1)
+        dp = tra.ctx.nranks > 1
+        if dp:  # data parallel: the replicas must start equal and shuffle alike (as engine.Model.fit does)
+            from . import parallel
+
+            def bcast(a):
+                return parallel.broadcast_array(a, device=tra.ctx.device)
+            for m, tr in ((ae, tra), (em, tre)):
+                m._stack.set_weights(bcast(m._stack.get_weights()))
+                it, mm, vv = tr.get_state()
+                tr.set_state(int(bcast(np.array([it], np.int64))[0]), bcast(mm), bcast(vv))
+            if getattr(ae, "_vae_seed", None) is not None:
+                ae._vae_seed = int(bcast(np.array([ae._vae_seed], np.uint64))[0])
+                tra.set_vae(ae.kl_weight, ae.sample_latent, ae._vae_seed)
         hists = [cb_mod.History(), cb_mod.History()]
         params = {"epochs": epochs, "steps": -(-n // batch_size), "verbose": verbose}
         cbs = [cb_mod.CallbackList([hists[0]] + ae_callbacks, ae, params), cb_mod.CallbackList([hists[1]] + em_callbacks, em, params)]
@@ -372,6 +387,8 @@ class AutoEncoderEmulator(_EmulatorBase):
             tra.set_lr(float(ae.optimizer.lr) if ae_running else 0.0)
             tre.set_lr(float(em.optimizer.lr))
             perm = engine._rng.permutation(n).astype(np.int32)
+            if dp:
+                perm = bcast(perm)
             if em_running:
                 la, le = joint.run_epoch(perm, batch_size)
             else:  # the emulator has stopped: the autoencoder goes on alone

@@ -567,84 +567,6 @@ def test_one_launch_gradient_adam_kernel_state_and_packed_copies(ctx, prec, dims
         ostate.m[:] = m; ostate.v[:] = v
 
 
-def _fit_steps(ctx, dims, act, prec, x, y, w, batch, epochs, fused, seed=31, vae=None):
-    import os
-    native = pkg("_native")
-    Ws, bs = ora.init_mlp(dims, seed=seed)
-    old = os.environ.get("V21_STEP_FUSED")
-    os.environ["V21_STEP_FUSED"] = "1" if fused else "0"
-    try:
-        st = native.Stack(ctx, dims, act)
-        if vae:
-            st.set_weights((np.random.default_rng(seed).normal(size=st.num_params) * 0.05).astype(np.float32))
-        else:
-            st.set_weights(ora.flatten_params(Ws, bs))
-        tr = native.Trainer(st, prec, batch)  # the switch is read when the trainer is created
-    finally:
-        if old is None:
-            os.environ.pop("V21_STEP_FUSED")
-        else:
-            os.environ["V21_STEP_FUSED"] = old
-    tr.set_adam(lr=1e-3)
-    if vae:
-        tr.set_vae(*vae)
-    tr.set_data(0, x, y, w)
-    n = x.shape[0]
-    losses, grads = [], []
-    for ep in range(epochs):
-        losses.append(tr.run_epoch(ora.epoch_permutation(n, 3, ep), batch))
-        grads.append(tr.get_grad().astype(np.float64))
-    it, m, v = tr.get_state()
-    return np.array(losses), grads, st.get_weights(), m, v, it
-
-
-@pytest.mark.parametrize("prec", ["f16", "bf16"])
-@pytest.mark.parametrize("case", ["ae_b4096", "ae_b256_ragged", "direct_b1000", "vae_b512"])
-def test_one_launch_step_equals_two_launch_step(ctx, prec, case):
-    """csrc/train_step.h: the whole step in one launch (row blocks + weight-gradient workers signalling through
-    agent-scope counters) against the two-launch step (V21_STEP_FUSED=0: train_chain_kernel, then dw16_adam_kernel):
-    same chain arithmetic, the partial tiles summed over 16 waves instead of 8 -- so the first step's loss is
-    IDENTICAL and everything after agrees to fp32 summation order.  Several steps per epoch on different rows of every
-    batch: an operand fragment read before it was complete, or a stale copy of the previous step's fragment in another
-    XCD's L2, shows up as a gradient that is off by far more than that.  Run twice: the result must not depend on
-    which workgroup happened to take which tile."""
-    synth, native = pkg("synth"), pkg("_native")
-    vae = None
-    if case == "direct_b1000":
-        dims, act, n, batch = [7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0], 3000, 1000
-        par = synth.make_params(n, seed=3)
-        x = ora.par_transform(par, par).astype(np.float32)
-        sig = synth.signals_from_params(par)
-        y = ora.preproc(sig, sig)
-        w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
-    else:
-        dims, act = [451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0]
-        n, batch = {"ae_b4096": (3 * 4096 + 100, 4096), "ae_b256_ragged": (1000, 256), "vae_b512": (1536, 512)}[case]
-        if case == "vae_b512":
-            act = [1, native.ACT_GAUSS, 1, 1, 0]
-            vae = (1e-3, True, 7)
-        sig = synth.make_signals(n, seed=13)
-        x = ora.preproc(sig, sig); y = None
-        w = ora.relative_mse_row_weight(x, sig).astype(np.float32)
-    one = _fit_steps(ctx, dims, act, prec, x, y, w, batch, 2, fused=True, vae=vae)
-    again = _fit_steps(ctx, dims, act, prec, x, y, w, batch, 2, fused=True, vae=vae)
-    two = _fit_steps(ctx, dims, act, prec, x, y, w, batch, 2, fused=False, vae=vae)
-    for a, b in zip(one[:1] + one[2:5], again[:1] + again[2:5]):
-        np.testing.assert_array_equal(a, b)          # deterministic, whatever the tile-to-workgroup assignment
-    assert one[5] == two[5] == 2 * -(-n // batch)
-    np.testing.assert_allclose(one[0], two[0], rtol=2e-4)
-    for g1, g2 in zip(one[1], two[1]):
-        assert _cos(g1, g2) > 0.99999, _cos(g1, g2)
-        assert abs(np.linalg.norm(g1) / np.linalg.norm(g2) - 1) < 1e-4
-    # Adam amplifies summation-order differences of tiny gradients (m / sqrt(v)): compare the MOVEMENT of the weights
-    w0 = ora.flatten_params(*ora.init_mlp(dims, seed=31)).astype(np.float64) if vae is None else None
-    if w0 is not None:
-        d1, d2 = one[2] - w0, two[2] - w0
-        assert _cos(d1, d2) > 0.999, _cos(d1, d2)
-    np.testing.assert_allclose(one[3], two[3], rtol=0, atol=1e-3 * np.abs(two[3]).max())
-    np.testing.assert_allclose(one[4], two[4], rtol=0, atol=1e-3 * np.abs(two[4]).max())
-
-
 def test_chain_path_is_actually_used(ctx):
     """f16/bf16 trainers of stacks up to 512 wide (variational heads up to 32 latent dimensions) run the
     chain kernel (its stamps exist); f32, wider stacks and wider latents take the per-layer path."""
@@ -944,6 +866,118 @@ def test_joint_step_is_phase_two_when_the_encoder_is_frozen(ctx):
     st32 = native.Stack(ctx, em_dims, em_act)
     with pytest.raises(native.EngineError):
         native.Joint(tra, native.Trainer(st32, "f32", batch), latent_layer=1)
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_joint_step_full_width_against_the_oracle(ctx, prec):
+    """BASELINE configs[2] at its real widths: autoencoder 451 -> 352 -> 9 -> 32 -> 352 -> 451 + latent emulator
+    7 -> [352, 352, 352, 224] -> 9, batch 256 with a partial last batch (600 rows = 256 + 256 + 88).
+    (a) encoder frozen (lr 0): the emulator's epochs are the reference's second phase (emulator.py:753-764) --
+        against the float64 oracle's fit on the oracle's latents, and the autoencoder must not move;
+    (b) both models training: the autoencoder's half is bit-identical to the autoencoder trained alone (the two
+        families of row blocks share nothing), and the emulator's first-step loss is its float64 loss against the
+        encoder's latents of that step."""
+    native, synth = pkg("_native"), pkg("synth")
+    n, batch = 600, 256
+    sig = synth.make_signals(n, seed=5)
+    y = ora.preproc(sig, sig)
+    par = np.random.default_rng(8).uniform(-1, 1, size=(n, 7)).astype(np.float32)
+    wa = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    ae_dims, ae_act = [451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0]
+    em_dims, em_act = [7, 352, 352, 352, 224, 9], [1, 1, 1, 1, 0]
+    Wa, ba = ora.init_mlp(ae_dims, seed=31)
+    We, be = ora.init_mlp(em_dims, seed=32)
+    h = y.astype(np.float64)
+    for W_, b_, a_ in list(zip(Wa, ba, ae_act))[:2]:
+        h = h @ W_.astype(np.float64) + b_.astype(np.float64)
+        h = np.maximum(h, 0) if a_ else h
+    z = h                                                     # the oracle's latents of the initial encoder
+    wz = ora.mse_row_weight(z.astype(np.float32)).astype(np.float32)
+    tol_l, tol_n = (5e-3, 3e-2) if prec == "f16" else (4e-2, 1e-1)
+
+    def trainer(dims, act, Ws, bs, lr):
+        st = native.Stack(ctx, dims, act)
+        st.set_weights(ora.flatten_params(Ws, bs))
+        tr = native.Trainer(st, prec, batch)
+        tr.set_adam(lr=lr)
+        return st, tr
+    # ---- (a) frozen encoder
+    sta, tra = trainer(ae_dims, ae_act, Wa, ba, 0.0)
+    ste, tre = trainer(em_dims, em_act, We, be, 1e-3)
+    tra.set_data(0, y, None, wa)
+    tre.set_data(0, par, np.zeros((n, 9), np.float32), wz)
+    joint = native.Joint(tra, tre, latent_layer=1)
+    sto = ora.AdamState(ste.num_params, dtype=np.float64, lr=1e-3)
+    W, b = [a.astype(np.float64) for a in We], [a.astype(np.float64) for a in be]
+    for ep in range(2):
+        perm = ora.epoch_permutation(n, 9, ep)
+        la, le = joint.run_epoch(perm, batch)
+        W, b, hist = ora.fit(W, b, sto, par.astype(np.float64), z, wz.astype(np.float64), 1, batch, seed=9, dtype=np.float64,
+                             start_epoch=ep)
+        assert abs(le - hist["loss"][0]) / hist["loss"][0] < tol_l, (ep, le, hist["loss"][0])
+    np.testing.assert_array_equal(sta.get_weights(), ora.flatten_params(Wa, ba))   # lr = 0: untouched
+    w0 = ora.flatten_params(We, be).astype(np.float64)
+    dj, do = ste.get_weights() - w0, ora.flatten_params(W, b) - w0
+    cos = float(dj @ do / (np.linalg.norm(dj) * np.linalg.norm(do)))
+    assert cos > (0.99 if prec == "f16" else 0.9) and abs(np.linalg.norm(dj) / np.linalg.norm(do) - 1) < tol_n, cos
+    assert tra.get_state()[0] == tre.get_state()[0] == 6
+    # ---- (b) both models training
+    sta, tra = trainer(ae_dims, ae_act, Wa, ba, 1e-3)
+    ste, tre = trainer(em_dims, em_act, We, be, 1e-3)
+    sts, trs = trainer(ae_dims, ae_act, Wa, ba, 1e-3)        # the autoencoder alone
+    tra.set_data(0, y, None, wa); trs.set_data(0, y, None, wa)
+    tre.set_data(0, par, np.zeros((n, 9), np.float32), wz)
+    joint = native.Joint(tra, tre, latent_layer=1)
+    perm = ora.epoch_permutation(n, 9, 0)
+    la, le = joint.run_epoch(perm, batch)
+    ls = trs.run_epoch(perm, batch)
+    assert la == ls
+    np.testing.assert_array_equal(sta.get_weights(), sts.get_weights())
+    assert np.isfinite(le) and le > 0
+
+
+def test_joint_step_with_a_variational_autoencoder(ctx):
+    """The joint step with a (z_mean | z_log_var) head in the autoencoder: the emulator's targets are z_mean of the
+    encoder of that step (what encoder.predict returns).  With the autoencoder frozen the emulator's epoch equals a
+    separate trainer fed the float64 z_mean; with kl_weight = 0 and no sampling the autoencoder's half equals the
+    deterministic autoencoder's."""
+    native, synth = pkg("_native"), pkg("synth")
+    n, batch = 200, 128
+    sig = synth.make_signals(n, seed=6)
+    y = ora.preproc(sig, sig)
+    par = np.random.default_rng(9).uniform(-1, 1, size=(n, 7)).astype(np.float32)
+    wa = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    ae_dims, ae_act = [451, 64, 9, 32, 451], [1, native.ACT_GAUSS, 1, 0]
+    em_dims, em_act = [7, 48, 9], [1, 0]
+    sta = native.Stack(ctx, ae_dims, ae_act)
+    flat = (np.random.default_rng(3).normal(size=sta.num_params) * 0.05).astype(np.float32)
+    sta.set_weights(flat)
+    tra = native.Trainer(sta, "f16", batch); tra.set_adam(lr=0.0); tra.set_vae(1e-3, sample=True, seed=5)
+    We, be = ora.init_mlp(em_dims, seed=12)
+    ste = native.Stack(ctx, em_dims, em_act); ste.set_weights(ora.flatten_params(We, be))
+    tre = native.Trainer(ste, "f16", batch); tre.set_adam(lr=2e-3)
+    # float64 z_mean of the (frozen) encoder: Dense 451 -> 64 (ReLU), Dense 64 -> 18, first 9 columns
+    o = 0
+    W0 = flat[o:o + 451 * 64].reshape(451, 64).astype(np.float64); o += 451 * 64
+    b0 = flat[o:o + 64].astype(np.float64); o += 64
+    W1 = flat[o:o + 64 * 18].reshape(64, 18).astype(np.float64); o += 64 * 18
+    b1 = flat[o:o + 18].astype(np.float64)
+    zm = (np.maximum(y.astype(np.float64) @ W0 + b0, 0) @ W1 + b1)[:, :9]
+    wz = ora.mse_row_weight(zm.astype(np.float32)).astype(np.float32)
+    tra.set_data(0, y, None, wa)
+    tre.set_data(0, par, np.zeros((n, 9), np.float32), wz)
+    joint = native.Joint(tra, tre, latent_layer=1)
+    stx = native.Stack(ctx, em_dims, em_act); stx.set_weights(ora.flatten_params(We, be))
+    trx = native.Trainer(stx, "f16", batch); trx.set_adam(lr=2e-3)
+    trx.set_data(0, par, zm.astype(np.float32), wz)
+    for ep in range(2):
+        perm = ora.epoch_permutation(n, 4, ep)
+        la, le = joint.run_epoch(perm, batch)
+        lx = trx.run_epoch(perm, batch)
+        assert np.isfinite(la) and abs(le - lx) / lx < 3e-3, (ep, le, lx)
+    np.testing.assert_array_equal(sta.get_weights(), flat)
+    d1, d2 = ste.get_weights() - ora.flatten_params(We, be), stx.get_weights() - ora.flatten_params(We, be)
+    assert float(d1 @ d2 / (np.linalg.norm(d1) * np.linalg.norm(d2))) > 0.995
 
 
 def test_autoencoder_emulator_joint_training_through_the_class_surface(ctx):
