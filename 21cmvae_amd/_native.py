@@ -18,7 +18,7 @@ PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32,
               "f16": PREC_F16, "fp16": PREC_F16, "float16": PREC_F16,
               "bf16": PREC_BF16, "bfloat16": PREC_BF16}
 ACT_LINEAR, ACT_RELU, ACT_GAUSS = 0, 1, 2
-FWD_IN_TRANSFORM, FWD_OUT_TRANSFORM, FWD_FORCE_GENERIC, FWD_NO_SMALL = 1, 2, 4, 8
+FWD_IN_TRANSFORM, FWD_OUT_TRANSFORM, FWD_FORCE_GENERIC, FWD_NO_SMALL, FWD_FORCE_CHAIN = 1, 2, 4, 8, 16
 COMM_ID_BYTES = 128
 
 

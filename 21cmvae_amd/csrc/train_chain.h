@@ -112,6 +112,14 @@ struct ChainStep {
   // nothing written but the captured latents) -- nfwd = 0: the whole stack
   int nfwd;
   int blk0;  // physical block blk0 is logical block 0 of this body (the joint kernel runs two families of row blocks)
+  // FORWARD mode (Model.predict of any stack up to 512 wide, emulator.py:402 / :789-790; with fwd_only): the last layer's
+  // outputs leave as fp32 rows out[row * ldo + n] = z * out_std + out_mean[n] (preprocess.unpreproc, preprocess.py:27-46;
+  // out_mean == nullptr: plain outputs) instead of entering a loss; tin != nullptr: preprocess.par_transform
+  // (preprocess.py:49-110, statistics cached in *tin, device memory) is applied to the <= 8 input columns as they
+  // are gathered.  out == nullptr: training / validation.
+  float* out; long long ldo;
+  float out_std; const float* out_mean;
+  const v21_affine_in* tin;
 };
 struct ChainArgs : ChainModel, ChainStep {};
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
@@ -284,7 +292,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
      // a valid address and replaced by 0, and every lane writes its whole strip of the LDS images (columns
      // >= K are the zero padding the first contraction reads).
     const int K0 = a.lt[0].K, DO = a.lt[a.L - 1].N;
-    const float rwv = st.rw[srow];
+    const float rwv = st.rw ? st.rw[srow] : 0.f;
     long long sr[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -302,7 +310,14 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = lane + 64 * i;
-        const float t = xs[k < K0 ? k : K0 - 1];
+        float t = xs[k < K0 ? k : K0 - 1];
+        if (i == 0 && st.tin) {  // par_transform on the (<= 8) input columns, as affine_in_kernel does it
+          const int jc = lane < K0 ? lane : 0;
+          const float zf = st.tin->zero_floor[jc];
+          if (zf > 0.f && t == 0.f) t = zf;
+          if (st.tin->log_mask[jc]) t = __log10f(t);
+          t = (t - st.tin->lo[jc]) * st.tin->scale[jc] - 1.0f;
+        }
         v[r][i] = k < kmax ? t : 0.f;
       }
     }
@@ -313,13 +328,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       for (int i = 0; i < 8; ++i) {
         const int k = lane + 64 * i;  // <= 511 < PITCH, YP
         buf[0][m * PITCH + k] = (elem)v[r][i];
-        if (!st.y && !st.y_from_lds) ystg[m * YP + k] = v[r][i];
+        if (!st.y && !st.y_from_lds && !st.out) ystg[m * YP + k] = v[r][i];
       }
     }
     if (st.y_from_lds) {  // rows of the previous model's captured layer (fp32, in the variational head's buffer)
       const int DOl = a.lt[a.L - 1].N;
       for (int i = tid; i < 32 * DOl; i += 64 * NW) ystg[(i / DOl) * YP + i % DOl] = zs[(i / DOl) * ZP + i % DOl];
-    } else if (st.y) {  // separate targets: a second pass through the same registers
+    } else if (st.y && !st.out) {  // separate targets: a second pass through the same registers
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         const int kmax = m0 + RPW * wave + r < st.rows ? DO : 0;
@@ -485,6 +500,39 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
           uint2 pk = {P::pack2(acc[4 * g], acc[4 * g + 1]), P::pack2(acc[4 * g + 2], acc[4 * g + 3])};
           *reinterpret_cast<uint2*>(out + li * PITCH + n) = pk;
         }
+      } else if (st.out) {
+        // FORWARD mode: the tile (32 rows x 32 features, this lane: one row, 4 x 4 features) goes through this wave's
+        // 4.5 KB of the (unused) target area as [row][feature] and leaves as 16-byte stores -- eight lanes per row,
+        // 128 contiguous bytes -- instead of 32 rows x 16 bytes per instruction
+        constexpr int SP = 36;  // floats per staged row: 144 B, rows shifted by 4 banks
+        float* stg = ystg + wave * (32 * SP);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(stg + li * SP + 8 * g + 4 * lh) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (own writes only: the area is private to the wave)
+        typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+        const int c4 = 4 * (lane & 7), n = n0 + c4;
+        f32x4 mean4 = {0.f, 0.f, 0.f, 0.f};
+        if (st.out_mean) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mean4[e] = st.out_mean[n + e < ly.N ? n + e : ly.N - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 8 * i + (lane >> 3);
+          f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + row * SP + c4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] = v4[e] * st.out_std + mean4[e];
+          if (row < vrows) {
+            float* dst = st.out + (long long)(m0 + row) * st.ldo + n;
+            if (n + 3 < ly.N) *reinterpret_cast<f32x4_u*>(dst) = v4;
+            else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < ly.N) dst[e] = v4[e];
+            }
+          }
+        }
       } else {  // loss_i = w_i sum_j (p - y)^2,  dL/dp = scale w_i (p - y)
         const float gsc = st.scale * wi;
 #pragma unroll
@@ -528,7 +576,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     }
     // (Columns the tiles did not cover, up to the next contraction's padded range, keep what they held: the weights of
     // those k-steps are zero, and every 16-bit value an image ever holds is finite -- see the one-time clear above.)
-    if (last) {  // this lane's share of the row losses joins the other waves' behind the same barrier
+    if (last && !st.out) {  // this lane's share of the row losses joins the other waves' behind the same barrier
       lsum += __shfl_xor(lsum, 32, 64);
       if (lh == 0) red[wave][li] = lsum * rwl[li];
     }
@@ -543,7 +591,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     chain_stamp(a, 2 + l);
   }
 
-  if (LF < a.L) return;  // the encoder alone (joint step): its latents are in `zs`, nothing else is wanted
+  if (LF < a.L || st.out) return;  // the encoder alone (joint step: its latents are in `zs`), or FORWARD mode
   // ---- loss: lanes -> rows (written before the last layer's barrier, above) -> workgroup (fixed order) -> one
   // fixed-point atomic per workgroup
   if (tid < 32) {

@@ -265,6 +265,14 @@ struct v21_mlp {
   float* d_small[2] = {nullptr, nullptr};
   float* d_xpad = nullptr;  // host-API staging of zero-padded input rows
   long long stage_pad_rows = 0;
+  // one-launch forward of ANY stack up to 512 wide in f16 / bf16 (train_chain.h, FORWARD mode): the packed forward
+  // weight stream per precision (+ the backward stream the packing kernel writes beside it), rebuilt lazily
+  void* d_cfw[3] = {nullptr, nullptr, nullptr};
+  void* d_cbw[3] = {nullptr, nullptr, nullptr};
+  bool cfw_ok[3] = {false, false, false};
+  std::vector<long long> cfw_off, cbw_off;  // element offsets per layer
+  long long cfw_bytes = 0, cbw_bytes = 0;
+  v21_affine_in* d_tin = nullptr;           // device copy of the input transform
   // width of layer l's Dense output: dims[l+1], or 2*dims[l+1] = [z_mean | z_log_var] for V21_ACT_GAUSS
   int nw(int l) const { return act[l] == V21_ACT_GAUSS ? 2 * dims[l + 1] : dims[l + 1]; }
 };
@@ -326,6 +334,8 @@ extern "C" int v21_mlp_destroy(v21_mlp* m) {
   for (int i = 0; i < 2; ++i) if (m->d_small[i]) hipFree(m->d_small[i]);
   if (m->d_wt) hipFree(m->d_wt);
   if (m->d_xpad) hipFree(m->d_xpad);
+  for (int i = 0; i < 3; ++i) { if (m->d_cfw[i]) hipFree(m->d_cfw[i]); if (m->d_cbw[i]) hipFree(m->d_cbw[i]); }
+  if (m->d_tin) hipFree(m->d_tin);
   if (m->d_xs) hipFree(m->d_xs);
   if (m->d_ys) hipFree(m->d_ys);
   delete m;
@@ -338,6 +348,7 @@ extern "C" int v21_mlp_num_params(const v21_mlp* m, size_t* n) {
 }
 static void invalidate_streams(v21_mlp* m) {
   for (int i = 0; i < 3; ++i) m->stream_ok[i] = false;
+  for (int i = 0; i < 3; ++i) m->cfw_ok[i] = false;
   m->wpad_ok = false;
   m->wt_ok = false;
 }
@@ -365,6 +376,10 @@ extern "C" int v21_mlp_set_input_transform(v21_mlp* m, const v21_affine_in* t) {
   if (t->n != m->dims[0] || t->n > 8) return fail(V21_ERR_ARG, "input transform: n = %d, stack input = %d (max 8)", t->n, m->dims[0]);
   m->tin = *t;
   m->has_tin = true;
+  CHK(use(m->ctx));
+  if (!m->d_tin) HIPCHK(hipMalloc((void**)&m->d_tin, sizeof(v21_affine_in)));
+  HIPCHK(hipMemcpyAsync(m->d_tin, &m->tin, sizeof(v21_affine_in), hipMemcpyHostToDevice, m->ctx->stream));
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));
   return V21_OK;
 }
 extern "C" int v21_mlp_set_output_transform(v21_mlp* m, const v21_affine_out* t) {
@@ -497,13 +512,28 @@ static int forward_generic(v21_mlp* m, const float* d_x, long long ldx, long lon
 
 static int forward_small(v21_mlp* m, const float* d_x, long long ldx, long long n, float* d_y, long long ldy, int prec,
                          int flags);
+// Any stack up to 512 wide in f16 / bf16: the whole forward pass in ONE launch of the chain kernel in FORWARD mode
+// (train_chain.h) -- what every `_gen_model` output without a compiled fused kernel gets (custom `hidden_dims`,
+// emulator.py:12-48; the members of a sweep).  r3, 65,536 rows: the per-layer K-loop path took 0.85 ms on the
+// headline stack (15x the fused kernel) and 0.35 ms on the sample notebook's 7 -> [64, 128] -> 451 model.
+static bool chain_fwd_eligible(const v21_mlp* m, int precision, int flags) {
+  if (precision == V21_PREC_F32 || (flags & V21_FWD_FORCE_GENERIC)) return false;
+  for (int l = 0; l <= m->L; ++l)
+    if (m->dims[l] > kChainMaxDim) return false;
+  for (int l = 0; l < m->L; ++l)
+    if (m->act[l] == V21_ACT_GAUSS && (m->dims[l + 1] > kChainMaxLatent || l == m->L - 1)) return false;
+  if ((flags & V21_FWD_IN_TRANSFORM) && m->dims[0] > 8) return false;
+  return true;
+}
+static int forward_chain(v21_mlp* m, const float* d_x, long long ldx, long long n, float* d_y, long long ldy, int prec,
+                         int flags);
 // internal: d_x rows are already zero-padded to a multiple of 16 floats (ldx) in a buffer with slack --
 // the small-batch path reads them in place (set by v21_mlp_forward, which pads on the host)
 #define V21_FWD_X_PADDED 0x100
 static bool takes_small_path(const v21_mlp* m, long long n, int precision, int flags) {
   const bool fused = m->fused_id >= 0 && !(flags & V21_FWD_FORCE_GENERIC) &&
                      (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8);
-  return n <= V21_SMALL_BATCH_ROWS && !(flags & (V21_FWD_NO_SMALL | V21_FWD_FORCE_GENERIC)) &&
+  return n <= V21_SMALL_BATCH_ROWS && !(flags & (V21_FWD_NO_SMALL | V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN)) &&
          (precision == V21_PREC_F32 || !fused) && (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) &&
          m->maxdim <= kNtMaxKPerWg;
 }
@@ -517,12 +547,13 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
   CHK(use(m->ctx));
   if ((flags & V21_FWD_IN_TRANSFORM) && !m->has_tin) return fail(V21_ERR_STATE, "input transform requested but not set");
   if ((flags & V21_FWD_OUT_TRANSFORM) && !m->has_tout) return fail(V21_ERR_STATE, "output transform requested but not set");
-  const bool fused = m->fused_id >= 0 && !(flags & V21_FWD_FORCE_GENERIC) &&
+  const bool fused = m->fused_id >= 0 && !(flags & (V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN)) &&
                      (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) && ldy < (1ll << 21);
   // few rows: one latency-oriented launch per layer beats one wave walking the whole stack in f32
   // (and the K-loop GEMM of the generic path in any precision)
   if (takes_small_path(m, n, precision, flags) && ldy < (1ll << 21))
     return forward_small(m, d_x, ldx, n, d_y, ldy, precision, flags);
+  if (!fused && chain_fwd_eligible(m, precision, flags) && n < (1ll << 30)) return forward_chain(m, d_x, ldx, n, d_y, ldy, precision, flags);
   if (!fused) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
   CHK(ensure_stream(m, precision));
   FusedArgs a{};
@@ -1357,6 +1388,77 @@ static int launch_chain(v21_trainer* t, const float* x, long long ldx, const flo
   const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
   if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
   else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+
+// ---- FORWARD mode of the chain kernel for a stack without a trainer (declared above v21_mlp_forward_dev)
+static int ensure_chain_stream(v21_mlp* m, int prec) {
+  if (m->cfw_ok[prec]) return V21_OK;
+  hipStream_t st = m->ctx->stream;
+  const int L = m->L;
+  if (m->cfw_off.empty()) {
+    long long of = 0, ob = 0;
+    for (int l = 0; l < L; ++l) {
+      const int K = m->dims[l], N = m->nw(l);
+      m->cfw_off.push_back(of); of += (long long)((N + 31) / 32) * chain_steps(K) * 512;
+      m->cbw_off.push_back(ob); ob += (long long)((K + 31) / 32) * chain_steps(N) * 512;
+    }
+    m->cfw_bytes = of * 2; m->cbw_bytes = ob * 2;
+  }
+  if (!m->d_cfw[prec]) {
+    HIPCHK(hipMalloc(&m->d_cfw[prec], (size_t)m->cfw_bytes + 64)); HIPCHK(hipMemsetAsync(m->d_cfw[prec], 0, (size_t)m->cfw_bytes + 64, st));
+    HIPCHK(hipMalloc(&m->d_cbw[prec], (size_t)m->cbw_bytes + 64)); HIPCHK(hipMemsetAsync(m->d_cbw[prec], 0, (size_t)m->cbw_bytes + 64, st));
+  }
+  AdamArgs a{};  // the arena -> the packed streams (the trainer's repacking kernel without the Adam update)
+  a.w = m->d_w; a.n = (long long)m->nparams; a.L = L; a.do_adam = 0; a.skip_nt = 1;
+  a.fw = m->d_cfw[prec]; a.bw = m->d_cbw[prec]; a.cprec = prec == V21_PREC_F16 ? 1 : 2;
+  for (int l = 0; l < L; ++l) {
+    AdamLayer& al = a.lt[l];
+    al.w_off = m->w_off[l]; al.K = m->dims[l]; al.N = m->nw(l);
+    al.fw_off = m->cfw_off[l]; al.bw_off = m->cbw_off[l];
+    al.KS = chain_steps(al.K); al.NS = chain_steps(al.N);
+  }
+  hipLaunchKernelGGL(adam_repack_kernel, dim3((unsigned)((m->nparams + 255) / 256)), dim3(256), 0, st, a);
+  HIPCHK(hipGetLastError());
+  m->cfw_ok[prec] = true;
+  return V21_OK;
+}
+static int forward_chain(v21_mlp* m, const float* d_x, long long ldx, long long n, float* d_y, long long ldy, int prec,
+                         int flags) {
+  hipStream_t st = m->ctx->stream;
+  const int L = m->L;
+  CHK(ensure_chain_stream(m, prec));
+  CHK(chain_attr(prec));
+  ChainArgs a{};
+  a.L = L;
+  for (int l = 0; l < L; ++l) {
+    ChainLayer& c = a.lt[l];
+    c.K = m->dims[l]; c.N = m->nw(l);
+    c.gauss = m->act[l] == V21_ACT_GAUSS;
+    c.KS = chain_steps(c.K); c.NT = (c.N + 31) / 32;
+    c.NS = chain_steps(c.N); c.KT = (c.K + 31) / 32;
+    c.relu = m->act[l] == V21_ACT_RELU;
+    c.mask_tile = -1;  // no backward pass: no ReLU masks kept
+    c.fw_off = m->cfw_off[l] / 8; c.bw_off = m->cbw_off[l] / 8;
+    c.b_off = m->b_off[l];
+  }
+  a.fw = m->d_cfw[prec]; a.bw = m->d_cbw[prec]; a.w = m->d_w;
+  a.fw_bytes = m->cfw_bytes; a.bw_bytes = 0;  // (the prefetchers touch the forward stream only)
+  a.zcap_layer = -1;
+  a.sample = 0;  // a variational head evaluates z = z_mean (include/v21.h)
+  a.x = d_x; a.ldx = ldx; a.rows = (int)n;
+  a.fwd_only = 1;
+  a.out = d_y; a.ldo = ldy;
+  const bool tout = (flags & V21_FWD_OUT_TRANSFORM) && m->has_tout;
+  a.out_std = tout ? m->out_std : 1.0f;
+  a.out_mean = tout ? m->d_mean : nullptr;
+  a.tin = ((flags & V21_FWD_IN_TRANSFORM) && m->has_tin) ? m->d_tin : nullptr;
+  a.ncons = (int)(((n + 31) / 32 + 7) / 8 * 8);
+  a.npref = chain_prefetchers(a.ncons, 1);
+  const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
+  if (prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, st, a);
+  else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, a);
   HIPCHK(hipGetLastError());
   return V21_OK;
 }

@@ -658,6 +658,11 @@ def main():
                 gen[prec] = fwd_rate(stack, DIMS, prec, flags | native.FWD_FORCE_GENERIC)
                 gen[prec]["slowdown_vs_fused"] = (out["value"] if prec == args.precision else modes.get(prec, {}).get("signals_per_s", 0.0)) / gen[prec]["signals_per_s"]
             out["predict_generic_S1"] = gen
+            # the table-driven one-launch forward (csrc/train_chain.h FORWARD mode: what every stack without a compiled
+            # kernel runs in f16 / bf16), forced onto the headline stack for comparison with the compiled kernel
+            td = {prec: fwd_rate(stack, DIMS, prec, flags | native.FWD_FORCE_CHAIN) for prec in ("f16", "bf16")}
+            td["f16"]["slowdown_vs_fused"] = (out["value"] if args.precision == "f16" else modes.get("f16", {}).get("signals_per_s", 0.0)) / td["f16"]["signals_per_s"]
+            out["predict_table_driven_S1"] = td
             cdims = [7, 64, 128, 451]
             cst = native.Stack(ctx, cdims, [1, 1, 0])
             cst.set_weights(glorot(cdims, seed=5))

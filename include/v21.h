@@ -138,6 +138,9 @@ int v21_mlp_forward_dev(v21_mlp* mlp, const float* d_x, int64_t ldx, int64_t n,
 #define V21_FWD_OUT_TRANSFORM 2
 #define V21_FWD_FORCE_GENERIC 4
 #define V21_FWD_NO_SMALL 8
+/* diagnostics / benchmarks: the table-driven one-launch forward (csrc/train_chain.h, FORWARD mode: any stack up to 512
+ * wide, f16 / bf16) even where a compiled fused kernel exists -- what every other stack gets by default */
+#define V21_FWD_FORCE_CHAIN 16
 #define V21_SMALL_BATCH_ROWS 4096
 
 /* ---- trainer: replaces Model.compile + Model.fit (emulator.py:369-378, :739-747,

@@ -287,3 +287,87 @@ def test_large_results_come_back_in_pooled_pinned_buffers(ctx):
     assert pool["live"] == 0 and 1 <= len(pool["free"]) <= ctx.PIN_POOL_MAX
     y = st.forward(xs[0], "f16")                        # served from the pool again
     np.testing.assert_array_equal(y, copies[0])
+
+
+# ---- stacks WITHOUT a compiled fused kernel: the table-driven one-launch forward (csrc/train_chain.h, FORWARD mode) ----
+CUSTOM_STACKS = [
+    ([7, 64, 128, 451], [1, 1, 0]),                      # notebooks/sample_notebook.ipynb cell 9
+    ([7, 32, 128, 256, 451], [1, 1, 1, 0]),              # notebooks/Training.ipynb's smaller trial
+    ([7, 288, 352, 288, 224, 9], [1, 1, 1, 1, 0]),       # a latent emulator of another width
+    ([451, 352, 9], [1, 0]),                             # an encoder on its own (encoder.predict, emulator.py:753-754)
+    ([9, 500, 512, 33], [1, 1, 0]),                      # odd widths up to the 512 limit
+    ([451, 96, 9, 32, 451], [1, 2, 1, 0]),               # a variational autoencoder: predict uses z = z_mean
+]
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("case", range(len(CUSTOM_STACKS)))
+def test_one_launch_forward_of_custom_stacks_matches_oracle(ctx, case, prec):
+    """Every `_gen_model` output (emulator.py:12-48) gets a one-launch forward, not only the four compiled stacks:
+    against the float64 oracle at ragged row counts above the small-batch route (4,097; 5,000; 65,553) and, forced
+    through the flag, below it (1, 31, 257); with and without the fused par_transform / unpreproc."""
+    native = pkg("_native")
+    dims, act = CUSTOM_STACKS[case]
+    dense = [dims[0]] + [2 * d if a == 2 else d for d, a in zip(dims[1:], act)]  # (a GAUSS layer's Dense is 2 * latent wide)
+    rng = np.random.default_rng(case)
+    Ws, bs, k = [], [], dims[0]
+    for d, dd in zip(dims[1:], dense[1:]):
+        lim = np.sqrt(6.0 / (k + d))
+        Ws.append(rng.uniform(-lim, lim, size=(k, dd)).astype(np.float32))
+        bs.append(rng.normal(scale=0.05, size=dd).astype(np.float32))
+        k = d
+    st = native.Stack(ctx, dims, act)
+    st.set_weights(np.concatenate([a.ravel() for W, b in zip(Ws, bs) for a in (W, b)]))
+    assert not st.has_fused(prec)
+
+    def oracle(x):
+        h = np.asarray(x, np.float64)
+        for W, b, a in zip(Ws, bs, act):
+            z = h @ W.astype(np.float64) + b.astype(np.float64)
+            h = np.maximum(z, 0) if a == 1 else (z[:, :z.shape[1] // 2] if a == 2 else z)
+        return h
+    bound = HALF_BOUNDS[prec]
+    for n, fl in ((1, native.FWD_FORCE_CHAIN), (31, native.FWD_FORCE_CHAIN), (257, native.FWD_FORCE_CHAIN),
+                  (4097, 0), (5000, 0), (65553, 0)):
+        x = np.random.default_rng(n).uniform(-1, 1, size=(n, dims[0])).astype(np.float32)
+        y = st.forward(x, prec, flags=fl)
+        ref = oracle(x)
+        assert y.shape == ref.shape and np.isfinite(y).all()
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(y - ref).max() <= bound["max_abs"] * scale, (dims, prec, n, np.abs(y - ref).max())
+        # the same rows through the per-layer route: the two paths differ by operand rounding only
+        yg = st.forward(x[:300], prec, flags=native.FWD_FORCE_GENERIC)
+        assert np.abs(yg - y[:300]).max() <= 2 * bound["max_abs"] * scale
+    if dims[0] == 7 and dims[-1] == 451:   # the class surface's route: par_transform prologue + unpreproc epilogue
+        synth, pp = pkg("synth"), pkg("preprocess")
+        par_train = synth.make_params(2000, seed=1, corners=True)
+        sig_train = synth.make_signals(512, seed=3)
+        ps, ss = pp.ParamStats.of(par_train), pp.SignalStats.of(sig_train)
+        st.set_input_transform(ps.log_mask, ps.zero_floor, ps.lo, ps.hi)
+        st.set_output_transform(ss.std, ss.mean)
+        par = synth.make_params(6000, seed=5, dtype=np.float32)
+        y = st.forward(par, prec, flags=native.FWD_IN_TRANSFORM | native.FWD_OUT_TRANSFORM)
+        ref = oracle(ora.par_transform(par.astype(np.float64), par_train)) * float(ss.std) + np.asarray(ss.mean, np.float64)
+        err = _rel_err_percent(y, ref).mean()
+        assert err < bound["mean_pct"], (dims, prec, err)
+        yg = st.forward(par, prec, flags=native.FWD_IN_TRANSFORM | native.FWD_OUT_TRANSFORM | native.FWD_FORCE_GENERIC)
+        assert _rel_err_percent(y, yg).mean() < bound["mean_pct"]
+
+
+def test_one_launch_forward_on_a_fused_stack_and_through_the_class_surface(ctx):
+    """FWD_FORCE_CHAIN on the headline stack equals the compiled fused kernel to operand rounding; a DirectEmulator with
+    custom hidden_dims predicts through the one-launch route and meets the oracle's direct_predict."""
+    native, synth, emu = pkg("_native"), pkg("synth"), pkg("emulator")
+    Ws, bs = ora.init_mlp(S1, seed=3)
+    st = _stack(ctx, Ws, bs)
+    x = np.random.default_rng(0).uniform(-1, 1, size=(9000, 7)).astype(np.float32)
+    ref = ora.mlp_forward(Ws, bs, x)
+    yc = st.forward(x, "f16", flags=native.FWD_FORCE_CHAIN)
+    assert np.abs(yc - ref).max() <= HALF_BOUNDS["f16"]["max_abs"]
+    assert np.abs(yc - st.forward(x, "f16")).max() <= 2 * HALF_BOUNDS["f16"]["max_abs"]
+    data = synth.make_dataset(600, 80, 5000)
+    em = emu.DirectEmulator(hidden_dims=[64, 128], precision="f16", **data)
+    p = em.predict(data["par_test"])
+    Wl = em.emulator.get_weights()[0::2]; bl = em.emulator.get_weights()[1::2]
+    ref = ora.direct_predict(Wl, bl, data["par_test"], data["par_train"], data["signal_train"], dtype=np.float64)
+    assert _rel_err_percent(p, ref).mean() < HALF_BOUNDS["f16"]["mean_pct"]
