@@ -34,6 +34,13 @@ struct DwAdamModel {
   int L, nblk;
   float omb1, omb2, eps;
   int cprec;  // 1: f16, 2: bf16
+  // Which tiles an XCD works on (single-model launches; nullptr: contiguous runs of the row-major tile list).
+  // order[x * xper + i] = i-th tile of XCD x or -1: per layer the R x C grid of tiles is cut into 8 two-dimensional
+  // blocks, one per XCD, so that an XCD pulls R/rb rows of A-tiles and C/cb columns of B-tiles from HBM instead of
+  // R/8 rows and ALL C columns (r3: the launch's HBM-side reads were 57 MB for 20 MB of unique operands; every XCD
+  // starts with a cold L2 after the kernel boundary, so what it reads, it reads from HBM or the Infinity Cache)
+  const int* order;
+  int xper;
   DwAdamLayer lt[16];
 };
 // what changes from step to step (per model of a group)
@@ -167,7 +174,14 @@ __device__ __forceinline__ int dw_adam_logical_block(int nblk) {
 // one model, everything in the kernel-argument block
 template <class P>
 __global__ void __launch_bounds__(64 * kDwAdamWaves) dw16_adam_kernel(const DwAdamModel md, const DwAdamStep st) {
-  const int lb = dw_adam_logical_block(md.nblk);
+  int lb;
+  if (md.order) {  // (workgroups b, b + 8, ... share an XCD: observed round-robin dispatch; speed only)
+    if ((int)(blockIdx.x >> 3) >= md.xper) return;
+    lb = md.order[(int)(blockIdx.x & 7) * md.xper + (int)(blockIdx.x >> 3)];
+    if (lb < 0) return;
+  } else {
+    lb = dw_adam_logical_block(md.nblk);
+  }
   if (lb >= md.nblk) return;
   dw16_adam_body<P>(md, lb, st.sc.desc ? st.sc.desc[*st.sc.cur].alpha : st.alpha[0], st.out_scale[0], st.steps, st.slot, st.sc);
 }
