@@ -588,7 +588,7 @@ def main():
                      "kernel_ms": kern_s * 1e3,
                      "kernel_ms_min": float(min(timed.per_launch_ms)), "kernel_ms_median": float(np.median(timed.per_launch_ms)),
                      "time_base": "HIP events on the launch stream around the K timed launches (mean); min / median from "
-                                  "per-launch event pairs of a second run; profiles/r2/kernel_stats_bench_f16.csv "
+                                  "per-launch event pairs of a second run; profiles/%s/kernel_stats_bench_f16.csv " % PROFILE_TAG +
                                   "(rocprofv3 --kernel-trace --stats of this command) must agree with the mean",
                      "algorithmic_flop_per_launch": FLOP_PER_SIGNAL * B,
                      "hbm_GBps_algorithmic": BYTES_PER_SIGNAL * B / kern_s / 1e9,
@@ -600,12 +600,14 @@ def main():
     # HBM traffic per launch of the headline kernel: PMC counters cannot be read from inside the timed
     # process; they were collected with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) on
     # this same command and are kept under profiles/ (hbm_bytes = 2*FETCH*1024 + WRITE*1024 on gfx950).
-    pmc = os.path.join(ROOT, "profiles", "r2", "pmc_fused_%s.json" % args.precision)
+    pmc = os.path.join(ROOT, "profiles", PROFILE_TAG, "pmc_fused_%s.json" % args.precision)
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r2", "pmc_fused_%s.json" % args.precision)  # (the kernel is unchanged since r2)
     if os.path.exists(pmc) and B == BATCH:
         try:
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r2/pmc_fused_%s.json (rocprofv3 --pmc, kernel %s)" % (
-                args.precision, json.load(open(pmc)).get("_kernel", "?"))
+            out["roofline"]["traffic_source"] = "%s (rocprofv3 --pmc, kernel %s)" % (
+                os.path.relpath(pmc, ROOT), json.load(open(pmc)).get("_kernel", "?"))
             out["roofline"]["algorithmic_bytes"] = BYTES_PER_SIGNAL * B
         except Exception:
             pass

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of a round on the GPU box into gpurun_out/<tag>/ (copied to profiles/<tag>/ afterwards).
-#   gpurun -- bash scripts/collect_profiles.sh r2
+#   gpurun -- bash scripts/collect_profiles.sh r3
 # kernel-trace/--stats and --pmc passes are SEPARATE runs; the profiled program comes directly after `--`.
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -26,15 +26,37 @@ rocprofv3 --kernel-trace --stats -d $OUT/t256 -o t --output-format csv -- $PY $R
 cp $OUT/t256/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f32.csv
 rocprofv3 --kernel-trace --stats -d $OUT/t256h -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 256 f16 200 > $OUT/train_probe_b256_f16.txt 2>&1
 cp $OUT/t256h/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f16.csv
-for c in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $c --kernel-trace -d $OUT/tpmc_$c -o p --output-format csv -- $PY $ROOT/scripts/train_probe.py 4096 f16 30 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/t16k -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 16384 f16 100 > $OUT/train_probe_b16384_f16.txt 2>&1
+cp $OUT/t16k/t_kernel_stats.csv $OUT/kernel_stats_train_b16384_f16.csv
+echo "train stats done"
+# HBM-side bytes of every kernel of a step: one --pmc pass per counter, per workload
+for wl in "4096 f16" "16384 f16" "256 f32"; do
+  set -- $wl
+  for c in "FETCH_SIZE" "WRITE_SIZE"; do
+    rocprofv3 --pmc $c --kernel-trace -d $OUT/tpmc_$1_$2_$c -o p --output-format csv -- $PY $ROOT/scripts/train_probe.py $1 $2 30 > /dev/null 2>&1
+  done
+  $PY $ROOT/scripts/pmc_summary.py "v21::" $OUT/tpmc_$1_$2_*/p_counter_collection.csv > $OUT/pmc_train_b$1_$2.json
+  echo "pmc $wl done"
 done
-$PY $ROOT/scripts/pmc_summary.py "train_chain|gemm_dw16|adam_repack|dw16_adam" $OUT/tpmc_*/p_counter_collection.csv > $OUT/pmc_train_b4096_f16.json
+# instruction mix / wait accounting / L2->CU requests of the two kernels of the f16 step at 4,096 rows
+for grp in "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --kernel-trace -d $OUT/sq_$name -o p --output-format csv -- $PY $ROOT/scripts/train_probe.py 4096 f16 20 > /dev/null 2>&1 || echo "failed: $grp"
+done
+$PY $ROOT/scripts/pmc_summary.py "train_chain|dw16_adam" $OUT/sq_*/p_counter_collection.csv > $OUT/pmc_train_b4096_f16_sq_counters.json
+echo "sq counters done"
+# the table-driven one-launch forward (train_chain.h FORWARD mode) beside the compiled kernel, and the per-layer route
+rocprofv3 --kernel-trace --stats -d $OUT/fwd -o f --output-format csv -- $PY $ROOT/scripts/forward_routes_probe.py > $OUT/forward_routes_probe.txt 2>&1
+cp $OUT/fwd/f_kernel_stats.csv $OUT/kernel_stats_forward_routes.csv
+# the joint step (configs[2]) against the two models one after the other
+rocprofv3 --kernel-trace --stats -d $OUT/joint -o j --output-format csv -- $PY $ROOT/scripts/joint_probe.py > $OUT/joint_probe.txt 2>&1
+cp $OUT/joint/j_kernel_stats.csv $OUT/kernel_stats_joint_b256_f16.csv
+echo "forward + joint done"
 # 3b. is the headline kernel clock-bound?  the same launches on random and on all-zero operands
 cd $ROOT
 $PY scripts/power_probe.py > $OUT/power_probe_fused_random_vs_zero_operands.txt 2>&1
 # 4. in-kernel cycle stamps of the SHIPPED headline kernel (diagnostic build: not a benchmark)
 cd $ROOT
 V21_LIB=$ROOT/21cmvae_amd/libv21_stamp.so $PY scripts/diag_stamps.py f16 > $OUT/stamps_fused_f16x2sp_block_tile_cycles.txt 2>&1
-rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t4096 $OUT/t256 $OUT/t256h $OUT/tpmc_*
+rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t4096 $OUT/t256 $OUT/t256h $OUT/t16k $OUT/tpmc_* $OUT/sq_* $OUT/fwd $OUT/joint
 ls -la $OUT
