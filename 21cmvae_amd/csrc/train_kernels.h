@@ -283,6 +283,9 @@ struct AdamArgs {
   StepCtx sc;  // replayed step: alpha comes from the descriptor
   long long i0;  // first element this launch works on (sharded data-parallel Adam: a rank's slice of the arena)
   int no_pack;   // update w, m, v only: the packed copies are rebuilt in a second pass once every rank's slice is back
+  // f32 chain steps on a single rank (train_chain32.h): thread 0 turns the fixed-point batch loss into the float
+  // slot(s) and clears the accumulator (the 16-bit chain leaves that to its weight-gradient kernel)
+  unsigned long long* loss_acc; float* loss_out; float* loss_out2; int loss_slot;
   AdamLayer lt[16];
 };
 // The layer an arena element belongs to: every block of 256 consecutive elements lies in ONE layer except the few
@@ -343,7 +346,15 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
       const long long pf = L.fw_off + ((((long long)(n >> 5) * L.KS + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 3) + (k & 7);
       // backward fragment (tile k/32, n-step n/16): lane = 32*((n%16)/8) + k%32, element n%8
       const long long pb = L.bw_off + ((((long long)(k >> 5) * L.NS + (n >> 4)) * 64 + ((n >> 3) & 1) * 32 + (k & 31)) << 3) + (n & 7);
-      if (a.cprec == 1) {
+      if (a.cprec == 3) {
+        // fp32 streams of train_chain32.h (KS / NS = fragments per 32-wide tile, two per k16 / n16 step):
+        // forward fragment (tile n/32, step k/16, half (n/16)%2): lane = n%16 + 16*((k%16)/4), element k%4
+        const long long qf = L.fw_off + ((((long long)(n >> 5) * L.KS + 2 * (k >> 4) + ((n >> 4) & 1)) * 64 + (n & 15) + 16 * ((k >> 2) & 3)) << 2) + (k & 3);
+        // backward fragment (tile k/32, step n/16, half (k/16)%2): lane = k%16 + 16*((n%16)/4), element n%4
+        const long long qb = L.bw_off + ((((long long)(k >> 5) * L.NS + 2 * (n >> 4) + ((k >> 4) & 1)) * 64 + (k & 15) + 16 * ((n >> 2) & 3)) << 2) + (n & 3);
+        reinterpret_cast<float*>(a.fw)[qf] = wi;
+        reinterpret_cast<float*>(a.bw)[qb] = wi;
+      } else if (a.cprec == 1) {
         reinterpret_cast<_Float16*>(a.fw)[pf] = (_Float16)wi;
         reinterpret_cast<_Float16*>(a.bw)[pb] = (_Float16)wi;
       } else {
@@ -362,6 +373,12 @@ __device__ __forceinline__ void adam_repack_block(const AdamArgs& a, long long b
   else adam_repack_element(a, i, alpha, a.lt[adam_layer_of(a, i)]);
 }
 __global__ void adam_repack_kernel(const AdamArgs a) {
+  if (a.loss_acc && blockIdx.x == 0 && threadIdx.x == 0) {
+    const float f = (float)((double)(long long)*a.loss_acc * (1.0 / 4294967296.0));
+    *a.loss_out = f;
+    if (a.loss_out2 && (a.sc.desc || a.loss_slot >= 0)) a.loss_out2[a.sc.desc ? a.sc.desc[*a.sc.cur].slot : a.loss_slot] = f;
+    *a.loss_acc = 0ull;
+  }
   adam_repack_block(a, a.i0 + (long long)blockIdx.x * blockDim.x, a.i0 + a.n, a.sc.desc ? a.sc.desc[*a.sc.cur].alpha : a.alpha);
 }
 // sweep form: blockIdx.y = model, argument blocks in device memory (one per model)

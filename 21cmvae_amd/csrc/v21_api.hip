@@ -24,6 +24,7 @@
 #include "gemm_nt.h"
 #include "train_kernels.h"
 #include "train_chain.h"
+#include "train_chain32.h"
 #include "dw_adam.h"
 
 using namespace v21;
@@ -780,6 +781,10 @@ struct v21_trainer {
   unsigned long long seed = 0;
   // one-kernel forward + activation-gradient chain (train_chain.h; f16 / bf16 stacks up to 512 wide)
   bool chain = false;
+  // the same chain in fp32 (train_chain32.h): f32 stacks up to 512 wide without a variational layer; d_fw / d_bw then
+  // hold fp32 fragments, fw_off / bw_off count floats, and the weight-gradient operands are d_ht / d_dzt
+  bool chain32 = false;
+  int loss_slot_pending = -2;  // f32 chain step on one rank: the Adam launch publishes the loss (-2: nothing pending)
   void *d_fw = nullptr, *d_bw = nullptr;
   long long fw_bytes = 0, bw_bytes = 0;
   std::vector<long long> fw_off, bw_off;  // element offsets per layer
@@ -951,6 +956,28 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
       }
     }
   }
+  {  // eligibility of the fp32 chain kernel (train_chain32.h)
+    const char* env = getenv("V21_TRAIN_CHAIN");
+    bool ok = precision == V21_PREC_F32 && !(env && env[0] == '0') && t->gl < 0;
+    int mask_tiles = 0;
+    for (int l = 0; l <= L && ok; ++l) ok = m->dims[l] <= kChainMaxDim;
+    for (int l = 0; l + 1 < L; ++l) mask_tiles += m->act[l] == V21_ACT_RELU ? (m->dims[l + 1] + 31) / 32 : 0;
+    ok = ok && mask_tiles <= kC32MaskTiles;
+    if (ok) {
+      long long of = 0, ob = 0;  // floats
+      for (int l = 0; l < L; ++l) {
+        const int K = m->dims[l], N = m->nw(l);
+        t->fw_off.push_back(of); of += (long long)((N + 31) / 32) * chain32_frags(K) * 256;
+        t->bw_off.push_back(ob); ob += (long long)((K + 31) / 32) * chain32_frags(N) * 256;
+      }
+      t->fw_bytes = of * 4; t->bw_bytes = ob * 4;
+      HIPCHK(hipMalloc(&t->d_fw, (size_t)of * 4 + 64)); HIPCHK(hipMemsetAsync(t->d_fw, 0, (size_t)of * 4 + 64, st));
+      HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 4 + 64)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 4 + 64, st));
+      HIPCHK(hipMalloc((void**)&t->d_ticket, 16)); HIPCHK(hipMemsetAsync(t->d_ticket, 0, 16, st));
+      HIPCHK(hipMalloc((void**)&t->d_stamps, 64 * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, 64 * 8, st));
+      t->chain32 = true;
+    }
+  }
   t->max_slices = std::max(1, (max_batch + 127) / 128);  // weight-gradient slices down to 8 batch steps
   CHK(zalloc(&t->d_slab, (size_t)t->max_slices * (t->P + 4), st));
   *out = t;
@@ -979,6 +1006,7 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   if (t->d_slab) hipFree(t->d_slab);
   if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
   if (t->d_dworder) hipFree(t->d_dworder);
+  if (t->chain32) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_ticket); hipFree(t->d_stamps); }
   if (t->chain) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_partial); hipFree(t->d_ticket); hipFree(t->d_stamps);
     for (void* p : t->d_ht16) if (p) hipFree(p);
     for (void* p : t->d_dzt16) if (p) hipFree(p); }
@@ -1171,10 +1199,18 @@ static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_n
     if (t->chain) {
       al.fw_off = t->fw_off[l]; al.bw_off = t->bw_off[l];
       al.KS = chain_steps(al.K); al.NS = chain_steps(al.N);
+    } else if (t->chain32) {
+      al.fw_off = t->fw_off[l]; al.bw_off = t->bw_off[l];
+      al.KS = chain32_frags(al.K); al.NS = chain32_frags(al.N);
     }
   }
   if (t->chain) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->prec == V21_PREC_F16 ? 1 : 2; }
-  a.skip_nt = (skip_nt && t->chain) ? 1 : 0;
+  if (t->chain32) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = 3; }
+  a.skip_nt = (skip_nt && (t->chain || t->chain32)) ? 1 : 0;
+  if (do_adam && t->chain32 && t->loss_slot_pending > -2) {  // a single-rank f32 chain step: this launch publishes its loss
+    a.loss_acc = (unsigned long long*)t->d_ticket; a.loss_out = t->d_g + t->P; a.loss_out2 = t->d_steploss;
+    a.loss_slot = t->loss_slot_pending;
+  }
   a.sc = step_ctx(t);
   return a;
 }
@@ -1401,7 +1437,9 @@ static int chain_attr(int prec) {
   (void)hipGetDevice(&dev);
   bool* done = done_dev[dev & 63];
   if (done[prec]) return V21_OK;
-  if (prec == V21_PREC_F16) {
+  if (prec == V21_PREC_F32) {
+    HIPCHK(hipFuncSetAttribute((const void*)train_chain32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC32LdsBytes));
+  } else if (prec == V21_PREC_F16) {
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_joint_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
@@ -1430,6 +1468,43 @@ static int launch_chain(v21_trainer* t, const float* x, long long ldx, const flo
   const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
   if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
   else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+
+// ---- the fp32 chain (train_chain32.h)
+static ChainModel chain_model32(v21_trainer* t) {
+  v21_mlp* m = t->mlp;
+  const int L = m->L;
+  ChainModel a{};
+  a.L = L;
+  int mt = 0;
+  for (int l = 0; l < L; ++l) {
+    ChainLayer& c = a.lt[l];
+    c.K = m->dims[l]; c.N = m->nw(l);
+    c.KS = chain32_frags(c.K); c.NT = (c.N + 31) / 32;   // fragments per 32-wide tile
+    c.NS = chain32_frags(c.N); c.KT = (c.K + 31) / 32;
+    c.relu = m->act[l] == V21_ACT_RELU;
+    c.mask_tile = -1;
+    if (c.relu && l + 1 < L) { c.mask_tile = mt; mt += c.NT; }
+    c.fw_off = t->fw_off[l] / 4; c.bw_off = t->bw_off[l] / 4;  // units of one lane's 16 bytes
+    c.b_off = m->b_off[l];
+    c.ht16 = t->d_ht[l]; c.dzt16 = t->d_dzt[l + 1];           // fp32, feature-major, batch contiguous (pitch Bp)
+  }
+  a.fw = t->d_fw; a.bw = t->d_bw; a.w = m->d_w;
+  a.fw_bytes = t->fw_bytes; a.bw_bytes = t->bw_bytes;
+  a.BS = t->Bp;
+  a.loss_acc = (unsigned long long*)t->d_ticket;
+  a.stamps = t->d_stamps;
+  a.zcap_layer = -1;
+  return a;
+}
+static int launch_chain32_args(ChainArgs& a, hipStream_t st) {
+  CHK(chain_attr(V21_PREC_F32));
+  a.ncons = (int)((((long long)a.rows + kC32Rows - 1) / kC32Rows + 7) / 8 * 8);  // whole rounds of the 8 XCDs
+  a.npref = chain_prefetchers(a.ncons, 1);
+  const dim3 grid(a.ncons + 8 * a.npref), block(64 * kC32Waves);
+  hipLaunchKernelGGL(train_chain32_kernel, grid, block, kC32LdsBytes, st, a);
   HIPCHK(hipGetLastError());
   return V21_OK;
 }
@@ -1665,10 +1740,73 @@ static int launch_dw_adam_group(const std::vector<v21_trainer*>& tr, const DwAda
 static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows, int brows, float* loss_out,
                         long long row0);
 // one optimizer step on rows [first, first+rows) (through d_idx when given) of (x, y, rw)
+static int launch_nt_many(int prec, std::vector<NtArgs>& probs, hipStream_t st);
+// one f32 optimizer step in THREE launches (train_chain32.h): the chain over this rank's rows, every layer's weight
+// gradient in one grouped NT launch on the fp32 operands the chain left, Adam (which also rebuilds the packed fp32
+// streams and, on a single rank, publishes the batch loss)
+static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
+                                 const int* d_idx, long long first, int rows, int brows, float* loss_out, long long row0) {
+  v21_mlp* m = t->mlp;
+  hipStream_t st = t->ctx->stream;
+  const int L = m->L, dout = m->dims[L];
+  if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
+  const bool single = t->ctx->nranks == 1;
+  const bool in_table = single && rows > 0 && loss_out && t->d_steploss && loss_out >= t->d_steploss &&
+                        loss_out < t->d_steploss + t->steploss_cap;
+  int fold = 1;
+  if (rows > 0) {
+    CHK(ensure_copies(t, false));
+    ChainArgs a{};
+    static_cast<ChainModel&>(a) = chain_model32(t);
+    static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, dout, t, row0);
+    a.gs = 1.0f;  // fp32 operands: no scaling of the gradients
+    CHK(launch_chain32_args(a, st));
+    int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
+    const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
+    nslice = (rows + k_chunk - 1) / k_chunk;
+    std::vector<NtArgs> probs;
+    for (int l = 0; l < L; ++l) {  // [dW; db] = [H^T; 1^T] dZ
+      NtArgs g{};
+      g.A = t->d_ht[l]; g.lda = t->Bp;
+      g.B = t->d_dzt[l + 1]; g.ldb = t->Bp;
+      g.C = (nslice > 1 ? t->d_slab : t->d_g) + m->w_off[l]; g.ldc = m->nw(l);
+      g.M = m->dims[l] + 1; g.N = m->nw(l); g.K = rows;
+      g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = (long long)t->P + 4;
+      probs.push_back(g);
+    }
+    CHK(launch_nt_many(t->prec, probs, st));
+    fold = nslice > 1 && single ? nslice : 1;  // single rank: Adam sums the slabs itself
+    if (nslice > 1 && fold == 1) {
+      const long long n4 = ((long long)t->P + 3) / 4;
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
+                         (const float*)t->d_slab, nslice, (long long)t->P + 4, (long long)t->P);
+      HIPCHK(hipGetLastError());
+    }
+    if (!single) {  // the loss numerator rides in slot P of the arena: it must be there before the exchange
+      hipLaunchKernelGGL(chain32_loss_kernel, dim3(1), dim3(1), 0, st, (unsigned long long*)t->d_ticket, t->d_g + t->P);
+      HIPCHK(hipGetLastError());
+    }
+  } else {
+    HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
+  }
+  t->loss_slot_pending = (single && rows > 0) ? (in_table ? (int)(loss_out - t->d_steploss) : -1) : -2;
+  int r;
+  if (t->capturing) r = adam_and_copies(t, true, 0.f, true, fold);  // recorded, not run: step size and slot come from the descriptors
+  else r = reduce_and_update(t, true, fold);
+  t->loss_slot_pending = -2;
+  CHK(r);
+  if (t->capturing) return V21_OK;
+  if (loss_out && !in_table) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+  invalidate_streams(m);
+  m->wpad_ok = true;
+  return V21_OK;
+}
+
 static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
                          const int* d_idx, long long first, int rows, int brows, float* loss_out, long long row0) {
   v21_mlp* m = t->mlp;
   const int L = m->L, din = m->dims[0], dout = m->dims[L];
+  if (t->chain32) return train_on_rows_chain32(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, loss_out, row0);
   if (!t->chain) {
     if (rows > 0) CHK(gather_batch(t, x, ldx, y, ldy, rw, d_idx, first, rows));
     const float* yb = y ? t->d_yb : t->d_h[0];
@@ -1790,6 +1928,7 @@ static int step_graph(v21_trainer* t, const float* x, long long ldx, const float
   // everything that may not happen inside a capture: lazy refreshes, function attributes
   CHK(ensure_copies(t, !t->chain));
   if (t->chain) { CHK(chain_attr(t->prec)); CHK(dw16_attr(t->prec)); }
+  if (t->chain32) CHK(chain_attr(V21_PREC_F32));
   hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { (void)hipGetLastError(); t->graph_mode = 0; return V21_OK; }  // e.g. the legacy stream: run eagerly
   t->capturing = true;
@@ -1819,7 +1958,7 @@ static void after_replay(v21_trainer* t) {
   t->iter += 1;
   t->desc_next += 1;
   t->copies_ok = true;
-  t->nt_ok = !t->chain;
+  t->nt_ok = !t->chain && !t->chain32;
   invalidate_streams(t->mlp);
   t->mlp->wpad_ok = true;
 }
@@ -1898,6 +2037,22 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
   const long long n = t->n[which];
   const int din = m->dims[0], dout = m->dims[m->L];
   if (batch < 1) return fail(V21_ERR_ARG, "batch must be >= 1");
+  if (t->chain32) {  // the same in fp32 (train_chain32.h)
+    if (n > (1ll << 30)) return fail(V21_ERR_ARG, "too many rows for one validation launch");
+    CHK(ensure_copies(t, false));
+    ChainArgs a{};
+    static_cast<ChainModel&>(a) = chain_model32(t);
+    static_cast<ChainStep&>(a) = chain_step(t->d_x[which], din, t->y_is_x[which] ? nullptr : t->d_y[which], dout,
+                                            t->d_rw[which], nullptr, 0, (int)n, (int)n, dout);
+    a.fwd_only = 1;
+    CHK(launch_chain32_args(a, st));
+    long long acc = 0;
+    HIPCHK(hipMemcpyAsync(&acc, t->d_ticket, sizeof acc, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(t->d_ticket, 0, sizeof acc, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *loss = (double)acc * (1.0 / 4294967296.0) / (double)n;
+    return V21_OK;
+  }
   if (t->chain) {
     // ONE forward-only launch of the chain kernel over all n rows (csrc/train_chain.h: fwd_only) instead of 8 launches
     // per batch of the per-layer path: the same arithmetic as the training loss of this precision, no noise drawn
@@ -2514,7 +2669,7 @@ extern "C" int v21_trainer_set_vae(v21_trainer* t, float kl_weight, int sample, 
 extern "C" int v21_trainer_chain_stamps(v21_trainer* t, uint64_t* out, int n) {
   if (!t || !out) return fail(V21_ERR_ARG, "null argument");
   if (n < 1 || n > 64) return fail(V21_ERR_ARG, "n must be in [1,64]");
-  if (!t->chain) return fail(V21_ERR_STATE, "this trainer does not use the chain kernel");
+  if (!t->chain && !t->chain32) return fail(V21_ERR_STATE, "this trainer does not use the chain kernel");
   CHK(use(t->ctx));
   HIPCHK(hipMemcpyAsync(out, t->d_stamps, (size_t)n * 8, hipMemcpyDeviceToHost, t->ctx->stream));
   HIPCHK(hipStreamSynchronize(t->ctx->stream));

@@ -567,17 +567,93 @@ def test_one_launch_gradient_adam_kernel_state_and_packed_copies(ctx, prec, dims
         ostate.m[:] = m; ostate.v[:] = v
 
 
+@pytest.mark.parametrize("case", ["autoencoder_ragged", "direct_7_to_451", "latent_emulator", "batch_4096", "single_row"])
+def test_f32_chain_kernel_matches_per_layer_path_and_oracle(ctx, case):
+    """csrc/train_chain32.h (the fp32 chain: 16-row blocks on the 16 x 16 x 4 MFMA, weight gradients in one grouped NT
+    launch, Adam) against the per-layer f32 path (V21_TRAIN_CHAIN=0) and the float64 oracle at the stated f32 tolerance:
+    loss 2e-5, gradient 2e-4 of its scale, weights after the step, Adam moments; then two more epochs with a partial
+    last batch and the forward-only validation launch."""
+    import os
+    native, synth = pkg("_native"), pkg("synth")
+    if case == "direct_7_to_451":
+        dims, act, n = [7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0], 300
+        par = synth.make_params(n, seed=3)
+        x = ora.par_transform(par, par).astype(np.float32)
+        sig = synth.signals_from_params(par)
+        y = ora.preproc(sig, sig)
+        w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    elif case == "latent_emulator":
+        dims, act, n = [7, 352, 352, 352, 224, 9], [1, 1, 1, 1, 0], 257
+        rng = np.random.default_rng(3)
+        x = rng.uniform(-1, 1, size=(n, 7)).astype(np.float32)
+        y = rng.normal(size=(n, 9)).astype(np.float32)
+        w = ora.mse_row_weight(y).astype(np.float32)
+    else:
+        dims, act = [451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0]
+        n = {"autoencoder_ragged": 203, "batch_4096": 4096, "single_row": 1}[case]
+        sig = synth.make_signals(max(n, 4), seed=13)[:n]
+        x = ora.preproc(sig, sig); y = None
+        w = ora.relative_mse_row_weight(x, sig).astype(np.float32)
+    perm = np.random.default_rng(2).permutation(n).astype(np.int32)
+    batch = max(n, 2)
+    res = {}
+    for chain in (True, False):
+        old = os.environ.get("V21_TRAIN_CHAIN")
+        os.environ["V21_TRAIN_CHAIN"] = "1" if chain else "0"
+        try:
+            Ws, bs = ora.init_mlp(dims, seed=31)
+            st = native.Stack(ctx, dims, act)
+            st.set_weights(ora.flatten_params(Ws, bs))
+            tr = native.Trainer(st, "f32", batch)
+        finally:
+            if old is None:
+                os.environ.pop("V21_TRAIN_CHAIN")
+            else:
+                os.environ["V21_TRAIN_CHAIN"] = old
+        tr.set_adam(lr=1e-3)
+        tr.set_data(0, x, y, w)
+        tr.set_data(1, x[: max(1, n // 3)], None if y is None else y[: max(1, n // 3)], w[: max(1, n // 3)])
+        loss = tr.run_epoch(perm, batch)
+        g = tr.get_grad().astype(np.float64)
+        w1 = st.get_weights()
+        it, m1, v1 = tr.get_state()
+        more = [tr.run_epoch(ora.epoch_permutation(n, 5, ep), max(2, (n + 2) // 3)) for ep in range(2)]
+        val = tr.evaluate(1, batch)
+        res[chain] = (loss, g, w1, m1, v1, np.array(more + [val]), st.get_weights(), tr.get_state()[0])
+    # float64 oracle of the first step
+    W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
+    xs = x[perm].astype(np.float64); ys = xs if y is None else y[perm].astype(np.float64)
+    sto = ora.AdamState(st.num_params, dtype=np.float64, lr=1e-3)
+    W2, b2, lo, go = ora.train_step(W, b, sto, xs, ys, w[perm].astype(np.float64), np.float64)
+    lc, gc, wc, mc, vc, morec, wend, itc = res[True]
+    ln, gn, wn, mn, vn, moren, wendn, itn = res[False]
+    assert abs(lc - lo) / lo < 2e-5 and abs(lc - ln) / ln < 2e-5, (lc, ln, lo)
+    _close(gc, go, 2e-4, "gradient vs oracle")
+    _close(gc, gn, 2e-4, "gradient vs per-layer path")
+    _close(mc, sto.m, 2e-4, "adam m")
+    _close(vc, sto.v, 4e-4, "adam v")
+    _close(wc, ora.flatten_params(W2, b2), 1e-5, "weights after 1 step")
+    np.testing.assert_allclose(morec, moren, rtol=2e-4)  # later epochs + validation: the two paths stay together
+    assert itc == itn
+    d1, d2 = wend - ora.flatten_params(Ws, bs), wendn - ora.flatten_params(Ws, bs)
+    assert _cos(d1.astype(np.float64), d2.astype(np.float64)) > 0.999
+
+
 def test_chain_path_is_actually_used(ctx):
-    """f16/bf16 trainers of stacks up to 512 wide (variational heads up to 32 latent dimensions) run the
-    chain kernel (its stamps exist); f32, wider stacks and wider latents take the per-layer path."""
+    """Trainers of stacks up to 512 wide run a chain kernel (its stamps exist): f16 / bf16 (variational heads up to 32
+    latent dimensions) and, from r3 on, f32 without a variational layer (train_chain32.h); wider stacks, wider latents
+    and variational f32 stacks take the per-layer path."""
     native = pkg("_native")
     st = native.Stack(ctx, [16, 32, 16], [1, 0])
     x = np.zeros((8, 16), np.float32); w = np.ones(8, np.float32)
     tr = native.Trainer(st, "f16", 8); tr.set_data(0, x, None, w); tr.run_epoch(None, 8)
     s = tr.chain_stamps(6)
     assert s[0] > 0 and np.all(np.diff(s.astype(np.int64)[:5]) > 0)
-    for stack, prec in ((st, "f32"), (native.Stack(ctx, [16, 600, 16], [1, 0]), "f16"),
-                        (native.Stack(ctx, [16, 40, 16], [2, 0]), "bf16")):
+    t32 = native.Trainer(st, "f32", 8); t32.set_data(0, x, None, w); t32.run_epoch(None, 8)
+    s32 = t32.chain_stamps(6)
+    assert s32[0] > 0 and np.all(np.diff(s32.astype(np.int64)[:5]) > 0)
+    for stack, prec in ((native.Stack(ctx, [16, 600, 16], [1, 0]), "f32"), (native.Stack(ctx, [16, 600, 16], [1, 0]), "f16"),
+                        (native.Stack(ctx, [16, 40, 16], [2, 0]), "bf16"), (native.Stack(ctx, [16, 8, 16], [2, 0]), "f32")):
         t2 = native.Trainer(stack, prec, 8)
         with pytest.raises(native.EngineError):
             t2.chain_stamps(4)
