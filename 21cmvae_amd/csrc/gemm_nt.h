@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fused_fwd.h"
+#include "train_kernels.h"  // StepCtx
 
 namespace v21 {
 
@@ -62,6 +63,20 @@ enum { NT_FWD = 0, NT_FWD_RELU = 1, NT_DX = 2, NT_DX_MASK = 3, NT_DW = 4, NT_FWD
 
 constexpr int kNtMaxKPerWg = 512;
 
+// NT_DW with Adam in the epilogue (f32 chain steps on one rank whose batch fits one contraction slice, train_chain32.h):
+// the workgroup that forms a 32 x 32 tile of [dW; db] over the whole batch applies the update to the tile's arena
+// elements and rewrites their places in the packed fp32 weight streams -- no separate Adam launch (9 us of a 77-us step:
+// 3 us of launch, the gradient read back, scattered 4-byte stores either way).  Common to every problem of the group:
+struct NtAdamLayer { long long arena_off, fw_off, bw_off; int K, KS, NS; };  // per problem: [W; b] block, stream offsets (floats)
+struct NtAdamInfo {
+  float *w, *m, *v;            // arena, first and second moments (same layout as the gradient arena C points into)
+  float* fw; float* bw;        // packed fp32 streams (train_chain32.h)
+  float alpha, omb1, omb2, eps;
+  StepCtx sc;                  // replayed step: alpha and the loss slot come from the descriptor
+  unsigned long long* loss_acc; float* loss_out; float* loss_out2; int loss_slot;  // the step's batch loss (thread 0 of block 0)
+  NtAdamLayer lt[kNtMaxGroup];
+};
+
 template <class P> struct NtTraits;
 template <> struct NtTraits<PrecF32> { static constexpr int KSTEP = 8, MAXSTEPS = 16, REGS = 4; };
 template <> struct NtTraits<PrecF16> { static constexpr int KSTEP = 16, MAXSTEPS = 8, REGS = 8; };
@@ -70,8 +85,8 @@ template <> struct NtTraits<PrecBF16> { static constexpr int KSTEP = 16, MAXSTEP
 // T = MFMA tiles per side of the workgroup tile: T = 1 -> 32x32 (latency: small batches),
 // T = 2 -> 64x64 (twice the arithmetic intensity per loaded byte: large batches; the
 // contraction range of a wave is then walked in rounds of <= MAXSTEPS/2 k-steps).
-template <class P, int T, class GROUP>
-__global__ void __launch_bounds__(256) gemm_nt_kernel(const GROUP grp) {
+template <class P, int T, class GROUP, bool ADAM = false>
+__device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo* ad) {
   using TR = NtTraits<P>;
   int pi = 0;
   while (pi + 1 < grp.count && (int)blockIdx.x >= grp.first[pi + 1]) ++pi;  // uniform: scalar loop
@@ -199,6 +214,24 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GROUP grp) {
         if (EP == NT_DX_MASK) v = (m < g.M && g.mask[(long long)m * g.ldmask + n] > 0.f) ? v : 0.f;
         r[e] = v;
         if (m < g.M) C[(long long)m * g.ldc + n] = v;
+        if constexpr (ADAM) {
+          if (m < g.M) {  // Keras Adam on this element (train_kernels.h: adam_update_element) + its packed copies
+            const NtAdamLayer& al = ad->lt[pi];
+            const long long i = al.arena_off + (long long)m * g.ldc + n;
+            const float alpha = ad->sc.desc ? ad->sc.desc[*ad->sc.cur].alpha : ad->alpha;
+            const float m0 = ad->m[i], v0 = ad->v[i];
+            const float mi = m0 + (v - m0) * ad->omb1;
+            const float vi = v0 + (v * v - v0) * ad->omb2;
+            const float wi = ad->w[i] - (mi * alpha) / (sqrtf(vi) + ad->eps);
+            ad->m[i] = mi; ad->v[i] = vi; ad->w[i] = wi;
+            if (m < al.K) {  // a kernel element (the bias row has no packed copy); k = m
+              const long long qf = al.fw_off + ((((long long)(n >> 5) * al.KS + 2 * (m >> 4) + ((n >> 4) & 1)) * 64 + (n & 15) + 16 * ((m >> 2) & 3)) << 2) + (m & 3);
+              const long long qb = al.bw_off + ((((long long)(m >> 5) * al.NS + 2 * (n >> 4) + ((m >> 4) & 1)) * 64 + (m & 15) + 16 * ((n >> 2) & 3)) << 2) + (n & 3);
+              ad->fw[qf] = wi;
+              ad->bw[qb] = wi;
+            }
+          }
+        }
       }
       if (EP != NT_DW && g.CT) {  // rows of the transposed copy are padded past the batch: no bound check on m
         float4 t4 = make_float4(mrow + 0 < g.M ? r[0] : 0.f, mrow + 1 < g.M ? r[1] : 0.f, mrow + 2 < g.M ? r[2] : 0.f,
@@ -207,6 +240,22 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GROUP grp) {
       }
     }
   }
+}
+
+template <class P, int T, class GROUP>
+__global__ void __launch_bounds__(256) gemm_nt_kernel(const GROUP grp) {
+  gemm_nt_body<P, T, GROUP, false>(grp, nullptr);
+}
+// every weight gradient of an f32 chain step + Adam + the packed copies in one launch (NtAdamInfo above)
+template <int T>
+__global__ void __launch_bounds__(256) gemm_nt_dwadam_kernel(const NtGroupBig grp, const NtAdamInfo ad) {
+  if (ad.loss_acc && blockIdx.x == 0 && threadIdx.x == 0) {
+    const float f = (float)((double)(long long)*ad.loss_acc * (1.0 / 4294967296.0));
+    *ad.loss_out = f;
+    if (ad.loss_out2 && (ad.sc.desc || ad.loss_slot >= 0)) ad.loss_out2[ad.sc.desc ? ad.sc.desc[*ad.sc.cur].slot : ad.loss_slot] = f;
+    *ad.loss_acc = 0ull;
+  }
+  gemm_nt_body<PrecF32, T, NtGroupBig, true>(grp, &ad);
 }
 
 }  // namespace v21

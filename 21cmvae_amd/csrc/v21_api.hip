@@ -1774,6 +1774,46 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
       g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = (long long)t->P + 4;
       probs.push_back(g);
     }
+    if (single && nslice == 1 && L <= kNtMaxGroup && !(getenv("V21_DW32_ADAM") && getenv("V21_DW32_ADAM")[0] == '0')) {
+      // one rank, the batch is one contraction slice: gradients, Adam, the packed fp32 streams and the batch loss in ONE
+      // launch (gemm_nt.h: NtAdamInfo) -- the step is 2 launches
+      NtGroupBig grp{};
+      grp.count = L;
+      long long work = 0;
+      for (int l = 0; l < L; ++l) work += (long long)((probs[l].M + 63) / 64) * ((probs[l].N + 63) / 64);
+      const int T = work >= 192 ? 2 : 1;
+      int blocks = 0;
+      NtAdamInfo ad{};
+      for (int l = 0; l < L; ++l) {
+        NtArgs& g = grp.p[l];
+        g = probs[l];
+        g.tile = 32 * T;
+        g.nx = (g.N + g.tile - 1) / g.tile; g.ny = (g.M + g.tile - 1) / g.tile; g.nz = 1;
+        g.a_scale = g.b_scale = g.out_scale = 1.f;
+        g.k_chunk = g.K; g.slab_stride = 0;
+        grp.first[l] = blocks;
+        blocks += g.nx * g.ny;
+        ad.lt[l] = NtAdamLayer{m->w_off[l], t->fw_off[l], t->bw_off[l], m->dims[l], chain32_frags(m->dims[l]), chain32_frags(m->nw(l))};
+      }
+      grp.first[L] = blocks;
+      if (!t->capturing) t->iter += 1;
+      ad.w = m->d_w; ad.m = t->d_m; ad.v = t->d_v; ad.fw = (float*)t->d_fw; ad.bw = (float*)t->d_bw;
+      ad.alpha = t->capturing ? 0.f : adam_alpha(t->adam, t->iter);
+      ad.omb1 = 1.0f - t->adam.beta1; ad.omb2 = 1.0f - t->adam.beta2; ad.eps = t->adam.eps;
+      ad.sc = step_ctx(t);
+      ad.loss_acc = (unsigned long long*)t->d_ticket; ad.loss_out = t->d_g + t->P; ad.loss_out2 = t->d_steploss;
+      ad.loss_slot = in_table ? (int)(loss_out - t->d_steploss) : -1;
+      if (T == 2) hipLaunchKernelGGL(gemm_nt_dwadam_kernel<2>, dim3(blocks), dim3(256), 0, st, grp, ad);
+      else hipLaunchKernelGGL(gemm_nt_dwadam_kernel<1>, dim3(blocks), dim3(256), 0, st, grp, ad);
+      HIPCHK(hipGetLastError());
+      t->copies_ok = true;
+      t->nt_ok = false;
+      if (t->capturing) return V21_OK;
+      if (loss_out && !in_table) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
+      invalidate_streams(m);
+      m->wpad_ok = true;
+      return V21_OK;
+    }
     CHK(launch_nt_many(t->prec, probs, st));
     fold = nslice > 1 && single ? nslice : 1;  // single rank: Adam sums the slabs itself
     if (nslice > 1 && fold == 1) {
