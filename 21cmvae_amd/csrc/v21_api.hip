@@ -271,8 +271,8 @@ struct v21_mlp {
   void* d_cfw[3] = {nullptr, nullptr, nullptr};
   void* d_cbw[3] = {nullptr, nullptr, nullptr};
   bool cfw_ok[3] = {false, false, false};
-  std::vector<long long> cfw_off, cbw_off;  // element offsets per layer
-  long long cfw_bytes = 0, cbw_bytes = 0;
+  std::vector<long long> cfw_off[2], cbw_off[2];  // element offsets per layer; [0]: 16-bit streams, [1]: fp32 (train_chain32.h)
+  long long cfw_bytes[2] = {0, 0}, cbw_bytes[2] = {0, 0};
   v21_affine_in* d_tin = nullptr;           // device copy of the input transform
   // width of layer l's Dense output: dims[l+1], or 2*dims[l+1] = [z_mean | z_log_var] for V21_ACT_GAUSS
   int nw(int l) const { return act[l] == V21_ACT_GAUSS ? 2 * dims[l + 1] : dims[l + 1]; }
@@ -518,11 +518,11 @@ static int forward_small(v21_mlp* m, const float* d_x, long long ldx, long long 
 // emulator.py:12-48; the members of a sweep).  r3, 65,536 rows: the per-layer K-loop path took 0.85 ms on the
 // headline stack (15x the fused kernel) and 0.35 ms on the sample notebook's 7 -> [64, 128] -> 451 model.
 static bool chain_fwd_eligible(const v21_mlp* m, int precision, int flags) {
-  if (precision == V21_PREC_F32 || (flags & V21_FWD_FORCE_GENERIC)) return false;
+  if (flags & V21_FWD_FORCE_GENERIC) return false;
   for (int l = 0; l <= m->L; ++l)
     if (m->dims[l] > kChainMaxDim) return false;
   for (int l = 0; l < m->L; ++l)
-    if (m->act[l] == V21_ACT_GAUSS && (m->dims[l + 1] > kChainMaxLatent || l == m->L - 1)) return false;
+    if (m->act[l] == V21_ACT_GAUSS && (precision == V21_PREC_F32 || m->dims[l + 1] > kChainMaxLatent || l == m->L - 1)) return false;
   if ((flags & V21_FWD_IN_TRANSFORM) && m->dims[0] > 8) return false;
   return true;
 }
@@ -1514,27 +1514,29 @@ static int ensure_chain_stream(v21_mlp* m, int prec) {
   if (m->cfw_ok[prec]) return V21_OK;
   hipStream_t st = m->ctx->stream;
   const int L = m->L;
-  if (m->cfw_off.empty()) {
-    long long of = 0, ob = 0;
+  const int pc = prec == V21_PREC_F32 ? 1 : 0;
+  const int esz = pc ? 4 : 2;
+  if (m->cfw_off[pc].empty()) {
+    long long of = 0, ob = 0;  // elements
     for (int l = 0; l < L; ++l) {
       const int K = m->dims[l], N = m->nw(l);
-      m->cfw_off.push_back(of); of += (long long)((N + 31) / 32) * chain_steps(K) * 512;
-      m->cbw_off.push_back(ob); ob += (long long)((K + 31) / 32) * chain_steps(N) * 512;
+      m->cfw_off[pc].push_back(of); of += (long long)((N + 31) / 32) * (pc ? chain32_frags(K) * 256 : chain_steps(K) * 512);
+      m->cbw_off[pc].push_back(ob); ob += (long long)((K + 31) / 32) * (pc ? chain32_frags(N) * 256 : chain_steps(N) * 512);
     }
-    m->cfw_bytes = of * 2; m->cbw_bytes = ob * 2;
+    m->cfw_bytes[pc] = of * esz; m->cbw_bytes[pc] = ob * esz;
   }
   if (!m->d_cfw[prec]) {
-    HIPCHK(hipMalloc(&m->d_cfw[prec], (size_t)m->cfw_bytes + 64)); HIPCHK(hipMemsetAsync(m->d_cfw[prec], 0, (size_t)m->cfw_bytes + 64, st));
-    HIPCHK(hipMalloc(&m->d_cbw[prec], (size_t)m->cbw_bytes + 64)); HIPCHK(hipMemsetAsync(m->d_cbw[prec], 0, (size_t)m->cbw_bytes + 64, st));
+    HIPCHK(hipMalloc(&m->d_cfw[prec], (size_t)m->cfw_bytes[pc] + 64)); HIPCHK(hipMemsetAsync(m->d_cfw[prec], 0, (size_t)m->cfw_bytes[pc] + 64, st));
+    HIPCHK(hipMalloc(&m->d_cbw[prec], (size_t)m->cbw_bytes[pc] + 64)); HIPCHK(hipMemsetAsync(m->d_cbw[prec], 0, (size_t)m->cbw_bytes[pc] + 64, st));
   }
   AdamArgs a{};  // the arena -> the packed streams (the trainer's repacking kernel without the Adam update)
   a.w = m->d_w; a.n = (long long)m->nparams; a.L = L; a.do_adam = 0; a.skip_nt = 1;
-  a.fw = m->d_cfw[prec]; a.bw = m->d_cbw[prec]; a.cprec = prec == V21_PREC_F16 ? 1 : 2;
+  a.fw = m->d_cfw[prec]; a.bw = m->d_cbw[prec]; a.cprec = prec == V21_PREC_F32 ? 3 : prec == V21_PREC_F16 ? 1 : 2;
   for (int l = 0; l < L; ++l) {
     AdamLayer& al = a.lt[l];
     al.w_off = m->w_off[l]; al.K = m->dims[l]; al.N = m->nw(l);
-    al.fw_off = m->cfw_off[l]; al.bw_off = m->cbw_off[l];
-    al.KS = chain_steps(al.K); al.NS = chain_steps(al.N);
+    al.fw_off = m->cfw_off[pc][l]; al.bw_off = m->cbw_off[pc][l];
+    al.KS = pc ? chain32_frags(al.K) : chain_steps(al.K); al.NS = pc ? chain32_frags(al.N) : chain_steps(al.N);
   }
   hipLaunchKernelGGL(adam_repack_kernel, dim3((unsigned)((m->nparams + 255) / 256)), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
@@ -1545,6 +1547,7 @@ static int forward_chain(v21_mlp* m, const float* d_x, long long ldx, long long 
                          int flags) {
   hipStream_t st = m->ctx->stream;
   const int L = m->L;
+  const int pc = prec == V21_PREC_F32 ? 1 : 0;
   CHK(ensure_chain_stream(m, prec));
   CHK(chain_attr(prec));
   ChainArgs a{};
@@ -1553,15 +1556,15 @@ static int forward_chain(v21_mlp* m, const float* d_x, long long ldx, long long 
     ChainLayer& c = a.lt[l];
     c.K = m->dims[l]; c.N = m->nw(l);
     c.gauss = m->act[l] == V21_ACT_GAUSS;
-    c.KS = chain_steps(c.K); c.NT = (c.N + 31) / 32;
-    c.NS = chain_steps(c.N); c.KT = (c.K + 31) / 32;
+    c.KS = pc ? chain32_frags(c.K) : chain_steps(c.K); c.NT = (c.N + 31) / 32;
+    c.NS = pc ? chain32_frags(c.N) : chain_steps(c.N); c.KT = (c.K + 31) / 32;
     c.relu = m->act[l] == V21_ACT_RELU;
     c.mask_tile = -1;  // no backward pass: no ReLU masks kept
-    c.fw_off = m->cfw_off[l] / 8; c.bw_off = m->cbw_off[l] / 8;
+    c.fw_off = m->cfw_off[pc][l] / (pc ? 4 : 8); c.bw_off = m->cbw_off[pc][l] / (pc ? 4 : 8);  // units of one lane's 16 bytes
     c.b_off = m->b_off[l];
   }
   a.fw = m->d_cfw[prec]; a.bw = m->d_cbw[prec]; a.w = m->d_w;
-  a.fw_bytes = m->cfw_bytes; a.bw_bytes = 0;  // (the prefetchers touch the forward stream only)
+  a.fw_bytes = m->cfw_bytes[pc]; a.bw_bytes = 0;  // (the prefetchers touch the forward stream only)
   a.zcap_layer = -1;
   a.sample = 0;  // a variational head evaluates z = z_mean (include/v21.h)
   a.x = d_x; a.ldx = ldx; a.rows = (int)n;
@@ -1571,6 +1574,7 @@ static int forward_chain(v21_mlp* m, const float* d_x, long long ldx, long long 
   a.out_std = tout ? m->out_std : 1.0f;
   a.out_mean = tout ? m->d_mean : nullptr;
   a.tin = ((flags & V21_FWD_IN_TRANSFORM) && m->has_tin) ? m->d_tin : nullptr;
+  if (pc) return launch_chain32_args(a, st);
   a.ncons = (int)(((n + 31) / 32 + 7) / 8 * 8);
   a.npref = chain_prefetchers(a.ncons, 1);
   const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);

@@ -662,7 +662,8 @@ def main():
             out["predict_generic_S1"] = gen
             # the table-driven one-launch forward (csrc/train_chain.h FORWARD mode: what every stack without a compiled
             # kernel runs in f16 / bf16), forced onto the headline stack for comparison with the compiled kernel
-            td = {prec: fwd_rate(stack, DIMS, prec, flags | native.FWD_FORCE_CHAIN) for prec in ("f16", "bf16")}
+            td = {prec: fwd_rate(stack, DIMS, prec, flags | native.FWD_FORCE_CHAIN) for prec in ("f16", "bf16", "f32")}
+            td["f32"]["slowdown_vs_fused"] = modes.get("f32", {}).get("signals_per_s", 0.0) / td["f32"]["signals_per_s"]
             td["f16"]["slowdown_vs_fused"] = (out["value"] if args.precision == "f16" else modes.get("f16", {}).get("signals_per_s", 0.0)) / td["f16"]["signals_per_s"]
             out["predict_table_driven_S1"] = td
             cdims = [7, 64, 128, 451]
