@@ -107,6 +107,7 @@ SIGNATURES = {
     "v21_joint_create": (C.c_int, [_P, _P, C.c_int, C.POINTER(_P)]),
     "v21_joint_destroy": (C.c_int, [_P]),
     "v21_joint_run_epoch": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_double)]),
+    "v21_joint_eval": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "v21_comm_get_unique_id": (C.c_int, [_P, _P]),
     "v21_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "v21_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(CommHostOps)]),
@@ -529,6 +530,12 @@ class Joint:
             perm = np.ascontiguousarray(perm, dtype=np.int32)
             pp = perm.ctypes.data_as(C.POINTER(C.c_int32))
         check(self.lib.v21_joint_run_epoch(self.h, pp, int(batch), out))
+        return float(out[0]), float(out[1])
+
+    def evaluate(self):
+        """-> (autoencoder validation loss, emulator validation loss against the current encoder's latents)"""
+        out = (C.c_double * 2)()
+        check(self.lib.v21_joint_eval(self.h, out))
         return float(out[0]), float(out[1])
 
 

@@ -2703,6 +2703,56 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
   return V21_OK;
 }
 
+// validation of both models in ONE launch: the autoencoder's loss on its validation signals, and the emulator's loss on
+// the validation parameters against the latents the CURRENT encoder produces for the validation signals (what the
+// reference gets from encoder.predict(signal_val), emulator.py:754) -- no host round trip for the latents
+extern "C" int v21_joint_eval(v21_joint* j, double* losses) {
+  if (!j || !losses) return fail(V21_ERR_ARG, "null argument");
+  v21_trainer *ta = j->ae, *te = j->em;
+  if (ta->n[1] < 1 || te->n[1] != ta->n[1]) return fail(V21_ERR_STATE, "both trainers need validation sets of the same row count");
+  if (!ta->y_is_x[1]) return fail(V21_ERR_STATE, "the autoencoder's validation targets must be its inputs (y == NULL)");
+  CHK(use(ta->ctx));
+  hipStream_t st = ta->ctx->stream;
+  const long long n = ta->n[1];
+  if (n > (1ll << 30)) return fail(V21_ERR_ARG, "too many rows for one validation launch");
+  for (v21_trainer* t : {ta, te}) CHK(ensure_copies(t, false));
+  {
+    std::vector<ChainModel> tab = {chain_model(ta), chain_model(te)};
+    tab[0].zcap_layer = j->latent_layer;
+    tab[0].sample = 0;  // evaluation passes draw no noise
+    if (tab.size() != j->h_tab.size() || memcmp(tab.data(), j->h_tab.data(), 2 * sizeof(ChainModel)) != 0) {
+      HIPCHK(hipStreamSynchronize(st));
+      j->h_tab = tab;
+      HIPCHK(hipMemcpyAsync(j->d_tab, j->h_tab.data(), 2 * sizeof(ChainModel), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  }
+  CHK(chain_attr(ta->prec));
+  const int dsig = ta->mlp->dims[0], dpar = te->mlp->dims[0], dlat = te->mlp->dims[te->mlp->L];
+  ChainStep sa = chain_step(ta->d_x[1], dsig, nullptr, dsig, ta->d_rw[1], nullptr, 0, (int)n, (int)n, dsig);
+  ChainStep sb = chain_step(te->d_x[1], dpar, nullptr, dlat, te->d_rw[1], nullptr, 0, (int)n, (int)n, dlat);
+  sa.fwd_only = sb.fwd_only = 1;
+  sb.y_from_lds = 1;
+  sa.ncons = sb.ncons = (int)(((n + 31) / 32 + 7) / 8 * 8);
+  sb.blk0 = sa.ncons;
+  sa.npref = sb.npref = chain_prefetchers(2 * sa.ncons, 1);
+  const dim3 grid(2 * sa.ncons + 8 * sa.npref), block(64 * kChainWaves);
+  if (ta->prec == V21_PREC_F16)
+    hipLaunchKernelGGL(train_chain_joint_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+  else
+    hipLaunchKernelGGL(train_chain_joint_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+  HIPCHK(hipGetLastError());
+  long long acc[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(&acc[0], ta->d_ticket, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&acc[1], te->d_ticket, sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemsetAsync(ta->d_ticket, 0, sizeof(long long), st));
+  HIPCHK(hipMemsetAsync(te->d_ticket, 0, sizeof(long long), st));
+  HIPCHK(hipStreamSynchronize(st));
+  losses[0] = (double)acc[0] * (1.0 / 4294967296.0) / (double)n;
+  losses[1] = (double)acc[1] * (1.0 / 4294967296.0) / (double)n;
+  return V21_OK;
+}
+
 extern "C" int v21_trainer_set_vae(v21_trainer* t, float kl_weight, int sample, uint64_t seed) {
   if (!t) return fail(V21_ERR_ARG, "null trainer");
   if (t->gl < 0) return fail(V21_ERR_STATE, "the stack has no V21_ACT_GAUSS layer");

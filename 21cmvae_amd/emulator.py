@@ -354,6 +354,8 @@ class AutoEncoderEmulator(_EmulatorBase):
         tra.set_data(1, y_val, None, ae._row_weight(y_val))
         zdummy = np.zeros((n, lat), np.float32)
         tre.set_data(0, X_train, zdummy, em._row_weight(zdummy))
+        zdv = np.zeros((X_val.shape[0], lat), np.float32)
+        tre.set_data(1, X_val, zdv, em._row_weight(zdv))  # (targets: the encoder's latents of y_val, formed on the device)
         joint = nat.Joint(tra, tre, latent_layer=len(ae.encoder.layers) - 1)
         dp = tra.ctx.nranks > 1
         if dp:  # data parallel: the replicas must start equal and shuffle alike (as engine.Model.fit does)
@@ -394,16 +396,16 @@ class AutoEncoderEmulator(_EmulatorBase):
             else:  # the emulator has stopped: the autoencoder goes on alone
                 la, le = tra.run_epoch(perm, batch_size), None
             ae._dirty_host = em._dirty_host = True
+            # both validation passes in one launch; the emulator's against the current encoder's latents of the
+            # validation signals (the reference's encoder.predict(signal_val), emulator.py:754, without leaving the device)
+            va, ve = joint.evaluate() if em_running else (tra.evaluate(1, batch_size), None)
             if ae_running:
-                logs = {"loss": la, "val_loss": tra.evaluate(1, batch_size)}
+                logs = {"loss": la, "val_loss": va}
                 cbs[0].on_epoch_end(epoch, logs)
                 if ae.stop_training:
                     ae_running = False  # frozen from here on: the reference's phase 2
             if em_running:
-                ae._sync_host()
-                z_val = ae.encoder.predict(y_val)
-                tre.set_data(1, X_val, z_val, em._row_weight(z_val))
-                logs = {"loss": le, "val_loss": tre.evaluate(1, batch_size)}
+                logs = {"loss": le, "val_loss": ve}
                 cbs[1].on_epoch_end(epoch, logs)
                 if em.stop_training:
                     em_running = False

@@ -187,11 +187,18 @@ int v21_trainer_get_grad(v21_trainer* tr, float* g, size_t n);
  * gradient flows back into the encoder).  With the autoencoder's learning rate at 0 it is exactly the
  * reference's second phase.  `ae` holds the signals (set_data(0, signals, NULL, w)), `em` the parameters of the
  * same rows (its y argument is ignored); latent_layer = index of the encoder's linear output layer in `ae`'s
- * stack.  f16 / bf16 trainers (chain kernel), one rank.  losses[0] = autoencoder, losses[1] = emulator. */
+ * stack (linear, or the V21_ACT_GAUSS head: the emulator then learns z_mean).  f16 / bf16 trainers (chain kernel); with a
+ * communicator on the context every rank carries its share of every batch and each model's gradients are exchanged as
+ * in a plain step.  losses[0] = autoencoder, losses[1] = emulator. */
 typedef struct v21_joint v21_joint;
 int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_layer, v21_joint** out);
 int v21_joint_destroy(v21_joint* j);
 int v21_joint_run_epoch(v21_joint* j, const int32_t* perm /* nullable */, int batch, double* losses /* [2] */);
+/* Validation of both models in one launch on the trainers' validation sets (set_data(1, ...): signals for `ae`, the
+ * parameters of the same rows for `em`): losses[0] = the autoencoder's validation loss, losses[1] = the emulator's loss
+ * against the latents the CURRENT encoder produces for the validation signals (emulator.py:754 without the host round
+ * trip). */
+int v21_joint_eval(v21_joint* j, double* losses /* [2] */);
 /* Captured-step replay (hipGraph): run_epoch / step_dev capture one optimizer step per
  * batch geometry and replay it; first row, Adam step size and loss slot of each step come from a device
  * table.  Bit-identical to eager launches.  Off by default (the steps are GPU-bound on MI355X: replay frees

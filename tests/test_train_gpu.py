@@ -1019,6 +1019,15 @@ def test_joint_step_full_width_against_the_oracle(ctx, prec):
     cos = float(dj @ do / (np.linalg.norm(dj) * np.linalg.norm(do)))
     assert cos > (0.99 if prec == "f16" else 0.9) and abs(np.linalg.norm(dj) / np.linalg.norm(do) - 1) < tol_n, cos
     assert tra.get_state()[0] == tre.get_state()[0] == 6
+    # the one-launch validation of both models (v21_joint_eval): the autoencoder's is its own forward-only pass, bit for
+    # bit; the emulator's is its loss against the (frozen) encoder's latents of the validation signals
+    nv = 150
+    tra.set_data(1, y[:nv], None, wa[:nv]); tre.set_data(1, par[:nv], np.zeros((nv, 9), np.float32), wz[:nv])
+    va, ve = joint.evaluate()
+    assert va == tra.evaluate(1, batch)
+    tre.set_data(1, par[:nv], z[:nv].astype(np.float32), wz[:nv])
+    vx = tre.evaluate(1, batch)
+    assert abs(ve - vx) / vx < (3e-3 if prec == "f16" else 3e-2), (ve, vx)
     # ---- (b) both models training
     sta, tra = trainer(ae_dims, ae_act, Wa, ba, 1e-3)
     ste, tre = trainer(em_dims, em_act, We, be, 1e-3)
