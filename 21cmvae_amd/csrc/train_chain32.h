@@ -66,23 +66,32 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
   // ---- the wave's weight stream (rolling prefetch across tiles, layers and the forward / backward turn) and, for a
   // forward tile, its 8 bias values (features 32 t + 16 s + 4 kq + r)
   struct Job { const f32x4* w; const float* b; int nb; };  // nb: features of the layer left from the tile's first one
-  auto fwd_job = [&](int l, int t) __attribute__((always_inline)) -> Job {
+  // A layer with ONE tile (an output <= 32 wide: the 9-wide latent; backward, an input <= 32 wide) would keep one wave
+  // busy for its whole contraction while fifteen wait (r3 stamps: 8 k cycles each for 352 -> 9 forward and 352 <- 32
+  // backward).  There the CONTRACTION is split instead: wave w takes chunk w of the tile's stream (two k16 steps), the
+  // partial tiles meet in LDS and wave 0 finishes the tile.  A wave's unit in a layer is therefore a tile (several-tile
+  // layers) or a chunk of tile 0 (single-tile layers): at most one per wave either way (<= 16 tiles, <= 16 chunks).
+  auto fwd_units = [&](int l) __attribute__((always_inline)) -> int { return a.lt[l].NT == 1 ? a.lt[l].KS >> 2 : a.lt[l].NT; };
+  auto bwd_units = [&](int l) __attribute__((always_inline)) -> int { return a.lt[l].KT == 1 ? a.lt[l].NS >> 2 : a.lt[l].KT; };
+  auto fwd_job = [&](int l, int u) __attribute__((always_inline)) -> Job {
     const ChainLayer& ly = a.lt[l];
-    return Job{fw + ly.fw_off + ((long long)t * ly.KS) * 64 + lane, a.w + ly.b_off + 32 * t, ly.N - 32 * t};
+    if (ly.NT == 1) return Job{fw + ly.fw_off + (long long)(4 * u) * 64 + lane, a.w + ly.b_off, u == 0 ? ly.N : 0};
+    return Job{fw + ly.fw_off + ((long long)u * ly.KS) * 64 + lane, a.w + ly.b_off + 32 * u, ly.N - 32 * u};
   };
-  auto bwd_job = [&](int l, int t) __attribute__((always_inline)) -> Job {
+  auto bwd_job = [&](int l, int u) __attribute__((always_inline)) -> Job {
     const ChainLayer& ly = a.lt[l];
-    return Job{bw + ly.bw_off + ((long long)t * ly.NS) * 64 + lane, a.w, 0};
+    if (ly.KT == 1) return Job{bw + ly.bw_off + (long long)(4 * u) * 64 + lane, a.w, 0};
+    return Job{bw + ly.bw_off + ((long long)u * ly.NS) * 64 + lane, a.w, 0};
   };
   auto bwd_from = [&](int l) __attribute__((always_inline)) -> Job {
     if (!st.fwd_only)
       for (; l >= 1; --l)
-        if (wave < a.lt[l].KT) return bwd_job(l, wave);
+        if (wave < bwd_units(l)) return bwd_job(l, wave);
     return Job{fw + lane, a.w, 0};  // nothing left: any valid address (the data is never used)
   };
   auto fwd_from = [&](int l) __attribute__((always_inline)) -> Job {
     for (; l < a.L; ++l)
-      if (wave < a.lt[l].NT) return fwd_job(l, wave);
+      if (wave < fwd_units(l)) return fwd_job(l, wave);
     return bwd_from(a.L - 1);
   };
   auto load_bias = [&](const Job& j, float (&bv)[8]) __attribute__((always_inline)) {
@@ -156,24 +165,33 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
   int cur = 0;
 
   // The 16 rows x F features in `act` -> the fp32 operand of the weight gradient, feature-major with the batch
-  // contiguous (dst[f * BS + batch row]: what gemm_nt.h reads): one instruction = 4 features x 16 rows = four 64-byte
-  // segments.  Done by the waves WITHOUT a tile in the contraction that follows; rows past the batch are written as zeros.
+  // contiguous (dst[f * BS + batch row]: what gemm_nt.h reads).  A lane takes one feature and four consecutive rows
+  // (four LDS reads, conflict-free: 16 features x 4 row groups per instruction) and stores them as ONE 16-byte word: an
+  // instruction = 16 features x 64 contiguous bytes.  (First cut: one float per lane, 4 features x 16 rows per
+  // instruction -- four times the store instructions; the flush of a 352-wide activation by the few idle waves WAS the
+  // duration of the single-tile layers that follow the big ones.)  Done by the waves without a unit in the contraction
+  // that follows (tiles = 0: by everyone); rows past the batch are written as zeros.
   auto flush_t = [&](const float* act, int F, void* dst, int tiles) __attribute__((always_inline)) {
-    const int ngrp = (F + 3) >> 2;
+    const int ngrp = (F + 15) >> 4;
     float* d = reinterpret_cast<float*>(dst);
     const int w0 = tiles < NW ? tiles : 0;
     if (wave < w0 || st.fwd_only) return;
+    const int fq = lane >> 2, r4 = 4 * (lane & 3);
     for (int id = wave - w0; id < ngrp; id += NW - w0) {
-      const int f = 4 * id + kq;
-      if (f < F) d[(long long)f * a.BS + m0 + m] = m < vrows ? act[m * PITCH + f] : 0.f;
+      const int f = 16 * id + fq;
+      const int fc = f < F ? f : F - 1;
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = r4 + j < vrows ? act[(r4 + j) * PITCH + fc] : 0.f;
+      if (f < F) *reinterpret_cast<f32x4*>(d + (long long)f * a.BS + m0 + r4) = v;
     }
   };
 
   // One 32-wide tile: acc[s](rows = features 16 s + 4 kq + r of the tile, col = batch row m) over `nch` chunks of two
   // k16 steps.  Weight chunks roll as in train_chain_body (wa in use / wb in flight, roles alternate); the activation
   // words of the next k16 step are read from LDS under the 8 MFMAs of this one.
-  auto contract = [&](const f32x4* wsrc, const float* act, int nch, f32x4 (&acc)[2], const Job nxt) __attribute__((always_inline)) -> bool {
-    const float* ap = act + m * PITCH + 4 * kq;
+  auto contract = [&](const f32x4* wsrc, const float* act, int nch, f32x4 (&acc)[2], const Job nxt, int k16 = 0) __attribute__((always_inline)) -> bool {
+    const float* ap = act + m * PITCH + 4 * kq + 16 * k16;  // (k16: first k16 step of this unit within the contraction)
     load_bias(nxt, bnext);  // (the caller has consumed this tile's values)
     f32x4 bc = *reinterpret_cast<const f32x4*>(ap), bn;
     auto chunk = [&](f32x4 (&w)[4], int kc, bool more) __attribute__((always_inline)) {
@@ -223,6 +241,23 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     }
   };
 
+  // partial tiles of a split contraction: [wave][lane][8 floats] in the image the layer writes to (it is free until the
+  // finished tile goes there; 16 x 64 x 32 B = 32 KB of its 33 KB)
+  auto put_partial = [&](float* out, const f32x4 (&acc)[2]) __attribute__((always_inline)) {
+    f32x4* pb = reinterpret_cast<f32x4*>(out) + (wave * 64 + lane) * 2;
+    pb[0] = acc[0]; pb[1] = acc[1];
+  };
+  auto sum_partials = [&](const float* out, int n, f32x4 (&acc)[2]) __attribute__((always_inline)) {  // waves 0 .. n-1, fixed order
+    const f32x4* pb = reinterpret_cast<const f32x4*>(out) + lane * 2;
+    acc[0] = pb[0]; acc[1] = pb[1];
+    for (int w = 1; w < n; ++w) {
+      const f32x4 p0 = pb[w * 128], p1 = pb[w * 128 + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[0][r] += p0[r]; acc[1][r] += p1[r]; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every partial is in registers before the tile overwrites the area
+  };
+
   // ---- forward
   for (int l = 0; l < a.L; ++l) {
     const ChainLayer& ly = a.lt[l];
@@ -230,14 +265,11 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     const float* act = buf[cur];
     float* out = buf[cur ^ 1];
     const int nch = ly.KS >> 2;
-    flush_t(act, ly.K, ly.ht16, ly.NT);  // this layer's input -> operand of its weight gradient
-    for (int t = wave; t < ly.NT; t += NW) {
+    const bool split = ly.NT == 1;
+    const int units = split ? nch : ly.NT;
+    // what happens to a finished tile (bias already inside): the next layer's operand / the FORWARD-mode output / the loss
+    auto finish = [&](int t, f32x4 (&acc)[2]) __attribute__((always_inline)) {
       const int n0 = 32 * t;
-      f32x4 acc[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) acc[s] = f32x4{bnext[4 * s], bnext[4 * s + 1], bnext[4 * s + 2], bnext[4 * s + 3]};
-      const Job nxt = t + NW < ly.NT ? fwd_job(l, t + NW) : fwd_from(l + 1);
-      const bool odd = contract(fw + ly.fw_off + ((long long)t * ly.KS) * 64 + lane, act, nch, acc, nxt);
       if (!last) {
         unsigned bits = 0;
 #pragma unroll
@@ -287,7 +319,30 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
           *reinterpret_cast<f32x4*>(out + m * PITCH + n) = dd;
         }
       }
-      settle(odd);
+    };
+    flush_t(act, ly.K, ly.ht16, split ? 0 : units);  // this layer's input -> operand of its weight gradient (split layer: by everyone, the contraction is short)
+    if (wave < units) {
+      f32x4 acc[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc[s] = f32x4{bnext[4 * s], bnext[4 * s + 1], bnext[4 * s + 2], bnext[4 * s + 3]};
+      const Job nxt = fwd_from(l + 1);
+      if (!split) {
+        const bool odd = contract(fw + ly.fw_off + ((long long)wave * ly.KS) * 64 + lane, act, nch, acc, nxt);
+        finish(wave, acc);
+        settle(odd);
+      } else {  // chunk `wave` of the only tile (waves > 0 started from a zero bias: see fwd_job)
+        const bool odd = contract(fw + ly.fw_off + (long long)(4 * wave) * 64 + lane, act, 1, acc, nxt, 2 * wave);
+        put_partial(out, acc);
+        settle(odd);
+      }
+    }
+    if (split) {
+      chain_barrier();
+      if (wave == 0) {
+        f32x4 acc[2];
+        sum_partials(out, units, acc);
+        finish(0, acc);
+      }
     }
     if (last && !st.out) {  // this lane's share of the row losses (lanes m, m + 16, m + 32, m + 48 hold one row)
       lsum += __shfl_xor(lsum, 16, 64);
@@ -319,12 +374,10 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     const float* act = buf[cur];
     float* out = buf[cur ^ 1];
     const int nch = ly.NS >> 2;
-    flush_t(act, ly.N, ly.dzt16, ly.KT);  // dZ of this layer's output -> operand of its weight gradient
-    for (int t = wave; t < ly.KT; t += NW) {
+    const bool split = ly.KT == 1;
+    const int units = split ? nch : ly.KT;
+    auto finish = [&](int t, f32x4 (&acc)[2]) __attribute__((always_inline)) {
       const int k0 = 32 * t;
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      const Job nxt = t + NW < ly.KT ? bwd_job(l, t + NW) : bwd_from(l - 1);
-      const bool odd = contract(bw + ly.bw_off + ((long long)t * ly.NS) * 64 + lane, act, nch, acc, nxt);
       const unsigned bits = below.relu ? masks[below.mask_tile + t][lane] : 0xFFu;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -335,7 +388,28 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
         }
         *reinterpret_cast<f32x4*>(out + m * PITCH + k0 + 16 * s + 4 * kq) = acc[s];
       }
-      settle(odd);
+    };
+    flush_t(act, ly.N, ly.dzt16, split ? 0 : units);  // dZ of this layer's output -> operand of its weight gradient
+    if (wave < units) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const Job nxt = bwd_from(l - 1);
+      if (!split) {
+        const bool odd = contract(bw + ly.bw_off + ((long long)wave * ly.NS) * 64 + lane, act, nch, acc, nxt);
+        finish(wave, acc);
+        settle(odd);
+      } else {
+        const bool odd = contract(bw + ly.bw_off + (long long)(4 * wave) * 64 + lane, act, 1, acc, nxt, 2 * wave);
+        put_partial(out, acc);
+        settle(odd);
+      }
+    }
+    if (split) {
+      chain_barrier();
+      if (wave == 0) {
+        f32x4 acc[2];
+        sum_partials(out, units, acc);
+        finish(0, acc);
+      }
     }
     chain_barrier();
     cur ^= 1;
