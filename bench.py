@@ -704,10 +704,19 @@ def main():
                 if world > 1:
                     par = importlib.import_module("21cmvae_amd.parallel")
                     transport = "RCCL (in-library)" if dist.get_backend() == "nccl" else "host-staged over gloo"
+                    err = None
                     try:
                         par.init_engine_comm(ctx)
-                    except Exception as e:  # the in-library communicator did not come up: say so, use the process group's
-                        transport = "host-staged over the process group (in-library RCCL failed: %s)" % e
+                    except Exception as e:
+                        err = e
+                    # the fallback is decided COLLECTIVELY: ranks on different transports would hang in the
+                    # first exchange -- if the in-library communicator failed anywhere, every rank drops it
+                    flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=_pg_device(dist))
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                    if float(flag.item()) > 0:
+                        if err is None:
+                            ctx.comm_destroy()
+                        transport = "host-staged over the process group (in-library RCCL failed on some rank: %s)" % (err,)
                         par.init_engine_comm(ctx, backend="host")
                 tl = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
                                args.train_batch, args.precision, args.train_steps, 5)

@@ -248,7 +248,10 @@ int v21_sweep_run_epoch(v21_sweep* sw, const int32_t* perm, int batch, double* l
  *                       suite runs two ranks on one GPU over torch.distributed/gloo through it.
  * v21_comm_set_sharded(1): reduce-scatter of the gradient arena -> each rank applies Adam to its 1/R slice of
  * (w, m, v) only -> all-gather of the updated weights; 0 (default): one all-reduce, identical
- * Adam on every rank.  In sharded mode v21_trainer_get_state is a collective call (it gathers m and v). -------- */
+ * Adam on every rank.  In sharded mode v21_trainer_get_state is a collective call (it gathers m and v).  Switching
+ * the mode of a context does not touch trainers that already exist on it: after sharded steps a rank holds current
+ * moments for ITS slice only, so call v21_trainer_get_state + v21_trainer_set_state (or create a new trainer) before
+ * such a trainer goes on in all-reduce mode. -------- */
 #define V21_COMM_ID_BYTES 128
 typedef struct v21_comm_host_ops {
   void* user;

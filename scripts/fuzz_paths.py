@@ -1,6 +1,7 @@
 """Randomised cross-check of the device paths against the float64 oracle (run on a GPU box; not part of the
 test suite: tests/ holds the fixed cases).  Forward: fused / small-batch / generic; training: chain and
-per-layer paths, random depths, widths, batch sizes and activations."""
+per-layer paths, random depths, widths, batch sizes and activations.  f32 training runs the fp32 chain
+(train_chain32.h) since r3, FWD_NO_SMALL on a stack without a compiled kernel the chain kernels in FORWARD mode."""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,6 +32,11 @@ for case in range(ncase):
         err = np.abs(out - h).max() / scale
         if not err < 2e-5:
             bad += 1; print("FORWARD MISMATCH", dims, act, n, flags, err)
+    for prec, tol in (("f16", 3e-3), ("bf16", 3e-2)):  # the table-driven one-launch forward (chain kernel, FORWARD mode)
+        out = st.forward(x, prec, native.FWD_FORCE_CHAIN)
+        err = np.abs(out - h).max() / (np.abs(h).max() + 1e-6)
+        if not err < tol:
+            bad += 1; print("CHAIN FORWARD MISMATCH", prec, dims, act, n, err)
     lo, dz = ora.batch_loss_and_grad(h, y.astype(np.float64), w.astype(np.float64))
     dWs, dbs = [None] * L, [None] * L
     for li in range(L - 1, -1, -1):
