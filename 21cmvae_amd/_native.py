@@ -98,6 +98,7 @@ SIGNATURES = {
     "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
     "v21_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
+    "v21_trainer_enable_stamps": (C.c_int, [_P, C.c_int]),
     "v21_trainer_chain_stamps": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     "v21_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "v21_host_free": (C.c_int, [_P, _P]),
@@ -492,6 +493,10 @@ class Trainer:
         arithmetic, bit-identical results; the host enqueues one graph launch per step instead of 3-14 kernels
         (measured r2: the steps are GPU-bound, so this frees the host thread but does not shorten a step)."""
         check(self.lib.v21_trainer_use_graph(self.h, 1 if enable else 0))
+
+    def enable_stamps(self, on=True):
+        """Cycle stamps of the chain kernel's phases (diagnostics; off by default: they cost 2-3 us per step)."""
+        check(self.lib.v21_trainer_enable_stamps(self.h, 1 if on else 0))
 
     def chain_stamps(self, n=40):
         out = (C.c_uint64 * n)()

@@ -74,6 +74,7 @@ struct NtAdamInfo {
   float alpha, omb1, omb2, eps;
   StepCtx sc;                  // replayed step: alpha and the loss slot come from the descriptor
   unsigned long long* loss_acc; float* loss_out; float* loss_out2; int loss_slot;  // the step's batch loss (thread 0 of block 0)
+  int fmt;                     // 3: streams of train_chain32.h (16-row kernel), 4: of train_chain32s.h (8-row kernel)
   NtAdamLayer lt[kNtMaxGroup];
 };
 
@@ -225,8 +226,14 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
             const float wi = ad->w[i] - (mi * alpha) / (sqrtf(vi) + ad->eps);
             ad->m[i] = mi; ad->v[i] = vi; ad->w[i] = wi;
             if (m < al.K) {  // a kernel element (the bias row has no packed copy); k = m
-              const long long qf = al.fw_off + ((((long long)(n >> 5) * al.KS + 2 * (m >> 4) + ((n >> 4) & 1)) * 64 + (n & 15) + 16 * ((m >> 2) & 3)) << 2) + (m & 3);
-              const long long qb = al.bw_off + ((((long long)(m >> 5) * al.NS + 2 * (n >> 4) + ((m >> 4) & 1)) * 64 + (m & 15) + 16 * ((n >> 2) & 3)) << 2) + (n & 3);
+              long long qf, qb;  // (train_kernels.h: adam_repack_element spells the two formats out)
+              if (ad->fmt == 4) {
+                qf = al.fw_off + ((((long long)(n >> 6) * al.KS + (m >> 2)) * 64 + (n & 63)) << 2) + (m & 3);
+                qb = al.bw_off + ((((long long)(m >> 6) * al.NS + (n >> 2)) * 64 + (m & 63)) << 2) + (n & 3);
+              } else {
+                qf = al.fw_off + ((((long long)(n >> 5) * al.KS + 2 * (m >> 4) + ((n >> 4) & 1)) * 64 + (n & 15) + 16 * ((m >> 2) & 3)) << 2) + (m & 3);
+                qb = al.bw_off + ((((long long)(m >> 5) * al.NS + 2 * (n >> 4) + ((m >> 4) & 1)) * 64 + (m & 15) + 16 * ((n >> 2) & 3)) << 2) + (n & 3);
+              }
               ad->fw[qf] = wi;
               ad->bw[qb] = wi;
             }

@@ -87,6 +87,8 @@ struct ChainModel {
   // joint step (train_chain_joint_kernel): the fp32 outputs of this (linear) layer stay in LDS as the NEXT
   // model's targets (-1: none) -- the autoencoder's latent layer, emulator.py:753-754 without the host round trip
   int zcap_layer;
+  // train_chain32s.h: what every wave does in every layer, worked out by the host (C32sJob rows, read with scalar loads)
+  const int* jobs;
 };
 // the batch of this step (shared by every model of a sweep)
 struct ChainStep {
@@ -130,6 +132,11 @@ __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
   }
 }
 
+#ifdef V21_CHAIN_FINE  // (diagnostic build: per-wave stamps of workgroup 0, scripts/diag/chain_wave_stamps.py)
+#define CFINE(i) do { if (blockIdx.x == 0 && lane == 0 && a.stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); a.stamps[64 + (i) * 16 + wave] = t_; } } while (0)
+#else
+#define CFINE(i)
+#endif
 template <class P>
 __device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st);
 
@@ -366,6 +373,11 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // `tiles`: tile count of the contraction that follows.  The waves WITHOUT a tile in it do the flush while the
   // others already stream their weights (measured: done by everyone at the head of the layer it cost 6.3 k
   // cycles of the 67 k; `act` does not change during the layer, so there is no ordering to keep).
+  // Two fragments per turn (r3: one at a time a fragment took ~500 cycles -- two LDS reads, then a store that queues
+  // behind the weight loads saturating the CU's load/store path -- and in a 15-tile layer the ONE wave without a tile
+  // has 22 of them: it left the layer at 11.4 k cycles when the last tile was done at 9.2 k, per-wave stamps of
+  // scripts/diag/chain_wave_stamps.py.  Handing the fragments out through an LDS counter, the tile waves joining in when
+  // done, was slower still: every wave pays the counter's round trips in every layer, 58.9 k cycles against 55.5 k.)
   auto flush_t = [&](const elem* act, int F, void* dst, int tiles) __attribute__((always_inline)) {
     const int nfrag = 2 * ((F + 31) >> 5);
     frag* d = reinterpret_cast<frag*>(dst);
@@ -375,12 +387,16 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     //  on that when they return before the compute waves' last s_barrier.  Here nothing ends: this `return` leaves the
     //  lambda, and every wave of the workgroup goes on to the layer's barrier.)
     if (wave < w0 || st.fwd_only) return;
-    for (int id = wave - w0; id < nfrag; id += NW - w0) {
+    auto read_frag = [&](int id) __attribute__((always_inline)) -> chain_s8 {
       const int ft = id >> 1, q2 = id & 1;
       const int r0 = 16 * q2 + 8 * (g >> 1);
       const elem* p = act + (r0 + (i >> 2)) * PITCH + 32 * ft + 16 * (g & 1) + 4 * (i & 3);
       const chain_s4 lo = chain_tr_read(p), hi = chain_tr_read(p + 4 * PITCH);
-      chain_s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return chain_s8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto write_frag = [&](int id, chain_s8 v) __attribute__((always_inline)) {
+      const int ft = id >> 1, q2 = id & 1;
+      const int r0 = 16 * q2 + 8 * (g >> 1);
       if (vrows < 32) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -388,7 +404,16 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       }
       if (32 * ft + (lane & 31) < F)
         d[((long long)ft * a.BS + (m0 >> 4) + q2) * 64 + lane] = __builtin_bit_cast(frag, v);
+    };
+    const int nfl = NW - w0;
+    int id = wave - w0;
+    __builtin_amdgcn_s_setprio(3);  // (the waves without a tile are the YOUNGEST of the workgroup: see above)
+    for (; id + nfl < nfrag; id += 2 * nfl) {
+      const chain_s8 v0 = read_frag(id), v1 = read_frag(id + nfl);
+      write_frag(id, v0); write_frag(id + nfl, v1);
     }
+    if (id < nfrag) write_frag(id, read_frag(id));
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // One 32-wide tile: acc(rows = features of the tile, col = batch row li) over `nch` chunks of four
@@ -453,7 +478,9 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
     const int nch = ly.KS >> 2;
+    CFINE(4 * l);
     flush_t(act, ly.K, ly.ht16, ly.NT);  // this layer's input -> operand of its weight gradient
+    CFINE(4 * l + 1);
     const float wi = rwl[li];
     for (int t = wave; t < ly.NT; t += NW) {
       const int n0 = 32 * t;
@@ -552,6 +579,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       }
       settle(odd);
     }
+    CFINE(4 * l + 2);
     if (ly.gauss) {  // z = mu + exp(lv/2) eps -> the next layer's operand image; KL_i -> the row's loss
       chain_barrier();
       // one (batch row, latent dimension) per thread (latent <= 32 = 1,024 / 32): the draw of eps -- a hash, a logarithm,
@@ -581,6 +609,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       if (lh == 0) red[wave][li] = lsum * rwl[li];
     }
     chain_barrier();
+    CFINE(4 * l + 3);
     if (ly.gauss && tid < 32) {
       float kl = 0.f;
 #pragma unroll

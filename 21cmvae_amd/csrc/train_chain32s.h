@@ -1,0 +1,480 @@
+// train_chain32s.h -- the fp32 chain (train_chain32.h) for SMALL batches: 8 batch rows per workgroup (gfx950).
+//
+// train_chain32_kernel carries 16 rows per workgroup on the 16 x 16 x 4 f32 MFMA: at the reference's batch of 256 rows
+// that is 16 workgroups, and the launch is bound by the f32 MFMA rate of the 16 CUs they occupy (63 k cycles of matrix
+// work per workgroup; measured 127 k).  With the MFMAs compiled out the same kernel takes 78 k cycles: that is the fp32
+// weight stream (2.7 MB through one CU) and the per-layer latencies -- what a workgroup with LESS matrix work would be
+// left with.  Hence 8 rows per workgroup (32 workgroups at batch 256, 128 at 1,024) on the 4 x 4 x 1 f32 MFMA
+// (16 blocks of 4 x 4, K = 1; layout checked by scripts/diag/mfma4_probe.hip):
+//
+//   lane l = 4 b + j of a wave: block b <-> the features 4 b .. 4 b + 3 of a 64-FEATURE tile, j <-> batch row j of a
+//   group of four rows.  A operand = W[k][n0 + l] (lane l: ONE float), B operand = H[row j][k] (the same in all 16
+//   blocks: a broadcast LDS read), D register i = feature 4 b + i for row j: the result goes back to the fp32
+//   [row][feature] LDS image as one 16-byte write per lane and row group.  Two row groups share every weight word (two
+//   MFMAs per word: the load path, 64 B/clk, and the matrix pipe are in balance; with one group the load path would
+//   lose 2 : 1).  Weights come as 1-KiB fragments (lane l, element e = W[4 f + e][n0 + l]: four k per fragment, eight
+//   MFMAs), four fragments per chunk of the usual rolling prefetch.
+//   A layer has <= 8 tiles of 64 features, so its CONTRACTION may be split as well: unit (tile t, part s) takes a
+//   contiguous range of the tile's chunks, the partial tiles meet in LDS and the wave of part 0 finishes the tile.  Which
+//   layers are split, and what every wave does in every layer, the HOST works out once per trainer (c32s_split,
+//   c32s_build_jobs below): the kernel reads its row of that table with scalar loads.
+// Measured on the autoencoder stack at batch 256 (scripts/train_probe.py): 16-row kernel 129 k
+// cycles -> this kernel 101 k with the units derived in the kernel -> 83 k with the host's table -> 79 k with the split
+// chosen per layer; the step 73.6 -> 52.5 us.  Diagnostic builds (-DV21_C32S_NOLOAD / NOMFMA / NOLDS: the kernel without
+// its weight loads / MFMAs / operand reads) put the three big layers at ~14.5 k cycles each on MFMAs alone (12.3 k is
+// the pipe's rate, 8.8 cycles per 4 x 4 x 1 with two waves per SIMD), ~15 k on the stream alone (11.4 k at the load
+// path's 63 B/clk), 18-19 k together; the six small layers, the gather and the loss are ~25 k of fixed cost.
+// Used for f32 trainers whose max_batch is <= kC32sMaxBatch (a trainer commits to ONE packed-stream format: this
+// kernel's `cprec = 4` streams, or the 16-row kernel's).  Same ChainModel / ChainStep blocks (ChainLayer::KS / NS =
+// fragments per 64-wide tile, NT / KT = 64-wide tiles); training and validation (fwd_only); no FORWARD mode, no
+// variational layer.
+#pragma once
+#include "train_chain32.h"
+
+namespace v21 {
+#ifdef V21_C32S_NOLOAD  // (diagnostic builds: the kernel without its weight loads / LDS reads / MFMAs -- wrong results)
+#define WLOAD(dst, src) asm volatile("" : "+v"(dst))
+#else
+#define WLOAD(dst, src) dst = src
+#endif
+#ifdef V21_CHAIN_FINE  // (diagnostic build: per-wave stamps of workgroup 0, scripts/diag/chain_wave_stamps.py)
+#define FINE(i) do { if (blockIdx.x == 0 && lane == 0 && a.stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); a.stamps[64 + (i) * 16 + wave] = t_; } } while (0)
+#else
+#define FINE(i)
+#endif
+
+constexpr int kC32sRows = 8;
+constexpr int kC32sWaves = 16;
+constexpr int kC32sMaxBatch = 1024;
+constexpr int kC32sMaskTiles = 120;
+constexpr int kC32sBufBytes = 2 * kC32sRows * kC32Pitch * 4;
+constexpr int kC32sYBytes = kC32sRows * kC32Pitch * 4;
+constexpr int kC32sMaskBytes = kC32sMaskTiles * 64 * 2;
+constexpr int kC32sPartBytes = kC32sWaves * 64 * 8 * 4;  // partial tiles of a split contraction: [wave][lane][8 floats]
+constexpr int kC32sLdsBytes = kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes + kC32sWaves * kC32sRows * 4 + kC32sRows * 4 + 64;
+// fragments (4 k each) per 64-feature tile over a contraction range of d, whole chunks of four
+__host__ __device__ constexpr int chain32s_frags(int d) { return ((d + 3) / 4 + 3) / 4 * 4; }
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+// how a layer's contraction is cut: `tiles` 64-wide tiles x `parts` chunk ranges of `cps` chunks = units, one per wave
+struct C32sSplit { int tiles, parts, cps, units; };
+inline C32sSplit c32s_split(int tiles, int nch) {
+  // Splitting the contraction buys balance (a SIMD's MFMA pipe is already full with two of these waves: 8.8 cycles per
+  // 4 x 4 x 1 MFMA against 8.4 with four, scripts/diag/mfma4_rate_probe.hip) and costs the meeting of the partial tiles
+  // (a second barrier, the sum, ~700 cycles).  Wave w sits on SIMD w % 4: the layer lasts as long as its busiest SIMD,
+  // or as one wave's chunks end to end (a chunk's loads are issued one chunk ahead: ~600 cycles from issue to use).
+  const int kChunkCycles = 32 * 9, kChunkLatency = 600, kMeetCycles = 700;
+  int max_parts = kC32sWaves / tiles;
+  if (max_parts > nch) max_parts = nch;
+  if (max_parts < 1) max_parts = 1;
+  C32sSplit best{tiles, 1, nch, tiles};
+  long long best_cost = -1;
+  for (int want = 1; want <= max_parts; ++want) {
+    const int cps = (nch + want - 1) / want, parts = (nch + cps - 1) / cps;
+    int simd[4] = {0, 0, 0, 0};
+    for (int u = 0; u < tiles * parts; ++u) {
+      const int sidx = u % parts, c0 = sidx * cps;
+      simd[u % 4] += std::min(cps, nch - c0);
+    }
+    const int busiest = std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3]));
+    const long long cost = std::max((long long)busiest * kChunkCycles, (long long)cps * kChunkLatency) + (parts > 1 ? kMeetCycles : 0);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = C32sSplit{tiles, parts, cps, tiles * parts}; }
+  }
+  return best;
+}
+// What a wave does in one step of the chain (steps 0 .. L-1: forward layers; L .. 2L-2: backward layers L-1 .. 1), worked
+// out by the host.  (First cut: every wave derived its unit and its next unit in the kernel -- three integer divisions
+// per split, a search over the layers for the next one: ~1,500 VALU cycles per wave and layer, and since the waves of a
+// SIMD issue oldest first, the younger waves' preambles waited behind the older waves' MFMAs: their contractions started
+// 2 / 6 / 12 k cycles late in an 18-k-cycle layer.)  One row per (step, wave), row 0 of the table = before step 0; read
+// with scalar loads.
+struct C32sJob {
+  int w_off;    // first fragment of the unit (16-byte words from the stream's base, lane 0)
+  int nch;      // chunks of the unit (0: this wave has no unit in this step)
+  int f0;       // first fragment within the tile's contraction
+  int t, s;     // tile, part
+  int parts;    // parts per tile in this step
+  int units;    // units of this step
+  int nxt_w_off, nxt_bw;  // the wave's NEXT unit (whose first chunk rolls in under this one's last): offset, 1 = backward stream
+  int nxt_b_off, nxt_nb;  // ... its bias (arena offset of the tile's first feature) and how many features have one (0: none)
+  int pad[5];
+};
+static_assert(sizeof(C32sJob) == 64, "C32sJob rows are read as 16 dwords");
+// rows (1 + 2 L - 1) x 16 waves; `fw_off` / `bw_off` in 16-byte words, `b_off` in floats (ChainLayer's)
+inline void c32s_build_jobs(const ChainModel& a, C32sJob* tab) {
+  const int L = a.L, steps = 2 * L - 1;
+  for (int i = 0; i < (steps + 1) * kC32sWaves; ++i) tab[i] = C32sJob{};
+  for (int i = 0; i < steps; ++i) {
+    const bool fwd = i < L;
+    const int l = fwd ? i : L - 1 - (i - L);
+    const ChainLayer& ly = a.lt[l];
+    const C32sSplit sp = fwd ? c32s_split(ly.NT, ly.KS >> 2) : c32s_split(ly.KT, ly.NS >> 2);
+    const int frags = fwd ? ly.KS : ly.NS, nch = frags >> 2;
+    for (int w = 0; w < kC32sWaves; ++w) {
+      C32sJob& j = tab[(1 + i) * kC32sWaves + w];
+      j.parts = sp.parts; j.units = sp.units;
+      if (w >= sp.units) continue;
+      j.t = w / sp.parts; j.s = w % sp.parts;
+      const int c0 = j.s * sp.cps;
+      j.nch = std::min(sp.cps, nch - c0);
+      j.f0 = 4 * c0;
+      j.w_off = (int)((fwd ? ly.fw_off : ly.bw_off) + ((long long)j.t * frags + 4 * c0) * 64);
+    }
+  }
+  for (int w = 0; w < kC32sWaves; ++w) {  // every row's "next unit" (searched backwards)
+    int nw = 0, nbw = 0, nb_off = 0, nnb = 0;  // nothing left: any valid address (the data is never used)
+    for (int i = steps - 1; i >= -1; --i) {
+      C32sJob& j = tab[(1 + i) * kC32sWaves + w];
+      j.nxt_w_off = nw; j.nxt_bw = nbw; j.nxt_b_off = nb_off; j.nxt_nb = nnb;
+      if (i >= 0 && j.nch > 0) {
+        const bool fwd = i < L;
+        const int l = fwd ? i : L - 1 - (i - L);
+        nw = j.w_off; nbw = fwd ? 0 : 1;
+        nb_off = fwd ? (int)a.lt[l].b_off + 64 * j.t : 0;
+        nnb = fwd && j.s == 0 ? a.lt[l].N - 64 * j.t : 0;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const ChainStep& st) {
+  constexpr int NW = kC32sWaves, ROWS = kC32sRows, PITCH = kC32Pitch;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  float(*buf)[ROWS * PITCH] = reinterpret_cast<float(*)[ROWS * PITCH]>(chain_smem);
+  float* ystg = reinterpret_cast<float*>(chain_smem + kC32sBufBytes);
+  unsigned short(*masks)[64] = reinterpret_cast<unsigned short(*)[64]>(chain_smem + kC32sBufBytes + kC32sYBytes);
+  f32x4* part = reinterpret_cast<f32x4*>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes);
+  float(*red)[ROWS] = reinterpret_cast<float(*)[ROWS]>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes);
+  float* rwl = reinterpret_cast<float*>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes + NW * ROWS * 4);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jr = lane & 3, blk = lane >> 2;  // batch row within a group of four, feature block of the tile
+  const long long first = st.sc.desc ? st.sc.desc[*st.sc.cur].first : st.first;
+  const int nrb = (st.rows + ROWS - 1) / ROWS;
+  const int bidx = (int)blockIdx.x - st.blk0;
+  const int rb = (bidx & 7) * ((nrb + 7) >> 3) + (bidx >> 3);  // XCD-major row blocks (speed only)
+  if (rb >= nrb) return;
+  const int m0 = rb * ROWS;
+  const int vrows = st.rows - m0;  // valid rows of this block (>= 1; < 8 only in the last block)
+
+  const f32x4* fw = reinterpret_cast<const f32x4*>(a.fw);
+  const f32x4* bw = reinterpret_cast<const f32x4*>(a.bw);
+
+  // ---- the wave's rows of the job table (uniform: scalar loads from the constant address space)
+  struct Job { const f32x4* w; const float* b; int nb; };  // first fragment; bias of the tile (nb features have one)
+  typedef const C32sJob __attribute__((address_space(4)))* jobptr;
+  const jobptr jobs = (jobptr)(unsigned long long)a.jobs + wave;
+  // (a row is fetched one step before it is used: the scalar loads of a step's row miss the constant cache -- every
+  // wave has its own 64 bytes per step -- and ~600 cycles at the head of each of nine steps were exactly that)
+  auto row = [&](int r) __attribute__((always_inline)) -> C32sJob {
+    const jobptr p = jobs + (r < 2 * a.L ? r : 2 * a.L - 1) * NW;
+    C32sJob j;
+    j.w_off = p->w_off; j.nch = p->nch; j.f0 = p->f0; j.t = p->t; j.s = p->s; j.parts = p->parts; j.units = p->units;
+    j.nxt_w_off = p->nxt_w_off; j.nxt_bw = p->nxt_bw; j.nxt_b_off = p->nxt_b_off; j.nxt_nb = p->nxt_nb;
+    return j;
+  };
+  auto next_of = [&](const C32sJob& j) __attribute__((always_inline)) -> Job {
+    return Job{(j.nxt_bw ? bw : fw) + j.nxt_w_off + lane, a.w + j.nxt_b_off, j.nxt_nb};
+  };
+  auto load_bias = [&](const Job& j, f32x4& bv) __attribute__((always_inline)) {  // features 4 blk .. + 3 of the tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 4 * blk + r;
+      const float v = j.b[o < j.nb ? o : 0];  // (clamped: always a valid address; nb = 0 for parts > 0 and backward jobs)
+      bv[r] = o < j.nb ? v : 0.f;
+    }
+  };
+  // waves 0 .. 7 gather one row of the block each: the source row first (the oldest load in flight)
+  const int mq = m0 + (wave < ROWS ? wave : 0);
+  long long srow = (wave < ROWS && mq < st.rows) ? first + mq : first + m0;  // clamped: always a valid position
+  if (st.idx) srow = st.idx[srow];
+  f32x4 wa[4], wb[4];
+  f32x4 bnext;
+  {
+    const Job j0 = next_of(row(0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wa[j] = j0.w[j * 64];
+    load_bias(j0, bnext);
+  }
+  chain_stamp(a, 0);
+  // buf[1] <- 0 once: padding columns must hold finite values (they meet zero weights); buf[0] is written in full below
+  for (int i = tid; i < ROWS * PITCH / 4; i += 64 * NW) reinterpret_cast<f32x4*>(buf[1])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- gather: x[idx] -> buf[0] (and the target rows)
+  if (wave < ROWS) {
+    const int K0 = a.lt[0].K, DO = a.lt[a.L - 1].N;
+    const float rwv = st.rw ? st.rw[srow] : 0.f;
+    if (lane == 0) rwl[wave] = mq < st.rows ? rwv : 0.f;
+    const int kmax = mq < st.rows ? K0 : 0;
+    const float* xs = st.x + srow * st.ldx;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = lane + 64 * i;
+      const float t = xs[k < K0 ? k : K0 - 1];
+      v[i] = k < kmax ? t : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = lane + 64 * i;  // <= 511 < PITCH
+      buf[0][wave * PITCH + k] = v[i];
+      if (!st.y) ystg[wave * PITCH + k] = v[i];
+    }
+    if (st.y) {
+      const int ymax = mq < st.rows ? DO : 0;
+      const float* ys = st.y + srow * st.ldy;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = lane + 64 * i;
+        const float t = ys[k < DO ? k : DO - 1];
+        v[i] = k < ymax ? t : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ystg[wave * PITCH + lane + 64 * i] = v[i];
+    }
+  }
+  chain_barrier();
+  chain_stamp(a, 1);
+  float lsum[2] = {0.f, 0.f};
+  int cur = 0;
+  C32sJob jnext = row(1);
+
+  // The 8 rows x F features in `act` -> the fp32 operand of the weight gradient (dst[f * BS + batch row], gemm_nt.h): a lane
+  // takes one feature and four consecutive rows and stores them as one 16-byte word (32 features x 32 contiguous bytes per
+  // instruction).  Done by the waves without a unit in the contraction that follows; rows past the batch are zeros.
+  auto flush_t = [&](const float* act, int F, void* dst, int units) __attribute__((always_inline)) {
+    const int ngrp = (F + 31) >> 5;
+    float* d = reinterpret_cast<float*>(dst);
+    const int w0 = units < NW ? units : 0;
+    if (wave < w0 || st.fwd_only) return;
+    const int fq = lane >> 1, r4 = 4 * (lane & 1);
+    __builtin_amdgcn_s_setprio(3);  // (the waves without a unit are the youngest of the workgroup, and the SIMDs issue oldest first)
+    for (int id = wave - w0; id < ngrp; id += NW - w0) {
+      const int f = 32 * id + fq;
+      const int fc = f < F ? f : F - 1;
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = r4 + j < vrows ? act[(r4 + j) * PITCH + fc] : 0.f;
+      if (f < F) *reinterpret_cast<f32x4*>(d + (long long)f * a.BS + m0 + r4) = v;
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // One unit: acc[g](register i = feature 4 blk + i of the tile, row 4 g + jr) over `nch` chunks of four fragments
+  // starting at fragment f0 of the tile's contraction.  Weight chunks roll as in train_chain_body (wa in use / wb in
+  // flight, roles alternate); the activation words of the next fragment are read under the 8 MFMAs of this one.
+  // (Units padded to whole PAIRS of chunks, so that the two buffers never change roles and no register move waits for a
+  // chunk in flight: measured slower -- +3 % of stream in the 451-wide layers, a zero chunk in the 9-wide one.)
+  auto contract = [&](const f32x4* wsrc, const float* act, int nch, f32x4 (&acc)[2], const Job nxt, int f0) __attribute__((always_inline)) -> bool {
+    const float* ap = act + jr * PITCH + 4 * f0;
+    load_bias(nxt, bnext);  // (the caller has consumed this unit's values)
+    f32x4 b0 = *reinterpret_cast<const f32x4*>(ap), b1 = *reinterpret_cast<const f32x4*>(ap + 4 * PITCH), n0v, n1v;
+    auto chunk = [&](f32x4 (&w)[4], int kc, bool more) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int fn = 4 * kc + j + 1;  // the next fragment of this unit (read ahead; past the unit: a harmless re-read)
+#ifndef V21_C32S_NOLDS
+        if (j < 3 || more) {
+          n0v = *reinterpret_cast<const f32x4*>(ap + 4 * fn);
+          n1v = *reinterpret_cast<const f32x4*>(ap + 4 * PITCH + 4 * fn);
+        }
+#endif
+#ifdef V21_C32S_NOMFMA  // (one VALU instruction per fragment keeps the loads alive)
+        asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[0][0]) : "v"(w[j][0]), "v"(b0[0]), "v"(b1[0]));
+#else
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = mfma4(w[j][e], b0[e], acc[0]);
+          acc[1] = mfma4(w[j][e], b1[e], acc[1]);
+        }
+#endif
+#ifndef V21_C32S_NOLDS
+        b0 = n0v; b1 = n1v;
+#endif
+      }
+    };
+    int c = 0;
+    for (; c + 2 <= nch; c += 2) {
+      {
+        const f32x4* p = wsrc + (long long)(4 * (c + 1)) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) WLOAD(wb[j], p[j * 64]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (keeps the first MFMA -- and the wait for the CURRENT chunk -- below these loads)
+      chunk(wa, c, true);
+      {
+        const f32x4* p = c + 2 < nch ? wsrc + (long long)(4 * (c + 2)) * 64 : nxt.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) WLOAD(wa[j], p[j * 64]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      chunk(wb, c + 1, c + 2 < nch);
+    }
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) WLOAD(wb[j], nxt.w[j * 64]);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk(wa, c, false);
+      return true;
+    }
+    return false;
+  };
+  auto settle = [&](bool odd) __attribute__((always_inline)) {
+    if (odd) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wa[j] = wb[j];
+    }
+  };
+  auto put_partial = [&](const f32x4 (&acc)[2]) __attribute__((always_inline)) {
+    f32x4* pb = part + (wave * 64 + lane) * 2;
+    pb[0] = acc[0]; pb[1] = acc[1];
+  };
+  auto sum_partials = [&](int n, f32x4 (&acc)[2]) __attribute__((always_inline)) {  // waves wave .. wave + n - 1, fixed order
+    const f32x4* pb = part + (wave * 64 + lane) * 2;
+    acc[0] = pb[0]; acc[1] = pb[1];
+    for (int w = 1; w < n; ++w) {
+      const f32x4 p0 = pb[w * 128], p1 = pb[w * 128 + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[0][r] += p0[r]; acc[1][r] += p1[r]; }
+    }
+  };
+
+  // ---- forward
+  for (int l = 0; l < a.L; ++l) {
+    const ChainLayer& ly = a.lt[l];
+    const bool last = l == a.L - 1;
+    const float* act = buf[cur];
+    float* out = buf[cur ^ 1];
+    const C32sJob jb = jnext;
+    jnext = row(2 + l);
+    const int parts = jb.parts, t = jb.t;
+    auto finish = [&](int t, f32x4 (&acc)[2]) __attribute__((always_inline)) {
+      const int n = 64 * t + 4 * blk;
+      if (!last) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (ly.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc[g][r] = fmaxf(acc[g][r], 0.f);
+              bits |= (acc[g][r] > 0.f ? 1u : 0u) << (4 * g + r);
+            }
+          }
+          *reinterpret_cast<f32x4*>(out + (4 * g + jr) * PITCH + n) = acc[g];
+        }
+        if (ly.relu && ly.mask_tile >= 0) masks[ly.mask_tile + t][lane] = (unsigned short)bits;
+      } else {  // loss_i = w_i sum_j (p - y)^2,  dL/dp = scale w_i (p - y)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const float gsc = st.scale * rwl[4 * g + jr];
+          const f32x4 yq = *reinterpret_cast<const f32x4*>(ystg + (4 * g + jr) * PITCH + n);
+          f32x4 dd;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float df = n + r < ly.N ? acc[g][r] - yq[r] : 0.f;
+            lsum[g] += df * df;
+            dd[r] = gsc * df;
+          }
+          *reinterpret_cast<f32x4*>(out + (4 * g + jr) * PITCH + n) = dd;
+        }
+      }
+    };
+    FINE(4 * l);
+    flush_t(act, ly.K, ly.ht16, jb.units);  // this layer's input -> operand of its weight gradient
+    if (jb.nch > 0) {
+      f32x4 acc[2] = {bnext, bnext};
+      FINE(4 * l + 1);
+      const bool odd = contract(fw + jb.w_off + lane, act, jb.nch, acc, next_of(jb), jb.f0);
+      if (parts == 1) finish(t, acc);
+      else put_partial(acc);
+      settle(odd);
+    }
+    FINE(4 * l + 2);
+    if (parts > 1) {
+      chain_barrier();
+      FINE(4 * l + 3);
+      if (jb.nch > 0 && jb.s == 0) {
+        f32x4 acc[2];
+        sum_partials(parts, acc);
+        finish(t, acc);
+      }
+    }
+    if (last) {  // this lane's share of the row losses (the 16 lanes with the same jr hold one row of each group)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float v = lsum[g];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (blk == 0) red[wave][4 * g + jr] = v * rwl[4 * g + jr];
+      }
+    }
+    chain_barrier();
+    cur ^= 1;
+    chain_stamp(a, 2 + l);
+  }
+
+  // ---- loss: lanes -> rows -> workgroup (fixed order) -> one fixed-point atomic per workgroup
+  if (tid < ROWS) {
+    float sl = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sl += red[w][tid];
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) sl += __shfl_xor(sl, o, 64);
+    if (tid == 0) atomicAdd(a.loss_acc, (unsigned long long)(long long)llrint((double)sl * 4294967296.0));
+  }
+  chain_stamp(a, 2 + a.L);
+  if (st.fwd_only) return;
+
+  // ---- backward: layer l consumes dZ_l (in buf[cur]) and produces dZ_{l-1}
+  for (int l = a.L - 1; l >= 1; --l) {
+    const ChainLayer& ly = a.lt[l];
+    const ChainLayer& below = a.lt[l - 1];
+    const float* act = buf[cur];
+    float* out = buf[cur ^ 1];
+    const C32sJob jb = jnext;
+    jnext = row(2 + a.L + (a.L - 1 - l));
+    const int parts = jb.parts, t = jb.t;
+    auto finish = [&](int t, f32x4 (&acc)[2]) __attribute__((always_inline)) {
+      const int k = 64 * t + 4 * blk;
+      const unsigned bits = below.relu ? masks[below.mask_tile + t][lane] : 0xFFu;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[g][r];
+          acc[g][r] = ((bits >> (4 * g + r)) & 1u) ? v : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(out + (4 * g + jr) * PITCH + k) = acc[g];
+      }
+    };
+    flush_t(act, ly.N, ly.dzt16, jb.units);  // dZ of this layer's output -> operand of its weight gradient
+    if (jb.nch > 0) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const bool odd = contract(bw + jb.w_off + lane, act, jb.nch, acc, next_of(jb), jb.f0);
+      if (parts == 1) finish(t, acc);
+      else put_partial(acc);
+      settle(odd);
+    }
+    if (parts > 1) {
+      chain_barrier();
+      if (jb.nch > 0 && jb.s == 0) {
+        f32x4 acc[2];
+        sum_partials(parts, acc);
+        finish(t, acc);
+      }
+    }
+    chain_barrier();
+    cur ^= 1;
+    chain_stamp(a, 3 + a.L + (a.L - 1 - l));
+  }
+  flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
+}
+
+__global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_kernel(const ChainArgs a) {
+  if ((int)blockIdx.x >= a.ncons) { chain_prefetch(a, a); return; }
+  train_chain32s_body(a, a);
+}
+
+}  // namespace v21

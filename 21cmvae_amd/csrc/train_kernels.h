@@ -346,7 +346,14 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
       const long long pf = L.fw_off + ((((long long)(n >> 5) * L.KS + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 3) + (k & 7);
       // backward fragment (tile k/32, n-step n/16): lane = 32*((n%16)/8) + k%32, element n%8
       const long long pb = L.bw_off + ((((long long)(k >> 5) * L.NS + (n >> 4)) * 64 + ((n >> 3) & 1) * 32 + (k & 31)) << 3) + (n & 7);
-      if (a.cprec == 3) {
+      if (a.cprec == 4) {
+        // fp32 streams of train_chain32s.h (KS / NS = fragments of four k / n per 64-wide tile):
+        // forward fragment (tile n/64, k/4): lane = n%64, element k%4; backward (tile k/64, n/4): lane = k%64, element n%4
+        const long long qf = L.fw_off + ((((long long)(n >> 6) * L.KS + (k >> 2)) * 64 + (n & 63)) << 2) + (k & 3);
+        const long long qb = L.bw_off + ((((long long)(k >> 6) * L.NS + (n >> 2)) * 64 + (k & 63)) << 2) + (n & 3);
+        reinterpret_cast<float*>(a.fw)[qf] = wi;
+        reinterpret_cast<float*>(a.bw)[qb] = wi;
+      } else if (a.cprec == 3) {
         // fp32 streams of train_chain32.h (KS / NS = fragments per 32-wide tile, two per k16 / n16 step):
         // forward fragment (tile n/32, step k/16, half (n/16)%2): lane = n%16 + 16*((k%16)/4), element k%4
         const long long qf = L.fw_off + ((((long long)(n >> 5) * L.KS + 2 * (k >> 4) + ((n >> 4) & 1)) * 64 + (n & 15) + 16 * ((k >> 2) & 3)) << 2) + (k & 3);

@@ -25,6 +25,12 @@
 #include "train_kernels.h"
 #include "train_chain.h"
 #include "train_chain32.h"
+#include "train_chain32s.h"
+#ifdef V21_CHAIN_FINE
+constexpr int kStampSlots = 2048;  // (diagnostic build: per-wave stamps)
+#else
+constexpr int kStampSlots = 64;
+#endif
 #include "dw_adam.h"
 
 using namespace v21;
@@ -784,6 +790,10 @@ struct v21_trainer {
   // the same chain in fp32 (train_chain32.h): f32 stacks up to 512 wide without a variational layer; d_fw / d_bw then
   // hold fp32 fragments, fw_off / bw_off count floats, and the weight-gradient operands are d_ht / d_dzt
   bool chain32 = false;
+  bool chain32s = false;  // ... with the 8-row kernel and its stream format (train_chain32s.h): trainers of small batches
+  int* d_jobs = nullptr;  // train_chain32s.h: C32sJob rows
+  int c32_frags(int d) const { return chain32s ? chain32s_frags(d) : chain32_frags(d); }
+  int c32_tiles(int d) const { return chain32s ? (d + 63) / 64 : (d + 31) / 32; }
   int loss_slot_pending = -2;  // f32 chain step on one rank: the Adam launch publishes the loss (-2: nothing pending)
   void *d_fw = nullptr, *d_bw = nullptr;
   long long fw_bytes = 0, bw_bytes = 0;
@@ -795,6 +805,7 @@ struct v21_trainer {
   int dw_xper = 0;
   long long BS = 0;                    // batch steps of 16 per feature tile
   unsigned long long* d_stamps = nullptr;
+  bool stamps_on = false;  // v21_trainer_enable_stamps: a stamp costs the stamping wave ~600 cycles (s_memtime + its wait), eleven per launch
   // ---- replayed steps (hipGraph).  One optimizer step is captured once per (rows, global rows, data pointers)
   // and replayed; what differs between steps comes from a device table of StepDesc (train_kernels.h) that the
   // host fills for the steps ahead: an epoch's steps in run_epoch, the next kDescRing steps in step_dev.
@@ -823,6 +834,7 @@ static int zalloc(float** p, size_t nfloat, hipStream_t st) {
   return V21_OK;
 }
 
+static int build_chain32s_jobs(v21_trainer* t);
 extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_trainer** out) {
   if (!m || !out) return fail(V21_ERR_ARG, "null argument");
   if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
@@ -897,7 +909,7 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
       HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 2 + 64)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 2 + 64, st));
       CHK(zalloc(&t->d_partial, (size_t)(max_batch + 31) / 32 + 4, st));
       HIPCHK(hipMalloc((void**)&t->d_ticket, 16)); HIPCHK(hipMemsetAsync(t->d_ticket, 0, 16, st));
-      HIPCHK(hipMalloc((void**)&t->d_stamps, 64 * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, 64 * 8, st));
+      HIPCHK(hipMalloc((void**)&t->d_stamps, kStampSlots * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, kStampSlots * 8, st));
       t->BS = ((long long)max_batch + 31) / 32 * 2 + 2;
       t->d_ht16.assign(L + 1, nullptr); t->d_dzt16.assign(L + 1, nullptr);
       const unsigned short one = precision == V21_PREC_F16 ? 0x3C00 : 0x3F80;
@@ -961,25 +973,31 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
     bool ok = precision == V21_PREC_F32 && !(env && env[0] == '0') && t->gl < 0;
     int mask_tiles = 0;
     for (int l = 0; l <= L && ok; ++l) ok = m->dims[l] <= kChainMaxDim;
-    for (int l = 0; l + 1 < L; ++l) mask_tiles += m->act[l] == V21_ACT_RELU ? (m->dims[l + 1] + 31) / 32 : 0;
-    ok = ok && mask_tiles <= kC32MaskTiles;
+    // a trainer of small batches (the reference's 256 rows) takes the 8-row kernel: twice the workgroups, half the
+    // matrix work in each (train_chain32s.h); V21_CHAIN32S = 0 / 1 overrides the choice
+    const char* es = getenv("V21_CHAIN32S");
+    t->chain32s = es ? es[0] == '1' : max_batch <= kC32sMaxBatch;
+    for (int l = 0; l + 1 < L; ++l) mask_tiles += m->act[l] == V21_ACT_RELU ? t->c32_tiles(m->dims[l + 1]) : 0;
+    ok = ok && mask_tiles <= (t->chain32s ? kC32sMaskTiles : kC32MaskTiles);
+    if (!ok) t->chain32s = false;
     if (ok) {
       long long of = 0, ob = 0;  // floats
       for (int l = 0; l < L; ++l) {
         const int K = m->dims[l], N = m->nw(l);
-        t->fw_off.push_back(of); of += (long long)((N + 31) / 32) * chain32_frags(K) * 256;
-        t->bw_off.push_back(ob); ob += (long long)((K + 31) / 32) * chain32_frags(N) * 256;
+        t->fw_off.push_back(of); of += (long long)t->c32_tiles(N) * t->c32_frags(K) * 256;
+        t->bw_off.push_back(ob); ob += (long long)t->c32_tiles(K) * t->c32_frags(N) * 256;
       }
       t->fw_bytes = of * 4; t->bw_bytes = ob * 4;
       HIPCHK(hipMalloc(&t->d_fw, (size_t)of * 4 + 64)); HIPCHK(hipMemsetAsync(t->d_fw, 0, (size_t)of * 4 + 64, st));
       HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 4 + 64)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 4 + 64, st));
       HIPCHK(hipMalloc((void**)&t->d_ticket, 16)); HIPCHK(hipMemsetAsync(t->d_ticket, 0, 16, st));
-      HIPCHK(hipMalloc((void**)&t->d_stamps, 64 * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, 64 * 8, st));
+      HIPCHK(hipMalloc((void**)&t->d_stamps, kStampSlots * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, kStampSlots * 8, st));
       t->chain32 = true;
     }
   }
   t->max_slices = std::max(1, (max_batch + 127) / 128);  // weight-gradient slices down to 8 batch steps
   CHK(zalloc(&t->d_slab, (size_t)t->max_slices * (t->P + 4), st));
+  if (t->chain32s) CHK(build_chain32s_jobs(t));
   *out = t;
   return V21_OK;
 }
@@ -1006,7 +1024,7 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   if (t->d_slab) hipFree(t->d_slab);
   if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
   if (t->d_dworder) hipFree(t->d_dworder);
-  if (t->chain32) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_ticket); hipFree(t->d_stamps); }
+  if (t->chain32) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_ticket); hipFree(t->d_stamps); if (t->d_jobs) hipFree(t->d_jobs); }
   if (t->chain) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_partial); hipFree(t->d_ticket); hipFree(t->d_stamps);
     for (void* p : t->d_ht16) if (p) hipFree(p);
     for (void* p : t->d_dzt16) if (p) hipFree(p); }
@@ -1201,11 +1219,11 @@ static AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_n
       al.KS = chain_steps(al.K); al.NS = chain_steps(al.N);
     } else if (t->chain32) {
       al.fw_off = t->fw_off[l]; al.bw_off = t->bw_off[l];
-      al.KS = chain32_frags(al.K); al.NS = chain32_frags(al.N);
+      al.KS = t->c32_frags(al.K); al.NS = t->c32_frags(al.N);
     }
   }
   if (t->chain) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->prec == V21_PREC_F16 ? 1 : 2; }
-  if (t->chain32) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = 3; }
+  if (t->chain32) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->chain32s ? 4 : 3; }
   a.skip_nt = (skip_nt && (t->chain || t->chain32)) ? 1 : 0;
   if (do_adam && t->chain32 && t->loss_slot_pending > -2) {  // a single-rank f32 chain step: this launch publishes its loss
     a.loss_acc = (unsigned long long*)t->d_ticket; a.loss_out = t->d_g + t->P; a.loss_out2 = t->d_steploss;
@@ -1413,7 +1431,7 @@ static ChainModel chain_model(v21_trainer* t) {
   a.fw_bytes = t->fw_bytes; a.bw_bytes = t->bw_bytes;
   a.BS = t->BS;
   a.loss_acc = (unsigned long long*)t->d_ticket;
-  a.stamps = t->d_stamps;
+  a.stamps = t->stamps_on ? t->d_stamps : nullptr;
   a.zcap_layer = -1;
   if (t->gl >= 0) { a.kl_weight = t->kl_weight; a.sample = t->sample; a.seed = t->seed; a.step = (unsigned long long)t->iter; }
   return a;
@@ -1439,6 +1457,7 @@ static int chain_attr(int prec) {
   if (done[prec]) return V21_OK;
   if (prec == V21_PREC_F32) {
     HIPCHK(hipFuncSetAttribute((const void*)train_chain32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC32LdsBytes));
+    HIPCHK(hipFuncSetAttribute((const void*)train_chain32s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC32sLdsBytes));
   } else if (prec == V21_PREC_F16) {
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
@@ -1455,6 +1474,8 @@ static int chain_attr(int prec) {
 static int chain_prefetchers(int ncons, int models) {
   if (models > 1) return 0;  // a sweep: measured slower with them (8 models, 24 prefetchers each: 106 k -> 95 k model-steps/s)
   const int idle = 256 - ncons;
+  static const char* env = getenv("V21_CHAIN_PREF");  // (diagnosis: prefetcher workgroups per XCD, 0 = none)
+  if (env) return std::max(0, std::min(atoi(env), idle / 8));
   return idle >= 8 ? std::min(8, idle / 8) : 0;
 }
 static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
@@ -1482,8 +1503,8 @@ static ChainModel chain_model32(v21_trainer* t) {
   for (int l = 0; l < L; ++l) {
     ChainLayer& c = a.lt[l];
     c.K = m->dims[l]; c.N = m->nw(l);
-    c.KS = chain32_frags(c.K); c.NT = (c.N + 31) / 32;   // fragments per 32-wide tile
-    c.NS = chain32_frags(c.N); c.KT = (c.K + 31) / 32;
+    c.KS = t->c32_frags(c.K); c.NT = t->c32_tiles(c.N);   // fragments per tile (32 wide; 64 in the 8-row kernel)
+    c.NS = t->c32_frags(c.N); c.KT = t->c32_tiles(c.K);
     c.relu = m->act[l] == V21_ACT_RELU;
     c.mask_tile = -1;
     if (c.relu && l + 1 < L) { c.mask_tile = mt; mt += c.NT; }
@@ -1495,12 +1516,30 @@ static ChainModel chain_model32(v21_trainer* t) {
   a.fw_bytes = t->fw_bytes; a.bw_bytes = t->bw_bytes;
   a.BS = t->Bp;
   a.loss_acc = (unsigned long long*)t->d_ticket;
-  a.stamps = t->d_stamps;
+  a.stamps = t->stamps_on ? t->d_stamps : nullptr;
   a.zcap_layer = -1;
+  a.jobs = t->d_jobs;
   return a;
 }
-static int launch_chain32_args(ChainArgs& a, hipStream_t st) {
+// the 8-row kernel's job table (once per trainer: it depends on the layer widths only)
+static int build_chain32s_jobs(v21_trainer* t) {
+  const ChainModel a = chain_model32(t);
+  std::vector<C32sJob> tab((size_t)2 * a.L * kC32sWaves);
+  c32s_build_jobs(a, tab.data());
+  HIPCHK(hipMalloc((void**)&t->d_jobs, tab.size() * sizeof(C32sJob)));
+  HIPCHK(hipMemcpyAsync(t->d_jobs, tab.data(), tab.size() * sizeof(C32sJob), hipMemcpyHostToDevice, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  return V21_OK;
+}
+static int launch_chain32_args(ChainArgs& a, hipStream_t st, bool small = false) {
   CHK(chain_attr(V21_PREC_F32));
+  if (small) {  // the 8-row kernel (train_chain32s.h)
+    a.ncons = (int)((((long long)a.rows + kC32sRows - 1) / kC32sRows + 7) / 8 * 8);
+    a.npref = chain_prefetchers(a.ncons, 1);
+    hipLaunchKernelGGL(train_chain32s_kernel, dim3(a.ncons + 8 * a.npref), dim3(64 * kC32sWaves), kC32sLdsBytes, st, a);
+    HIPCHK(hipGetLastError());
+    return V21_OK;
+  }
   a.ncons = (int)((((long long)a.rows + kC32Rows - 1) / kC32Rows + 7) / 8 * 8);  // whole rounds of the 8 XCDs
   a.npref = chain_prefetchers(a.ncons, 1);
   const dim3 grid(a.ncons + 8 * a.npref), block(64 * kC32Waves);
@@ -1764,7 +1803,7 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
     static_cast<ChainModel&>(a) = chain_model32(t);
     static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, dout, t, row0);
     a.gs = 1.0f;  // fp32 operands: no scaling of the gradients
-    CHK(launch_chain32_args(a, st));
+    CHK(launch_chain32_args(a, st, t->chain32s));
     int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
     const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
     nslice = (rows + k_chunk - 1) / k_chunk;
@@ -1797,7 +1836,7 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
         g.k_chunk = g.K; g.slab_stride = 0;
         grp.first[l] = blocks;
         blocks += g.nx * g.ny;
-        ad.lt[l] = NtAdamLayer{m->w_off[l], t->fw_off[l], t->bw_off[l], m->dims[l], chain32_frags(m->dims[l]), chain32_frags(m->nw(l))};
+        ad.lt[l] = NtAdamLayer{m->w_off[l], t->fw_off[l], t->bw_off[l], m->dims[l], t->c32_frags(m->dims[l]), t->c32_frags(m->nw(l))};
       }
       grp.first[L] = blocks;
       if (!t->capturing) t->iter += 1;
@@ -1807,6 +1846,7 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
       ad.sc = step_ctx(t);
       ad.loss_acc = (unsigned long long*)t->d_ticket; ad.loss_out = t->d_g + t->P; ad.loss_out2 = t->d_steploss;
       ad.loss_slot = in_table ? (int)(loss_out - t->d_steploss) : -1;
+      ad.fmt = t->chain32s ? 4 : 3;
       if (T == 2) hipLaunchKernelGGL(gemm_nt_dwadam_kernel<2>, dim3(blocks), dim3(256), 0, st, grp, ad);
       else hipLaunchKernelGGL(gemm_nt_dwadam_kernel<1>, dim3(blocks), dim3(256), 0, st, grp, ad);
       HIPCHK(hipGetLastError());
@@ -2089,7 +2129,7 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
     static_cast<ChainStep&>(a) = chain_step(t->d_x[which], din, t->y_is_x[which] ? nullptr : t->d_y[which], dout,
                                             t->d_rw[which], nullptr, 0, (int)n, (int)n, dout);
     a.fwd_only = 1;
-    CHK(launch_chain32_args(a, st));
+    CHK(launch_chain32_args(a, st, t->chain32s));
     long long acc = 0;
     HIPCHK(hipMemcpyAsync(&acc, t->d_ticket, sizeof acc, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemsetAsync(t->d_ticket, 0, sizeof acc, st));
@@ -2760,10 +2800,18 @@ extern "C" int v21_trainer_set_vae(v21_trainer* t, float kl_weight, int sample, 
   t->kl_weight = kl_weight; t->sample = sample ? 1 : 0; t->seed = (unsigned long long)seed;
   return V21_OK;
 }
+extern "C" int v21_trainer_enable_stamps(v21_trainer* t, int enable) {
+  if (!t) return fail(V21_ERR_ARG, "null trainer");
+  if (!t->chain && !t->chain32) return fail(V21_ERR_STATE, "this trainer does not use the chain kernel");
+  if (t->capturing) return fail(V21_ERR_STATE, "not while steps are being recorded");
+  t->stamps_on = enable != 0;
+  return V21_OK;
+}
 extern "C" int v21_trainer_chain_stamps(v21_trainer* t, uint64_t* out, int n) {
   if (!t || !out) return fail(V21_ERR_ARG, "null argument");
-  if (n < 1 || n > 64) return fail(V21_ERR_ARG, "n must be in [1,64]");
+  if (n < 1 || n > kStampSlots) return fail(V21_ERR_ARG, "n must be in [1,%d]", kStampSlots);
   if (!t->chain && !t->chain32) return fail(V21_ERR_STATE, "this trainer does not use the chain kernel");
+  if (!t->stamps_on) return fail(V21_ERR_STATE, "stamps are off (v21_trainer_enable_stamps)");
   CHK(use(t->ctx));
   HIPCHK(hipMemcpyAsync(out, t->d_stamps, (size_t)n * 8, hipMemcpyDeviceToHost, t->ctx->stream));
   HIPCHK(hipStreamSynchronize(t->ctx->stream));

@@ -212,8 +212,11 @@ int v21_trainer_use_graph(v21_trainer* tr, int enable);
 int v21_debug_poison_lds(v21_ctx* ctx, uint32_t pattern);
 /* diagnostics: s_memtime stamps of workgroup 0 of the last chain-kernel launch (train_chain.h):
  * [0] start, [1] batch gathered, [2..L+1] after forward layer l, [L+2] loss reduced,
- * [L+3..] after each backward layer (top down).  V21_ERR_STATE when the trainer runs the
- * per-layer path (f32, variational or >512-wide stacks). */
+ * [L+3..] after each backward layer (top down).  Off by default (a stamp holds its wave for ~600 cycles and the
+ * other waves meet it at the next barrier: eleven stamps were 2-3 us of every step until r3); enable_stamps turns
+ * them on for the launches that follow (steps already recorded into graphs keep what they were recorded with).
+ * V21_ERR_STATE when the trainer runs the per-layer path (variational f32 or >512-wide stacks) or stamps are off. */
+int v21_trainer_enable_stamps(v21_trainer* tr, int enable);
 int v21_trainer_chain_stamps(v21_trainer* tr, uint64_t* out, int n);
 /* Variational mode of a stack with a V21_ACT_GAUSS layer (A13; build-side extension, no
  * reference arithmetic exists for it): loss_i = recon_i + kl_weight * KL_i,

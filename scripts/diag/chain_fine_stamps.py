@@ -10,6 +10,7 @@ dims, act = [451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0]
 ctx = native.Context(0); st = native.Stack(ctx, dims, act)
 rng = np.random.default_rng(0); st.set_weights(rng.normal(scale=0.05, size=st.num_params).astype(np.float32))
 tr = native.Trainer(st, "f16", B)
+tr.enable_stamps()
 x = rng.normal(size=(B, 451)).astype(np.float32); w = np.full(B, 1 / 451, np.float32)
 d_x, d_w = ctx.malloc(x.nbytes), ctx.malloc(w.nbytes); ctx.h2d(d_x, x); ctx.h2d(d_w, w)
 for _ in range(50): tr.step_dev(d_x, None, d_w, B, B)

@@ -26,6 +26,8 @@ ctx.sync()
 t2 = time.perf_counter()
 print("B=%d %s: host enqueue %.1f us/step, total %.1f us/step" % (B, prec, (t1 - t0) / steps * 1e6, (t2 - t0) / steps * 1e6))
 try:
+    tr.enable_stamps()   # (off while timing: eleven stamps cost 2-3 us per step)
+    tr.step_dev(d_x, None, d_w, B, B); ctx.sync()
     s = tr.chain_stamps(2 + 5 + 1 + 4).astype(np.int64)
     d = np.diff(s)
     print("chain stamps (ticks):", d.tolist(), "total", int(s[-1] - s[0]))

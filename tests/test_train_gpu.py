@@ -567,13 +567,17 @@ def test_one_launch_gradient_adam_kernel_state_and_packed_copies(ctx, prec, dims
         ostate.m[:] = m; ostate.v[:] = v
 
 
+@pytest.mark.parametrize("rows", ["rows16", "rows8"])
 @pytest.mark.parametrize("case", ["autoencoder_ragged", "direct_7_to_451", "latent_emulator", "batch_4096", "single_row"])
-def test_f32_chain_kernel_matches_per_layer_path_and_oracle(ctx, case):
+def test_f32_chain_kernel_matches_per_layer_path_and_oracle(ctx, case, rows, monkeypatch):
     """csrc/train_chain32.h (the fp32 chain: 16-row blocks on the 16 x 16 x 4 MFMA, weight gradients in one grouped NT
-    launch, Adam) against the per-layer f32 path (V21_TRAIN_CHAIN=0) and the float64 oracle at the stated f32 tolerance:
-    loss 2e-5, gradient 2e-4 of its scale, weights after the step, Adam moments; then two more epochs with a partial
-    last batch and the forward-only validation launch."""
+    launch, Adam) and csrc/train_chain32s.h (8-row blocks on the 4 x 4 x 1 MFMA, its own packed-stream format; the
+    default for trainers of <= 1,024 rows -- both kernels are forced here on every case) against the per-layer f32 path
+    (V21_TRAIN_CHAIN=0) and the float64 oracle at the stated f32 tolerance: loss 2e-5, gradient 2e-4 of its scale,
+    weights after the step, Adam moments; then two more epochs with a partial last batch and the forward-only
+    validation launch."""
     import os
+    monkeypatch.setenv("V21_CHAIN32S", "1" if rows == "rows8" else "0")
     native, synth = pkg("_native"), pkg("synth")
     if case == "direct_7_to_451":
         dims, act, n = [7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0], 300
@@ -668,17 +672,20 @@ def test_chain_path_is_actually_used(ctx):
     native = pkg("_native")
     st = native.Stack(ctx, [16, 32, 16], [1, 0])
     x = np.zeros((8, 16), np.float32); w = np.ones(8, np.float32)
-    tr = native.Trainer(st, "f16", 8); tr.set_data(0, x, None, w); tr.run_epoch(None, 8)
+    tr = native.Trainer(st, "f16", 8); tr.set_data(0, x, None, w)
+    with pytest.raises(native.EngineError):
+        tr.chain_stamps(6)          # off until asked for (they cost 2-3 us per step)
+    tr.enable_stamps(); tr.run_epoch(None, 8)
     s = tr.chain_stamps(6)
     assert s[0] > 0 and np.all(np.diff(s.astype(np.int64)[:5]) > 0)
-    t32 = native.Trainer(st, "f32", 8); t32.set_data(0, x, None, w); t32.run_epoch(None, 8)
+    t32 = native.Trainer(st, "f32", 8); t32.set_data(0, x, None, w); t32.enable_stamps(); t32.run_epoch(None, 8)
     s32 = t32.chain_stamps(6)
     assert s32[0] > 0 and np.all(np.diff(s32.astype(np.int64)[:5]) > 0)
     for stack, prec in ((native.Stack(ctx, [16, 600, 16], [1, 0]), "f32"), (native.Stack(ctx, [16, 600, 16], [1, 0]), "f16"),
                         (native.Stack(ctx, [16, 40, 16], [2, 0]), "bf16"), (native.Stack(ctx, [16, 8, 16], [2, 0]), "f32")):
         t2 = native.Trainer(stack, prec, 8)
         with pytest.raises(native.EngineError):
-            t2.chain_stamps(4)
+            t2.enable_stamps()
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16"])
@@ -742,6 +749,8 @@ def test_variational_stack_on_the_chain_kernel(ctx, prec):
         tr.set_adam(lr=1e-3)
         tr.set_state(7)
         tr.set_data(0, y, None, w)
+        if chain:
+            tr.enable_stamps()
         loss = tr.run_epoch(None, n)
         res[chain] = (loss, tr.get_grad().astype(np.float64))
         if chain:
