@@ -443,8 +443,19 @@ class Trainer:
             y = np.ascontiguousarray(y, dtype=np.float32)
             assert y.shape[0] == x.shape[0]
         assert rw.shape == (x.shape[0],)
+        # A second train() on the same arrays (the reference's recipe: emulator.py:739-764 re-feeds its numpy arrays
+        # on every call) finds its split resident: (shape, 128-bit hash of every byte) of the three buffers decides.
+        # One pass of the hash is ~2 ms for the reference's 44 MB against ~6.5 ms of pageable upload.
+        from .preprocess import _digest
+        key = tuple((a.shape, _digest(a.reshape(-1).view(np.uint8).data)) if a is not None else None for a in (x, y, rw))
+        if getattr(self, "_resident", None) is None:
+            self._resident = {}
+        if self._resident.get(which) == key:
+            return
+        self._resident.pop(which, None)
         check(self.lib.v21_trainer_set_data(self.h, which, _fptr(x), _fptr(y) if y is not None else None,
                                             _fptr(rw), x.shape[0]))
+        self._resident[which] = key
 
     def run_epoch(self, perm, batch):
         loss = C.c_double(0)

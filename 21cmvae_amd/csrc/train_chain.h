@@ -377,7 +377,10 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // behind the weight loads saturating the CU's load/store path -- and in a 15-tile layer the ONE wave without a tile
   // has 22 of them: it left the layer at 11.4 k cycles when the last tile was done at 9.2 k, per-wave stamps of
   // scripts/diag/chain_wave_stamps.py.  Handing the fragments out through an LDS counter, the tile waves joining in when
-  // done, was slower still: every wave pays the counter's round trips in every layer, 58.9 k cycles against 55.5 k.)
+  // done, was slower still: every wave pays the counter's round trips in every layer, 58.9 k cycles against 55.5 k.
+  // Nor does it help to make the tile waves finish together -- s_setprio by progress, so that a wave that is ahead
+  // yields: they then all end at ~10 k where the oldest ended at 5 k and the youngest at 9.4 k; the layer's weights pass
+  // the CU's load path at ~38 B/clk either way.)
   auto flush_t = [&](const elem* act, int F, void* dst, int tiles) __attribute__((always_inline)) {
     const int nfrag = 2 * ((F + 31) >> 5);
     frag* d = reinterpret_cast<frag*>(dst);

@@ -9,6 +9,8 @@ section 8b).  This module provides that subset -- ``Sequential`` (what
 ``stop_training`` -- with numpy in and out, and runs everything numeric through the
 C ABI (``_native``) on the GPU.  There is no CPU execution path.
 """
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from . import _native, callbacks as cb_mod, losses as loss_mod, optimizers as opt_mod
@@ -358,15 +360,35 @@ class Model:
         self.stop_training = False
         self._dirty_host = True
         cbs.on_train_begin()
+
+        def draw():
+            return _rng.permutation(n).astype(np.int32)
+
+        # The next epoch's permutation is drawn while this epoch runs on the GPU (run_epoch blocks inside the library with
+        # the GIL released; drawing 24,562 indices takes ~0.25 ms, 4 % of an f32 epoch of the reference recipe during
+        # which the GPU sat idle).  Same generator, same order of draws; a draw that early stopping leaves unused is
+        # undone (the generator's state is put back), so the stream of random numbers is what it was without this.
+        pool = ThreadPoolExecutor(1) if shuffle else None
+        ahead = rng_before = None
         for epoch in range(initial_epoch, epochs):
             cbs.on_epoch_begin(epoch)
             tr.set_lr(float(self.optimizer.lr))
             if getattr(self, "_vae_seed", None) is not None:  # a callback may anneal kl_weight between epochs
                 tr.set_vae(self.kl_weight, self.sample_latent, self._vae_seed)
-            perm = _rng.permutation(n).astype(np.int32) if shuffle else None
+            perm = None
+            if shuffle:
+                perm = ahead.result() if ahead is not None else draw()
+                ahead = None
             if dp and perm is not None:
                 perm = bcast(perm)
-            logs = {"loss": tr.run_epoch(perm, batch_size)}
+            if shuffle and epoch + 1 < epochs:
+                rng_before = _rng.bit_generator.state
+                ahead = pool.submit(draw)
+            try:
+                logs = {"loss": tr.run_epoch(perm, batch_size)}
+            finally:
+                if ahead is not None:
+                    ahead.result()  # (nothing else touches the generator while the draw is running)
             self._dirty_host = True
             if validation_data is not None:
                 logs["val_loss"] = tr.evaluate(1, min(vb, tr.max_batch))
@@ -375,6 +397,10 @@ class Model:
             cbs.on_epoch_end(epoch, logs)
             if self.stop_training:
                 break
+        if ahead is not None:  # drawn ahead, never used
+            _rng.bit_generator.state = rng_before
+        if pool is not None:
+            pool.shutdown()
         cbs.on_train_end()
         self.optimizer.iterations = tr.get_state()[0]
         self._sync_host()
