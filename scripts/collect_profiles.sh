@@ -24,6 +24,8 @@ rocprofv3 --kernel-trace --stats -d $OUT/t4096 -o t --output-format csv -- $PY $
 cp $OUT/t4096/t_kernel_stats.csv $OUT/kernel_stats_train_b4096_f16.csv
 rocprofv3 --kernel-trace --stats -d $OUT/t256 -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 256 f32 200 > $OUT/train_probe_b256_f32.txt 2>&1
 cp $OUT/t256/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f32.csv
+V21_CHAIN32S=0 rocprofv3 --kernel-trace --stats -d $OUT/t256r16 -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 256 f32 200 > $OUT/train_probe_b256_f32_rows16_kernel.txt 2>&1
+cp $OUT/t256r16/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f32_rows16_kernel.csv
 rocprofv3 --kernel-trace --stats -d $OUT/t256h -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 256 f16 200 > $OUT/train_probe_b256_f16.txt 2>&1
 cp $OUT/t256h/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f16.csv
 rocprofv3 --kernel-trace --stats -d $OUT/t16k -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 16384 f16 100 > $OUT/train_probe_b16384_f16.txt 2>&1
@@ -58,5 +60,11 @@ $PY scripts/power_probe.py > $OUT/power_probe_fused_random_vs_zero_operands.txt 
 # 4. in-kernel cycle stamps of the SHIPPED headline kernel (diagnostic build: not a benchmark)
 cd $ROOT
 V21_LIB=$ROOT/21cmvae_amd/libv21_stamp.so $PY scripts/diag_stamps.py f16 > $OUT/stamps_fused_f16x2sp_block_tile_cycles.txt 2>&1
+# 5. per-wave stamps of the chain kernels (diagnostic build) and the two micro-benchmarks their analysis rests on
+V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/chain_wave_stamps.py 4096 f16 > $OUT/wave_stamps_chain_b4096_f16.txt 2>&1
+V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/chain_wave_stamps.py 256 f32 > $OUT/wave_stamps_chain_b256_f32_rows8_kernel.txt 2>&1
+[ -x scripts/diag/l1_stream_probe ] && scripts/diag/l1_stream_probe > $OUT/l1_stream_probe.txt 2>&1
+[ -x scripts/diag/mfma4_rate_probe ] && scripts/diag/mfma4_rate_probe > $OUT/mfma4_rate_probe.txt 2>&1
+rm -rf $OUT/t256r16
 rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t4096 $OUT/t256 $OUT/t256h $OUT/t16k $OUT/tpmc_* $OUT/sq_* $OUT/fwd $OUT/joint
 ls -la $OUT
