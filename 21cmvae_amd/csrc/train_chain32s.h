@@ -4,7 +4,7 @@
 // that is 16 workgroups, and the launch is bound by the f32 MFMA rate of the 16 CUs they occupy (63 k cycles of matrix
 // work per workgroup; measured 127 k).  With the MFMAs compiled out the same kernel takes 78 k cycles: that is the fp32
 // weight stream (2.7 MB through one CU) and the per-layer latencies -- what a workgroup with LESS matrix work would be
-// left with.  Hence 8 rows per workgroup (32 workgroups at batch 256, 128 at 1,024) on the 4 x 4 x 1 f32 MFMA
+// left with.  Hence 8 rows per workgroup (32 workgroups at batch 256, 256 at 2,048) on the 4 x 4 x 1 f32 MFMA
 // (16 blocks of 4 x 4, K = 1; layout checked by scripts/diag/mfma4_probe.hip):
 //
 //   lane l = 4 b + j of a wave: block b <-> the features 4 b .. 4 b + 3 of a 64-FEATURE tile, j <-> batch row j of a
@@ -45,7 +45,7 @@ namespace v21 {
 
 constexpr int kC32sRows = 8;
 constexpr int kC32sWaves = 16;
-constexpr int kC32sMaxBatch = 1024;
+constexpr int kC32sMaxBatch = 2048;  // 256 workgroups: one round of the chip (2,048 rows: 92.8 us per step against the 16-row kernel's 106.8)
 constexpr int kC32sMaskTiles = 120;
 constexpr int kC32sBufBytes = 2 * kC32sRows * kC32Pitch * 4;
 constexpr int kC32sYBytes = kC32sRows * kC32Pitch * 4;

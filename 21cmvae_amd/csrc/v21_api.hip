@@ -1817,6 +1817,8 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
       g.ep = NT_DW; g.nz = nslice; g.k_chunk = k_chunk; g.slab_stride = (long long)t->P + 4;
       probs.push_back(g);
     }
+    // (one contraction slice = up to kNtMaxKPerWg rows.  Letting one workgroup walk 1,024 or 2,048 rows instead of the
+    //  sliced three-launch path below: 71.3 against 70.6 us and 96.7 against 92.8 us per step -- no gain.)
     if (single && nslice == 1 && L <= kNtMaxGroup && !(getenv("V21_DW32_ADAM") && getenv("V21_DW32_ADAM")[0] == '0')) {
       // one rank, the batch is one contraction slice: gradients, Adam, the packed fp32 streams and the batch loss in ONE
       // launch (gemm_nt.h: NtAdamInfo) -- the step is 2 launches

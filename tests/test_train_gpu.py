@@ -572,7 +572,7 @@ def test_one_launch_gradient_adam_kernel_state_and_packed_copies(ctx, prec, dims
 def test_f32_chain_kernel_matches_per_layer_path_and_oracle(ctx, case, rows, monkeypatch):
     """csrc/train_chain32.h (the fp32 chain: 16-row blocks on the 16 x 16 x 4 MFMA, weight gradients in one grouped NT
     launch, Adam) and csrc/train_chain32s.h (8-row blocks on the 4 x 4 x 1 MFMA, its own packed-stream format; the
-    default for trainers of <= 1,024 rows -- both kernels are forced here on every case) against the per-layer f32 path
+    default for trainers of <= 2,048 rows -- both kernels are forced here on every case) against the per-layer f32 path
     (V21_TRAIN_CHAIN=0) and the float64 oracle at the stated f32 tolerance: loss 2e-5, gradient 2e-4 of its scale,
     weights after the step, Adam moments; then two more epochs with a partial last batch and the forward-only
     validation launch."""
