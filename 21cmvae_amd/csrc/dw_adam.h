@@ -95,6 +95,10 @@ __device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int 
   // Rounds of U steps (2 U fragments, 16 KiB in flight per wave).  A rolling refill of each consumed slot was
   // measured SLOWER (19.3 vs 16.9 us at batch 4,096): the kernel is bound by the bytes one CU can pull (~55 GB/s
   // when most lines come from beyond L2; 666 KB per CU at batch 4,096), not by the round trips.
+  // (r3: 64 x 32 tiles -- two A-tiles against one B-tile per workgroup, the B fragments loaded once for two MFMAs:
+  // 147 MB through the load paths instead of 194 MB, 196 workgroups, one per CU -- were SLOWER as well: 52.0 against
+  // 46.0 us per step at 4,096 rows, 62.3 against 53.3 at 6,144.  What a CU pulls is set by the bytes it has in flight
+  // against a ~2 us trip beyond L2, and one 165-VGPR workgroup per CU holds 144 KiB where two of these hold 256.)
   int s = wave;
   for (; s + NW * (U - 1) < steps; s += NW * U) {
     frag fa[U], fb[U];
