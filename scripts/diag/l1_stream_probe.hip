@@ -47,7 +47,7 @@ int main() {
         hipMemcpy(&t, dt, 8, hipMemcpyDeviceToHost);
       }
       const double moved = (double)fpw * waves * 1024 * (reps - 1);
-      printf("waves %2d  loads in flight/wave %2d : %8llu ticks (s_memtime, 100 MHz) for %.0f KiB x %d passes -> %.1f B per tick\n", waves, D, t, moved / (reps - 1) / 1024, reps - 1, moved / (double)t);
+      printf("waves %2d  loads in flight/wave %2d : %8llu cycles (s_memtime) for %.0f KiB x %d passes -> %.1f B per cycle\n", waves, D, t, moved / (reps - 1) / 1024, reps - 1, moved / (double)t);
     }
   }
   return 0;
