@@ -75,6 +75,9 @@ struct NtAdamInfo {
   StepCtx sc;                  // replayed step: alpha and the loss slot come from the descriptor
   unsigned long long* loss_acc; float* loss_out; float* loss_out2; int loss_slot;  // the step's batch loss (thread 0 of block 0)
   int fmt;                     // 3: streams of train_chain32.h (16-row kernel), 4: of train_chain32s.h (8-row kernel)
+#ifdef V21_CHAIN_FINE
+  unsigned long long* dbg;     // diagnostic build: phase stamps of a few workgroups (scripts/diag/dwadam_stamps.py)
+#endif
   NtAdamLayer lt[kNtMaxGroup];
 };
 
@@ -86,15 +89,21 @@ template <> struct NtTraits<PrecBF16> { static constexpr int KSTEP = 16, MAXSTEP
 // T = MFMA tiles per side of the workgroup tile: T = 1 -> 32x32 (latency: small batches),
 // T = 2 -> 64x64 (twice the arithmetic intensity per loaded byte: large batches; the
 // contraction range of a wave is then walked in rounds of <= MAXSTEPS/2 k-steps).
+#ifdef V21_CHAIN_FINE
+#define NTFINE(i) do { if constexpr (ADAM) { if ((threadIdx.x & 63) == 0 && ad->dbg && (blockIdx.x % 47) == 0 && blockIdx.x / 47 < 8) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ad->dbg[((blockIdx.x / 47) * 8 + (i)) * 4 + (threadIdx.x >> 6)] = t_; } } } while (0)
+#else
+#define NTFINE(i)
+#endif
 template <class P, int T, class GROUP, bool ADAM = false>
 __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo* ad) {
   using TR = NtTraits<P>;
+  NTFINE(0);
   int pi = 0;
   while (pi + 1 < grp.count && (int)blockIdx.x >= grp.first[pi + 1]) ++pi;  // uniform: scalar loop
   const int bid = blockIdx.x - grp.first[pi];
   const NtArgs& g = grp.p[pi];
   const int bx = bid % g.nx, by = (bid / g.nx) % g.ny, bz = bid / (g.nx * g.ny);
-  const int EP = g.ep;
+  const int EP = ADAM ? (int)NT_DW : g.ep;  // (the fused gradient + Adam launch has one epilogue: no branches on g.ep)
   constexpr int KSTEP = TR::KSTEP, REGS = TR::REGS;
   constexpr int ROUND = TR::MAXSTEPS / (T * T > 1 ? 2 : 1);  // k-steps in flight per round
   constexpr int HOFF = (REGS == 8 ? 8 : 4);
@@ -111,6 +120,35 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
   const int per = (nsteps + 3) / 4;
   const int s0 = wave * per, s1 = min(nsteps, s0 + per);
 
+  // ADAM, 32 x 32 tiles: this thread's four arena elements (rows m0 + 8 wave + 4 lh + e, column n0 + li) are requested
+  // NOW, before the operands: they arrive in the same ~2-us window, where the epilogue used to start its own round trip
+  // after the tiles had met (phase stamps, scripts/diag/dwadam_stamps.py: operands +7.3 k cycles, MFMAs +4.8 k, meeting
+  // +0.7 k, epilogue +8.4 k of a 22-k-cycle workgroup).  Elements past the edge are clamped to a valid one, never stored.
+  // Everything the epilogue needs of the problem and of the Adam block, read ONCE here: both live in the kernel-argument
+  // segment and are indexed by `pi`, so every use further down was a scalar load of its own, waited for on the spot -- some
+  // thirty ~200-cycle round trips in a row were the epilogue's 8 k cycles.
+  struct { float* C; long long ldc; int M, N; long long arena_off, fw_off, bw_off; int K, KS, NS, fmt; float alpha, omb1, omb2, eps;
+           float *w, *m, *v, *fw, *bw; } h{};
+  if constexpr (ADAM) {
+    const NtAdamLayer& al = ad->lt[pi];
+    h.C = g.C; h.ldc = g.ldc; h.M = g.M; h.N = g.N;
+    h.arena_off = al.arena_off; h.fw_off = al.fw_off; h.bw_off = al.bw_off; h.K = al.K; h.KS = al.KS; h.NS = al.NS; h.fmt = ad->fmt;
+    h.alpha = ad->sc.desc ? ad->sc.desc[*ad->sc.cur].alpha : ad->alpha;
+    h.omb1 = ad->omb1; h.omb2 = ad->omb2; h.eps = ad->eps;
+    h.w = ad->w; h.m = ad->m; h.v = ad->v; h.fw = ad->fw; h.bw = ad->bw;
+  }
+  float am[4], av[4], aw[4];
+  if constexpr (ADAM && T == 1) {
+    const NtAdamLayer& al = ad->lt[pi];
+    const int n = min(n0 + li, g.N - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = min(m0 + 8 * wave + 4 * lh + e, g.M - 1);
+      const long long i = al.arena_off + (long long)m * g.ldc + n;
+      am[e] = ad->m[i]; av[e] = ad->v[i]; aw[e] = ad->w[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (the requests stay ahead of the operand loads)
+  }
   const float* ap[T];
   const float* bp[T];
 #pragma unroll
@@ -144,6 +182,7 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
           }
       }
     }
+    NTFINE(1);
 #pragma unroll
     for (int s = 0; s < ROUND; ++s) {
       if (r0 + s < s1) {
@@ -179,6 +218,7 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
       }
     }
   }
+  NTFINE(2);
   // ---- meet in LDS; wave w finishes accumulator registers 4w..4w+3 = rows 8w + 4h + {0..3} of each tile
 #pragma unroll
   for (int ti = 0; ti < T; ++ti)
@@ -187,7 +227,10 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
 #pragma unroll
       for (int i = 0; i < 16; ++i) part[wave][ti * T + tj][i][lane] = acc[ti][tj][i];
   __syncthreads();
-  float* C = g.C + (long long)bz * g.slab_stride;
+  NTFINE(3);
+  float* C = ADAM ? h.C : g.C + (long long)bz * g.slab_stride;
+  const int gM = ADAM ? h.M : g.M, gN = ADAM ? h.N : g.N;
+  const long long gldc = ADAM ? h.ldc : g.ldc;
 #pragma unroll
   for (int ti = 0; ti < T; ++ti) {
 #pragma unroll
@@ -201,7 +244,7 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
       }
       const int n = n0 + 32 * tj + li;
       const int mrow = m0 + 32 * ti + 8 * wave + 4 * lh;  // rows mrow .. mrow+3
-      if (n >= g.N) continue;
+      if (n >= gN) continue;
       float bias = 0.f;
       if (EP == NT_FWD || EP == NT_FWD_RELU || EP == NT_FWD_UNPRE) bias = g.bias[n];
       const float amean = EP == NT_FWD_UNPRE ? g.aff_mean[n] : 0.f;
@@ -212,30 +255,30 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
         if (EP == NT_FWD) v = v + bias;
         if (EP == NT_FWD_RELU) v = fmaxf(v + bias, 0.f);
         if (EP == NT_FWD_UNPRE) v = (v + bias) * g.aff_std + amean;  // rounded as numpy does: (p * std) + mean
-        if (EP == NT_DX_MASK) v = (m < g.M && g.mask[(long long)m * g.ldmask + n] > 0.f) ? v : 0.f;
+        if (EP == NT_DX_MASK) v = (m < gM && g.mask[(long long)m * g.ldmask + n] > 0.f) ? v : 0.f;
         r[e] = v;
-        if (m < g.M) C[(long long)m * g.ldc + n] = v;
+        if (m < gM) C[(long long)m * gldc + n] = v;
         if constexpr (ADAM) {
-          if (m < g.M) {  // Keras Adam on this element (train_kernels.h: adam_update_element) + its packed copies
-            const NtAdamLayer& al = ad->lt[pi];
-            const long long i = al.arena_off + (long long)m * g.ldc + n;
-            const float alpha = ad->sc.desc ? ad->sc.desc[*ad->sc.cur].alpha : ad->alpha;
-            const float m0 = ad->m[i], v0 = ad->v[i];
-            const float mi = m0 + (v - m0) * ad->omb1;
-            const float vi = v0 + (v * v - v0) * ad->omb2;
-            const float wi = ad->w[i] - (mi * alpha) / (sqrtf(vi) + ad->eps);
-            ad->m[i] = mi; ad->v[i] = vi; ad->w[i] = wi;
-            if (m < al.K) {  // a kernel element (the bias row has no packed copy); k = m
+          if (m < h.M) {  // Keras Adam on this element (train_kernels.h: adam_update_element) + its packed copies
+            const long long i = h.arena_off + (long long)m * h.ldc + n;
+            float m0, v0, w0;
+            if constexpr (T == 1) { m0 = am[e]; v0 = av[e]; w0 = aw[e]; }
+            else { m0 = h.m[i]; v0 = h.v[i]; w0 = h.w[i]; }
+            const float mi = m0 + (v - m0) * h.omb1;
+            const float vi = v0 + (v * v - v0) * h.omb2;
+            const float wi = w0 - (mi * h.alpha) / (sqrtf(vi) + h.eps);
+            h.m[i] = mi; h.v[i] = vi; h.w[i] = wi;
+            if (m < h.K) {  // a kernel element (the bias row has no packed copy); k = m
               long long qf, qb;  // (train_kernels.h: adam_repack_element spells the two formats out)
-              if (ad->fmt == 4) {
-                qf = al.fw_off + ((((long long)(n >> 6) * al.KS + (m >> 2)) * 64 + (n & 63)) << 2) + (m & 3);
-                qb = al.bw_off + ((((long long)(m >> 6) * al.NS + (n >> 2)) * 64 + (m & 63)) << 2) + (n & 3);
+              if (h.fmt == 4) {
+                qf = h.fw_off + ((((long long)(n >> 6) * h.KS + (m >> 2)) * 64 + (n & 63)) << 2) + (m & 3);
+                qb = h.bw_off + ((((long long)(m >> 6) * h.NS + (n >> 2)) * 64 + (m & 63)) << 2) + (n & 3);
               } else {
-                qf = al.fw_off + ((((long long)(n >> 5) * al.KS + 2 * (m >> 4) + ((n >> 4) & 1)) * 64 + (n & 15) + 16 * ((m >> 2) & 3)) << 2) + (m & 3);
-                qb = al.bw_off + ((((long long)(m >> 5) * al.NS + 2 * (n >> 4) + ((m >> 4) & 1)) * 64 + (m & 15) + 16 * ((n >> 2) & 3)) << 2) + (n & 3);
+                qf = h.fw_off + ((((long long)(n >> 5) * h.KS + 2 * (m >> 4) + ((n >> 4) & 1)) * 64 + (n & 15) + 16 * ((m >> 2) & 3)) << 2) + (m & 3);
+                qb = h.bw_off + ((((long long)(m >> 5) * h.NS + 2 * (n >> 4) + ((m >> 4) & 1)) * 64 + (m & 15) + 16 * ((n >> 2) & 3)) << 2) + (n & 3);
               }
-              ad->fw[qf] = wi;
-              ad->bw[qb] = wi;
+              h.fw[qf] = wi;
+              h.bw[qb] = wi;
             }
           }
         }
@@ -247,6 +290,9 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
       }
     }
   }
+  NTFINE(4);
+  if constexpr (ADAM) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  NTFINE(5);
 }
 
 template <class P, int T, class GROUP>

@@ -98,7 +98,14 @@ struct C32sJob {
   int units;    // units of this step
   int nxt_w_off, nxt_bw;  // the wave's NEXT unit (whose first chunk rolls in under this one's last): offset, 1 = backward stream
   int nxt_b_off, nxt_nb;  // ... its bias (arena offset of the tile's first feature) and how many features have one (0: none)
-  int pad[5];
+  // what the step needs of its layer (kept here, not read from ChainModel::lt[l] in the kernel: a dynamically indexed
+  // kernel-argument field is a scalar load where it is used, ~200 cycles each and waited for on the spot -- five such
+  // round trips stood at the head of every step)
+  int mask_tile;   // forward: first mask tile of this layer's ReLU (-1: a linear layer; a hidden ReLU layer always keeps
+                   // its mask); backward: of the layer below, whose mask applies to the gradient this step produces
+  int width;       // forward: output width N (the loss masks the padding); backward: unused
+  int flush_f;     // features of the activation image this step flushes (forward: K, backward: N)
+  unsigned flush_lo, flush_hi;  // ... and where to (ht16 of the layer / dzt16 of the layer)
 };
 static_assert(sizeof(C32sJob) == 64, "C32sJob rows are read as 16 dwords");
 // rows (1 + 2 L - 1) x 16 waves; `fw_off` / `bw_off` in 16-byte words, `b_off` in floats (ChainLayer's)
@@ -114,6 +121,12 @@ inline void c32s_build_jobs(const ChainModel& a, C32sJob* tab) {
     for (int w = 0; w < kC32sWaves; ++w) {
       C32sJob& j = tab[(1 + i) * kC32sWaves + w];
       j.parts = sp.parts; j.units = sp.units;
+      const ChainLayer& mk = fwd ? ly : a.lt[l - 1];
+      j.mask_tile = mk.relu ? mk.mask_tile : -1;
+      j.width = ly.N;
+      j.flush_f = fwd ? ly.K : ly.N;
+      const unsigned long long dst = (unsigned long long)(fwd ? ly.ht16 : ly.dzt16);
+      j.flush_lo = (unsigned)dst; j.flush_hi = (unsigned)(dst >> 32);
       if (w >= sp.units) continue;
       j.t = w / sp.parts; j.s = w % sp.parts;
       const int c0 = j.s * sp.cps;
@@ -173,6 +186,8 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     C32sJob j;
     j.w_off = p->w_off; j.nch = p->nch; j.f0 = p->f0; j.t = p->t; j.s = p->s; j.parts = p->parts; j.units = p->units;
     j.nxt_w_off = p->nxt_w_off; j.nxt_bw = p->nxt_bw; j.nxt_b_off = p->nxt_b_off; j.nxt_nb = p->nxt_nb;
+    j.mask_tile = p->mask_tile; j.width = p->width; j.flush_f = p->flush_f;
+    j.flush_lo = p->flush_lo; j.flush_hi = p->flush_hi;
     return j;
   };
   auto next_of = [&](const C32sJob& j) __attribute__((always_inline)) -> Job {
@@ -234,11 +249,11 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
       for (int i = 0; i < 8; ++i) ystg[wave * PITCH + lane + 64 * i] = v[i];
     }
   }
+  C32sJob jnext = row(1);  // (collected by the barrier's wait, see the layer loop)
   chain_barrier();
   chain_stamp(a, 1);
   float lsum[2] = {0.f, 0.f};
   int cur = 0;
-  C32sJob jnext = row(1);
 
   // The 8 rows x F features in `act` -> the fp32 operand of the weight gradient (dst[f * BS + batch row], gemm_nt.h): a lane
   // takes one feature and four consecutive rows and stores them as one 16-byte word (32 features x 32 contiguous bytes per
@@ -256,7 +271,10 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = r4 + j < vrows ? act[(r4 + j) * PITCH + fc] : 0.f;
-      if (f < F) *reinterpret_cast<f32x4*>(d + (long long)f * a.BS + m0 + r4) = v;
+      // (an address-space-1 store: `dst` comes out of the job row as an integer, and through a generic pointer this
+      //  would be a FLAT store, which counts on vmcnt AND lgkmcnt -- every wait of the contraction then degrades to 0)
+      typedef f32x4 __attribute__((address_space(1))) * gptr;
+      if (f < F) *(gptr)(unsigned long long)(d + (long long)f * a.BS + m0 + r4) = v;
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -279,6 +297,10 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
           n0v = *reinterpret_cast<const f32x4*>(ap + 4 * fn);
           n1v = *reinterpret_cast<const f32x4*>(ap + 4 * PITCH + 4 * fn);
         }
+        // (the reads stay AHEAD of this fragment's MFMAs: left to itself the scheduler now and then sinks them to just
+        // before their use, and the wait that follows exposes an LDS round trip per fragment -- 18.8 vs 21.5 k cycles per
+        // big layer between two builds that differed in unrelated scalar code)
+        __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifdef V21_C32S_NOMFMA  // (one VALU instruction per fragment keeps the loads alive)
         asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[0][0]) : "v"(w[j][0]), "v"(b0[0]), "v"(b1[0]));
@@ -342,12 +364,10 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
 
   // ---- forward
   for (int l = 0; l < a.L; ++l) {
-    const ChainLayer& ly = a.lt[l];
     const bool last = l == a.L - 1;
     const float* act = buf[cur];
     float* out = buf[cur ^ 1];
     const C32sJob jb = jnext;
-    jnext = row(2 + l);
     const int parts = jb.parts, t = jb.t;
     auto finish = [&](int t, f32x4 (&acc)[2]) __attribute__((always_inline)) {
       const int n = 64 * t + 4 * blk;
@@ -355,7 +375,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
         unsigned bits = 0;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          if (ly.relu) {
+          if (jb.mask_tile >= 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               acc[g][r] = fmaxf(acc[g][r], 0.f);
@@ -364,7 +384,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
           }
           *reinterpret_cast<f32x4*>(out + (4 * g + jr) * PITCH + n) = acc[g];
         }
-        if (ly.relu && ly.mask_tile >= 0) masks[ly.mask_tile + t][lane] = (unsigned short)bits;
+        if (jb.mask_tile >= 0) masks[jb.mask_tile + t][lane] = (unsigned short)bits;
       } else {  // loss_i = w_i sum_j (p - y)^2,  dL/dp = scale w_i (p - y)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -373,7 +393,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
           f32x4 dd;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float df = n + r < ly.N ? acc[g][r] - yq[r] : 0.f;
+            const float df = n + r < jb.width ? acc[g][r] - yq[r] : 0.f;
             lsum[g] += df * df;
             dd[r] = gsc * df;
           }
@@ -382,7 +402,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
       }
     };
     FINE(4 * l);
-    flush_t(act, ly.K, ly.ht16, jb.units);  // this layer's input -> operand of its weight gradient
+    flush_t(act, jb.flush_f, (void*)(((unsigned long long)jb.flush_hi << 32) | jb.flush_lo), jb.units);  // this layer's input -> operand of its weight gradient
     if (jb.nch > 0) {
       f32x4 acc[2] = {bnext, bnext};
       FINE(4 * l + 1);
@@ -410,6 +430,10 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
         if (blk == 0) red[wave][4 * g + jr] = v * rwl[4 * g + jr];
       }
     }
+    // the next step's row: requested HERE, so that the barrier's own `s_waitcnt lgkmcnt(0)` collects it.  (Requested at
+    // the head of the step it was still in flight inside the contraction, and with a scalar load outstanding every wait
+    // for an LDS read there became lgkmcnt(0): the operand read-ahead was gone, 18.8 -> 21.5 k cycles per big layer.)
+    jnext = row(2 + l);
     chain_barrier();
     cur ^= 1;
     chain_stamp(a, 2 + l);
@@ -429,16 +453,13 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
 
   // ---- backward: layer l consumes dZ_l (in buf[cur]) and produces dZ_{l-1}
   for (int l = a.L - 1; l >= 1; --l) {
-    const ChainLayer& ly = a.lt[l];
-    const ChainLayer& below = a.lt[l - 1];
     const float* act = buf[cur];
     float* out = buf[cur ^ 1];
     const C32sJob jb = jnext;
-    jnext = row(2 + a.L + (a.L - 1 - l));
     const int parts = jb.parts, t = jb.t;
     auto finish = [&](int t, f32x4 (&acc)[2]) __attribute__((always_inline)) {
       const int k = 64 * t + 4 * blk;
-      const unsigned bits = below.relu ? masks[below.mask_tile + t][lane] : 0xFFu;
+      const unsigned bits = jb.mask_tile >= 0 ? masks[jb.mask_tile + t][lane] : 0xFFu;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -449,7 +470,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
         *reinterpret_cast<f32x4*>(out + (4 * g + jr) * PITCH + k) = acc[g];
       }
     };
-    flush_t(act, ly.N, ly.dzt16, jb.units);  // dZ of this layer's output -> operand of its weight gradient
+    flush_t(act, jb.flush_f, (void*)(((unsigned long long)jb.flush_hi << 32) | jb.flush_lo), jb.units);  // dZ of this layer's output -> operand of its weight gradient
     if (jb.nch > 0) {
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       const bool odd = contract(bw + jb.w_off + lane, act, jb.nch, acc, next_of(jb), jb.f0);
@@ -465,6 +486,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
         finish(t, acc);
       }
     }
+    jnext = row(2 + a.L + (a.L - 1 - l));
     chain_barrier();
     cur ^= 1;
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));

@@ -1849,6 +1849,9 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
       ad.loss_acc = (unsigned long long*)t->d_ticket; ad.loss_out = t->d_g + t->P; ad.loss_out2 = t->d_steploss;
       ad.loss_slot = in_table ? (int)(loss_out - t->d_steploss) : -1;
       ad.fmt = t->chain32s ? 4 : 3;
+#ifdef V21_CHAIN_FINE
+      ad.dbg = t->stamps_on ? t->d_stamps + 1024 : nullptr;
+#endif
       if (T == 2) hipLaunchKernelGGL(gemm_nt_dwadam_kernel<2>, dim3(blocks), dim3(256), 0, st, grp, ad);
       else hipLaunchKernelGGL(gemm_nt_dwadam_kernel<1>, dim3(blocks), dim3(256), 0, st, grp, ad);
       HIPCHK(hipGetLastError());
