@@ -99,7 +99,12 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
   using TR = NtTraits<P>;
   NTFINE(0);
   int pi = 0;
-  while (pi + 1 < grp.count && (int)blockIdx.x >= grp.first[pi + 1]) ++pi;  // uniform: scalar loop
+  if constexpr (ADAM) {  // (no dependent chain of scalar loads: the whole table, then compares)
+#pragma unroll
+    for (int i = 1; i < kNtMaxGroup; ++i) pi += (i < grp.count && (int)blockIdx.x >= grp.first[i]) ? 1 : 0;
+  } else {
+    while (pi + 1 < grp.count && (int)blockIdx.x >= grp.first[pi + 1]) ++pi;  // uniform: scalar loop
+  }
   const int bid = blockIdx.x - grp.first[pi];
   const NtArgs& g = grp.p[pi];
   const int bx = bid % g.nx, by = (bid / g.nx) % g.ny, bz = bid / (g.nx * g.ny);
@@ -228,9 +233,86 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
       for (int i = 0; i < 16; ++i) part[wave][ti * T + tj][i][lane] = acc[ti][tj][i];
   __syncthreads();
   NTFINE(3);
-  float* C = ADAM ? h.C : g.C + (long long)bz * g.slab_stride;
-  const int gM = ADAM ? h.M : g.M, gN = ADAM ? h.N : g.N;
-  const long long gldc = ADAM ? h.ldc : g.ldc;
+  if constexpr (ADAM) {
+    // ---- gradient element -> Keras Adam (train_kernels.h: adam_update_element) -> arena, moments, packed fp32 streams.
+    // A thread holds rows mrow .. mrow + 3 of one column n: in the 8-row kernel's format (fmt 4) that is ONE 16-byte word
+    // of the forward stream, and after a 4 x 4 transpose inside the quad of lanes that holds columns n & ~3 .. + 3, one
+    // 16-byte word of the backward stream per lane -- 2 stores instead of 8 scattered 4-byte ones.
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti) {
+#pragma unroll
+      for (int tj = 0; tj < T; ++tj) {
+        const int n = n0 + 32 * tj + li;
+        const int mrow = m0 + 32 * ti + 8 * wave + 4 * lh;  // rows mrow .. mrow+3
+        const bool nvalid = n < h.N;
+        float wnew[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int reg = 4 * wave + e, tt = ti * T + tj;
+          const float v = (part[0][tt][reg][lane] + part[1][tt][reg][lane]) + (part[2][tt][reg][lane] + part[3][tt][reg][lane]);
+          const int m = mrow + e;
+          if (nvalid && m < h.M) {
+            const long long i = h.arena_off + (long long)m * h.ldc + n;
+            float m0v, v0v, w0v;
+            if constexpr (T == 1) { m0v = am[e]; v0v = av[e]; w0v = aw[e]; }
+            else { m0v = h.m[i]; v0v = h.v[i]; w0v = h.w[i]; }
+            const float mi = m0v + (v - m0v) * h.omb1;
+            const float vi = v0v + (v * v - v0v) * h.omb2;
+            const float wi = w0v - (mi * h.alpha) / (sqrtf(vi) + h.eps);
+            h.C[(long long)m * h.ldc + n] = v;
+            h.m[i] = mi; h.v[i] = vi; h.w[i] = wi;
+            if (m < h.K) wnew[e] = wi;  // (the bias row has no packed copy)
+          }
+        }
+        if (h.fmt == 4 && mrow + 3 < h.K) {  // (the same for the four lanes of a quad: they share wave, lh, ti)
+          if (nvalid)
+            *reinterpret_cast<f32x4v*>(h.fw + h.fw_off + ((((long long)(n >> 6) * h.KS + (mrow >> 2)) * 64 + (n & 63)) << 2)) =
+                f32x4v{wnew[0], wnew[1], wnew[2], wnew[3]};
+          // 4 x 4 transpose in the quad (n & 3 == li & 3: the tile starts at a multiple of 32): two butterfly stages
+          const int j = li & 3;
+          auto xchg1 = [&](float give) __attribute__((always_inline)) -> float {
+            return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+          };
+          auto xchg2 = [&](float give) __attribute__((always_inline)) -> float {
+            return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0x4E, 0xf, 0xf, true));
+          };
+          {  // partner j ^ 1 (quad_perm [1,0,3,2]): pairs (0,1) and (2,3)
+            const float g0 = xchg1((j & 1) ? wnew[0] : wnew[1]), g1 = xchg1((j & 1) ? wnew[2] : wnew[3]);
+            if (j & 1) { wnew[0] = g0; wnew[2] = g1; } else { wnew[1] = g0; wnew[3] = g1; }
+          }
+          {  // partner j ^ 2 (quad_perm [2,3,0,1]): pairs (0,2) and (1,3)
+            const float g0 = xchg2((j & 2) ? wnew[0] : wnew[2]), g1 = xchg2((j & 2) ? wnew[1] : wnew[3]);
+            if (j & 2) { wnew[0] = g0; wnew[1] = g1; } else { wnew[2] = g0; wnew[3] = g1; }
+          }
+          // now wnew[i] = W[mrow + j][nb + i], nb = n & ~3
+          const int mj = mrow + j, nb = n & ~3;
+          if (nb < h.N)
+            *reinterpret_cast<f32x4v*>(h.bw + h.bw_off + ((((long long)(mj >> 6) * h.NS + (nb >> 2)) * 64 + (mj & 63)) << 2)) =
+                f32x4v{wnew[0], wnew[1], wnew[2], wnew[3]};
+        } else if (nvalid) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int m = mrow + e;
+            if (m >= h.K) continue;
+            long long qf, qb;  // (train_kernels.h: adam_repack_element spells the two formats out)
+            if (h.fmt == 4) {
+              qf = h.fw_off + ((((long long)(n >> 6) * h.KS + (m >> 2)) * 64 + (n & 63)) << 2) + (m & 3);
+              qb = h.bw_off + ((((long long)(m >> 6) * h.NS + (n >> 2)) * 64 + (m & 63)) << 2) + (n & 3);
+            } else {
+              qf = h.fw_off + ((((long long)(n >> 5) * h.KS + 2 * (m >> 4) + ((n >> 4) & 1)) * 64 + (n & 15) + 16 * ((m >> 2) & 3)) << 2) + (m & 3);
+              qb = h.bw_off + ((((long long)(m >> 5) * h.NS + 2 * (n >> 4) + ((m >> 4) & 1)) * 64 + (m & 15) + 16 * ((n >> 2) & 3)) << 2) + (n & 3);
+            }
+            h.fw[qf] = wnew[e];
+            h.bw[qb] = wnew[e];
+          }
+        }
+      }
+    }
+  } else {
+  float* C = g.C + (long long)bz * g.slab_stride;
+  const int gM = g.M, gN = g.N;
+  const long long gldc = g.ldc;
 #pragma unroll
   for (int ti = 0; ti < T; ++ti) {
 #pragma unroll
@@ -258,30 +340,6 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
         if (EP == NT_DX_MASK) v = (m < gM && g.mask[(long long)m * g.ldmask + n] > 0.f) ? v : 0.f;
         r[e] = v;
         if (m < gM) C[(long long)m * gldc + n] = v;
-        if constexpr (ADAM) {
-          if (m < h.M) {  // Keras Adam on this element (train_kernels.h: adam_update_element) + its packed copies
-            const long long i = h.arena_off + (long long)m * h.ldc + n;
-            float m0, v0, w0;
-            if constexpr (T == 1) { m0 = am[e]; v0 = av[e]; w0 = aw[e]; }
-            else { m0 = h.m[i]; v0 = h.v[i]; w0 = h.w[i]; }
-            const float mi = m0 + (v - m0) * h.omb1;
-            const float vi = v0 + (v * v - v0) * h.omb2;
-            const float wi = w0 - (mi * h.alpha) / (sqrtf(vi) + h.eps);
-            h.m[i] = mi; h.v[i] = vi; h.w[i] = wi;
-            if (m < h.K) {  // a kernel element (the bias row has no packed copy); k = m
-              long long qf, qb;  // (train_kernels.h: adam_repack_element spells the two formats out)
-              if (h.fmt == 4) {
-                qf = h.fw_off + ((((long long)(n >> 6) * h.KS + (m >> 2)) * 64 + (n & 63)) << 2) + (m & 3);
-                qb = h.bw_off + ((((long long)(m >> 6) * h.NS + (n >> 2)) * 64 + (m & 63)) << 2) + (n & 3);
-              } else {
-                qf = h.fw_off + ((((long long)(n >> 5) * h.KS + 2 * (m >> 4) + ((n >> 4) & 1)) * 64 + (n & 15) + 16 * ((m >> 2) & 3)) << 2) + (m & 3);
-                qb = h.bw_off + ((((long long)(m >> 5) * h.NS + 2 * (n >> 4) + ((m >> 4) & 1)) * 64 + (m & 15) + 16 * ((n >> 2) & 3)) << 2) + (n & 3);
-              }
-              h.fw[qf] = wi;
-              h.bw[qb] = wi;
-            }
-          }
-        }
       }
       if (EP != NT_DW && g.CT) {  // rows of the transposed copy are padded past the batch: no bound check on m
         float4 t4 = make_float4(mrow + 0 < g.M ? r[0] : 0.f, mrow + 1 < g.M ? r[1] : 0.f, mrow + 2 < g.M ? r[2] : 0.f,
@@ -289,6 +347,7 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
         *reinterpret_cast<float4*>(g.CT + (long long)n * g.ldct + mrow) = t4;
       }
     }
+  }
   }
   NTFINE(4);
   if constexpr (ADAM) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
