@@ -26,6 +26,7 @@
 #include "train_chain.h"
 #include "train_chain32.h"
 #include "train_chain32s.h"
+#include "dw_adam32.h"
 #ifdef V21_CHAIN_FINE
 constexpr int kStampSlots = 2048;  // (diagnostic build: per-wave stamps)
 #else
@@ -1852,7 +1853,9 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
 #ifdef V21_CHAIN_FINE
       ad.dbg = t->stamps_on ? t->d_stamps + 1024 : nullptr;
 #endif
+      static const bool lds_rows = !(getenv("V21_DW32_LDS") && getenv("V21_DW32_LDS")[0] == '0');
       if (T == 2) hipLaunchKernelGGL(gemm_nt_dwadam_kernel<2>, dim3(blocks), dim3(256), 0, st, grp, ad);
+      else if (rows <= kDw32MaxRows && lds_rows) hipLaunchKernelGGL(dwadam32_kernel, dim3(blocks), dim3(256), 0, st, grp, ad);  // operands through LDS in whole rows (dw_adam32.h)
       else hipLaunchKernelGGL(gemm_nt_dwadam_kernel<1>, dim3(blocks), dim3(256), 0, st, grp, ad);
       HIPCHK(hipGetLastError());
       t->copies_ok = true;
