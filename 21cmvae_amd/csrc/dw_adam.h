@@ -41,6 +41,9 @@ struct DwAdamModel {
   // starts with a cold L2 after the kernel boundary, so what it reads, it reads from HBM or the Infinity Cache)
   const int* order;
   int xper;
+#ifdef V21_CHAIN_FINE
+  unsigned long long* dbg;  // diagnostic build: phase stamps of a few workgroups (scripts/diag/dwadam_stamps.py)
+#endif
   DwAdamLayer lt[16];
 };
 // what changes from step to step (per model of a group)
@@ -52,6 +55,11 @@ struct DwAdamStep {
 };
 constexpr int kDwAdamWaves = 8, kDwAdamInFlight = 8, kDwAdamPitch = 40;
 
+#ifdef V21_CHAIN_FINE
+#define DWFINE(i) do { if ((threadIdx.x & 63) == 0 && md.dbg && (blockIdx.x % 47) == 0 && blockIdx.x / 47 < 8) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); md.dbg[((blockIdx.x / 47) * 8 + (i)) * 8 + (threadIdx.x >> 6)] = t_; } } while (0)
+#else
+#define DWFINE(i)
+#endif
 template <class P>
 __device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int lb, const float alpha, const float out_scale,
                                                const int steps, const int slot, const StepCtx& sc) {
@@ -59,6 +67,7 @@ __device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int 
   constexpr int NW = kDwAdamWaves, U = kDwAdamInFlight;
   __shared__ __attribute__((aligned(16))) float part[NW][16][64];
   __shared__ __attribute__((aligned(16))) unsigned short pk[32 * kDwAdamPitch];
+  DWFINE(0);
   int pi = 0;
   while (pi + 1 < md.L && lb >= md.lt[pi + 1].first) ++pi;  // scalar
   const DwAdamLayer& g = md.lt[pi];
@@ -92,13 +101,18 @@ __device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  DWFINE(1);
   // Rounds of U steps (2 U fragments, 16 KiB in flight per wave).  A rolling refill of each consumed slot was
   // measured SLOWER (19.3 vs 16.9 us at batch 4,096): the kernel is bound by the bytes one CU can pull (~55 GB/s
   // when most lines come from beyond L2; 666 KB per CU at batch 4,096), not by the round trips.
   // (r3: 64 x 32 tiles -- two A-tiles against one B-tile per workgroup, the B fragments loaded once for two MFMAs:
   // 147 MB through the load paths instead of 194 MB, 196 workgroups, one per CU -- were SLOWER as well: 52.0 against
-  // 46.0 us per step at 4,096 rows, 62.3 against 53.3 at 6,144.  What a CU pulls is set by the bytes it has in flight
-  // against a ~2 us trip beyond L2, and one 165-VGPR workgroup per CU holds 144 KiB where two of these hold 256.)
+  // 46.0 us per step at 4,096 rows, 62.3 against 53.3 at 6,144 -- with six steps (18 KiB) in flight per wave, and just as
+  // slow with ten (30 KiB per wave, 213 VGPRs: 52.4 / 61.7 us): 196 workgroups, one per CU, leave 60 CUs idle and put eight
+  // waves on a load path that sixteen keep at 52 B/clk here (phase stamps, scripts/diag/dwadam_stamps.py, 4,096 rows: 20 k
+  // of a workgroup's 27.5 k cycles are this loop, 1 MB through each of the 124 CUs that hold two workgroups; ~3 k pass
+  // before the first request -- the kernel-argument block itself arrives cold from device memory at every launch, and
+  // reading this layer's block once instead of field by field did not shorten that: 33.8 against 33.3 us at 256 rows).)
   int s = wave;
   for (; s + NW * (U - 1) < steps; s += NW * U) {
     frag fa[U], fb[U];
@@ -122,9 +136,11 @@ __device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int 
     for (int u = 0; u < U; ++u)
       if (s + NW * u < steps) acc = P::template mfma<false>(fa[u], fb[u], acc);
   }
+  DWFINE(2);
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
   __syncthreads();
+  DWFINE(3);
   // ---- the eight partial tiles in a fixed order, Adam, the tile as 16-bit values for the packed copies.
   // element (row m, column c) of a 32 x 32 accumulator tile: lane c + 32 ((m % 8) / 4), register 4 (m / 8) + m % 4
 #pragma unroll
@@ -146,6 +162,7 @@ __device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int 
     pk[mrow * kDwAdamPitch + ncol] = bits;
   }
   __syncthreads();
+  DWFINE(4);
   typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
   if (wave < 2) {
     // forward fragment (n-tile tj, k-step 2 ti + wave): lane = 32 ((k % 16) / 8) + n % 32, element k % 8
@@ -166,6 +183,7 @@ __device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int 
                                 ((((long long)ti * g.NS + ns) * 64 + lane) << 3)) = v;
     }
   }
+  DWFINE(5);
 }
 
 // XCD-major logical blocks (workgroups b, b + 8, ... share an XCD: observed round-robin dispatch; speed only): an XCD

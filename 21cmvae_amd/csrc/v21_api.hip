@@ -1727,6 +1727,9 @@ static int launch_dw_adam(v21_trainer* t, int rows, int brows, float alpha, int 
   // (from ~2k rows on: below that the operands are small and the contiguous runs balance the XCDs better --
   //  r3, autoencoder stack, f16: 4,096 rows 46.9 -> 45.7 us per step, 1,024 rows 36.3 -> 37.4)
   if (rows >= 2048) { md.order = t->d_dworder; md.xper = t->dw_xper; }
+#ifdef V21_CHAIN_FINE
+  md.dbg = t->stamps_on ? t->d_stamps + 1024 : nullptr;
+#endif
   DwAdamStep st{};
   st.steps = (rows + 15) / 16;
   st.slot = slot;
