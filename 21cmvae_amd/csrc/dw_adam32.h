@@ -20,8 +20,14 @@ namespace v21 {
 
 constexpr int kDw32MaxRows = 256;
 
+#ifdef V21_CHAIN_FINE  // (diagnostic build: phase stamps of a few workgroups, scripts/diag/dwadam_stamps.py)
+#define D32FINE(i) do { if ((threadIdx.x & 63) == 0 && ad.dbg && (blockIdx.x % 47) == 0 && blockIdx.x / 47 < 8) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ad.dbg[((blockIdx.x / 47) * 8 + (i)) * 4 + (threadIdx.x >> 6)] = t_; } } while (0)
+#else
+#define D32FINE(i)
+#endif
 __global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, const NtAdamInfo ad) {
   __shared__ __attribute__((aligned(16))) float smem[64 * 256];  // operand rows, then the four partial tiles
+  D32FINE(0);
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   if (ad.loss_acc && blockIdx.x == 0 && threadIdx.x == 0) {
     const float f = (float)((double)(long long)*ad.loss_acc * (1.0 / 4294967296.0));
@@ -52,6 +58,7 @@ __global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, con
   const int bx = bid % nx, by = bid / nx;
   const int m0 = 32 * by, n0 = 32 * bx;
 
+  D32FINE(6);
   // this thread's four arena elements (rows m0 + 8 wave + 4 lh + e, column n0 + li): requested before the operands
   float pm[4], pv[4], pw[4];
   {
@@ -63,17 +70,34 @@ __global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, con
       pm[e] = am_[i]; pv[e] = av_[i]; pw[e] = aw_[i];
     }
   }
-  // ---- stage: wave w brings rows w, w + 4, ... (0 .. 31: H^T rows m0 + r; 32 .. 63: dZ^T rows n0 + r - 32)
+  D32FINE(7);
+  // ---- stage: wave w brings rows w, w + 4, ... (0 .. 31: H^T rows m0 + r; 32 .. 63: dZ^T rows n0 + r - 32).
+  // r & 15 = wave + 4 (i & 3): four swizzled lane offsets per operand, worked out once; the row pointer itself is scalar.
+  // (Phase stamps: the kernel-argument batch is read at ~2.1 k cycles, the Adam state requested at ~2.7 k, and the
+  // sixteen row loads of a wave take until ~7.1 k to ISSUE -- ~280 cycles each, whether a row costs 30 instructions or 15,
+  // and whether or not the table of first blocks is preloaded into SGPRs: the LDS-DMA requests themselves are paced.)
+  unsigned voffA[4], voffB[4];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int j = 0; j < 4; ++j) {
+    const int c = lane ^ (wave + 4 * j);
+    voffA[j] = 4 * c + 4 > lda ? 0u : 16u * c;  // (past the row: any valid address; those k are >= K and zeroed below)
+    voffB[j] = 4 * c + 4 > ldb ? 0u : 16u * c;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
     const int r = wave + 4 * i;
-    const float* row = r < 32 ? gA + (long long)min(m0 + r, M - 1) * lda : gB + (long long)min(n0 + r - 32, N - 1) * ldb;
-    const long long pitch = r < 32 ? lda : ldb;
-    int c = lane ^ (r & 15);
-    if (4 * c + 4 > pitch) c = 0;  // (past the row: any valid address; those k are >= K and zeroed below)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)(row + 4 * c),
+    const char* row = reinterpret_cast<const char*>(gA + (long long)min(m0 + r, M - 1) * lda);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)(row + voffA[i & 3]),
                                      (__attribute__((address_space(3))) void*)(smem + r * 256), 16, 0, 0);
   }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = wave + 4 * i;
+    const char* row = reinterpret_cast<const char*>(gB + (long long)min(n0 + r, N - 1) * ldb);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)(row + voffB[i & 3]),
+                                     (__attribute__((address_space(3))) void*)(smem + (32 + r) * 256), 16, 0, 0);
+  }
+  D32FINE(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // ---- contraction: wave w takes its quarter of the k-steps of 8
@@ -95,11 +119,13 @@ __global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, con
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
     }
   }
+  D32FINE(2);
   __syncthreads();  // every wave is done with the operand rows: the partial tiles take their place
   float(*part)[16][64] = reinterpret_cast<float(*)[16][64]>(smem);
 #pragma unroll
   for (int i = 0; i < 16; ++i) part[wave][i][lane] = acc[i];
   __syncthreads();
+  D32FINE(3);
   // ---- gradient element -> Keras Adam (train_kernels.h: adam_update_element) -> arena, moments, packed fp32 streams.
   // wave w finishes accumulator registers 4 w .. 4 w + 3 = rows 8 w + 4 lh + {0..3} of the tile (as gemm_nt_body)
   const int n = n0 + li, mrow = m0 + 8 * wave + 4 * lh;
@@ -163,6 +189,11 @@ __global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, con
       abw[qb] = wnew[e];
     }
   }
+  D32FINE(4);
+#ifdef V21_CHAIN_FINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  D32FINE(5);
 }
 
 }  // namespace v21

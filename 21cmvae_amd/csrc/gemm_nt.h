@@ -350,7 +350,9 @@ __device__ __forceinline__ void gemm_nt_body(const GROUP& grp, const NtAdamInfo*
   }
   }
   NTFINE(4);
+#ifdef V21_CHAIN_FINE
   if constexpr (ADAM) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
   NTFINE(5);
 }
 

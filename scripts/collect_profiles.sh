@@ -63,6 +63,9 @@ V21_LIB=$ROOT/21cmvae_amd/libv21_stamp.so $PY scripts/diag_stamps.py f16 > $OUT/
 # 5. per-wave stamps of the chain kernels (diagnostic build) and the two micro-benchmarks their analysis rests on
 V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/chain_wave_stamps.py 4096 f16 > $OUT/wave_stamps_chain_b4096_f16.txt 2>&1
 V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/chain_wave_stamps.py 256 f32 > $OUT/wave_stamps_chain_b256_f32_rows8_kernel.txt 2>&1
+V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/dwadam_stamps.py 256 f32 > $OUT/phase_stamps_dwadam_b256_f32.txt 2>&1
+V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so V21_DW32_LDS=0 $PY scripts/diag/dwadam_stamps.py 256 f32 > $OUT/phase_stamps_dwadam_b256_f32_register_operands.txt 2>&1
+V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/dwadam_stamps.py 4096 f16 > $OUT/phase_stamps_dw16_adam_b4096_f16.txt 2>&1
 [ -x scripts/diag/l1_stream_probe ] && scripts/diag/l1_stream_probe > $OUT/l1_stream_probe.txt 2>&1
 [ -x scripts/diag/mfma4_rate_probe ] && scripts/diag/mfma4_rate_probe > $OUT/mfma4_rate_probe.txt 2>&1
 rm -rf $OUT/t256r16

@@ -28,3 +28,5 @@ d = s[1024:1024 + 8 * 8 * NW].reshape(8, 8, NW)
 names = ["start", "loads issued", "MFMAs done", "tiles met", "epilogue issued", "stores drained"] if prec == "f32" else ["start", "state requested", "MFMAs done", "tiles met", "Adam done", "end"]
 for b in range(8):
     print("workgroup %3d:" % (47 * b), "  ".join("%s %s" % (names[i], [int(v - d[b, 0].min()) for v in d[b, i]]) for i in range(6)))
+    if d[b, 6].any():
+        print("      (scalars read %s, Adam state requested %s)" % ([int(v - d[b, 0].min()) for v in d[b, 6]], [int(v - d[b, 0].min()) for v in d[b, 7]]))
