@@ -251,6 +251,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // forward tile, its bias (lane i: bias[32 t + i], 0 past the layer's width; the tile start hands the 32
   // values out by readlane).  Vector loads on purpose: the compiler cannot prove the arena read-only (no
   // scalar loads), and sixteen dependent loads per lane at the start of a tile would stall the stream.
+  // (r3, measured and dropped: splitting the CONTRACTION of single-tile layers across the waves, as train_chain32.h does --
+  // 352 -> 9 forward and 32 <- 352 backward keep one wave busy for six chunks end to end, 3.5 k + 3.1 k cycles of 55 k.
+  // This kernel sits at its 128 registers with 43 scalar registers already spilled; a second site of the contraction or of
+  // the epilogue, or both folded into a two-pass loop with one site each, spills 68-156 vector registers to scratch: the
+  // step went from 46 to 114 us.  The partial tiles also cannot simply meet in the free activation image here: as 16-bit
+  // operands fp32 sums are garbage -- one half-word in 32 carries the exponent of a NaN / Inf -- and the image's padding
+  // columns are read again against zero weights, so the area must be cleared after the meeting.)
   struct Job { const frag* w; const float* b; bool bok; };
   auto fwd_job = [&](int l, int t) __attribute__((always_inline)) -> Job {
     const ChainLayer& ly = a.lt[l];
