@@ -137,7 +137,9 @@ __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
 #else
 #define CFINE(i)
 #endif
-template <class P>
+// FEAT: which features of the general body an instantiation carries (see train_chain_body)
+constexpr int kChainGauss = 1, kChainJoint = 2, kChainOut = 4, kChainAll = 7;
+template <class P, int FEAT = kChainAll>
 __device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st);
 
 // Every row-block workgroup streams the model's whole packed weight set, and the Adam kernel has just rewritten it:
@@ -160,17 +162,17 @@ __device__ __forceinline__ void chain_prefetch(const ChainModel& a, const ChainS
 }
 
 // one model: everything in the kernel-argument block
-template <class P>
+template <class P, int FEAT = kChainAll>
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const ChainArgs a) {
   if ((int)blockIdx.x >= a.ncons) { chain_prefetch(a, a); return; }
-  train_chain_body<P>(a, a);
+  train_chain_body<P, FEAT>(a, a);
 }
 // a sweep: blockIdx.y = model, the per-model blocks in device memory
-template <class P>
+template <class P, bool GAUSS = true>  // GAUSS = false: no member of the sweep has a variational layer
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_group_kernel(const ChainModel* __restrict__ tab,
                                                                              const ChainStep st) {
   if ((int)blockIdx.x >= st.ncons) { chain_prefetch(tab[blockIdx.y], st); return; }
-  train_chain_body<P>(tab[blockIdx.y], st);
+  train_chain_body<P, GAUSS ? kChainGauss : 0>(tab[blockIdx.y], st);
 }
 
 // joint step (BASELINE configs[2]): the autoencoder (signals -> signals) and the latent emulator (parameters -> latent)
@@ -184,21 +186,22 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_group_kernel(con
 //                              with those latents as targets.  Recomputing the encoder costs ~1/6 of an autoencoder
 //                              pass and removes every dependence between the two families;
 //   blocks [2 ncons, ...)      prefetchers of both models' weight streams.
-template <class P>
+template <class P, bool GAUSS = true>  // GAUSS = false: the autoencoder is not variational (the emulator never is)
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_joint_kernel(const ChainModel* __restrict__ tab /* [2], device */,
                                                                              const ChainStep sa, const ChainStep sb) {
+  constexpr int FA = kChainJoint | (GAUSS ? kChainGauss : 0);
   if ((int)blockIdx.x >= 2 * sa.ncons) {
     ChainStep sp = sa;
     sp.ncons = 2 * sa.ncons;
     chain_prefetch(tab[0], sp); chain_prefetch(tab[1], sp);
     return;
   }
-  if ((int)blockIdx.x < sa.ncons) { train_chain_body<P>(tab[0], sa); return; }
+  if ((int)blockIdx.x < sa.ncons) { train_chain_body<P, FA>(tab[0], sa); return; }
   ChainStep se = sa;  // the encoder alone, for the emulator's rows
   se.fwd_only = 1; se.nfwd = tab[0].zcap_layer + 1; se.blk0 = sa.ncons;
-  train_chain_body<P>(tab[0], se);
+  train_chain_body<P, FA>(tab[0], se);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the encoder's last LDS accesses precede the emulator's gather
-  train_chain_body<P>(tab[1], sb);
+  train_chain_body<P, kChainJoint>(tab[1], sb);
 }
 
 // LDS-only rendezvous: own LDS writes retired, then the barrier.  Deliberately NOT __syncthreads():
@@ -214,8 +217,18 @@ __device__ __forceinline__ chain_s4 chain_tr_read(const void* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((chain_s4 __attribute__((address_space(3)))*)p);
 }
 
-template <class P>
+// FEAT: the features this instantiation carries -- kChainGauss: a variational layer (sampling, KL, its backward);
+// kChainJoint: the joint step's captured latents, targets from LDS, encoder-only passes, shifted block numbers;
+// kChainOut: FORWARD mode (outputs to global memory, fused parameter transform; no loss, no backward pass).  The flag set is
+// a promise of the host (which model, which launch), and it folds every branch on an absent feature away at compile time:
+// the general body (all three) sits at its 128 vector registers with 43 scalar registers spilled into lanes of one of
+// them and 5 vector registers in scratch; FEAT = 0 -- what a trainer of the reference's stacks launches -- has 15 and 0,
+// and its step is 1.4 us shorter at every batch size (r3: 46.0 -> 44.6 us at 4,096 rows, 33.3 -> 31.9 at 256).
+template <class P, int FEAT>
 __device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st) {
+#define GG(cond) ((FEAT & kChainGauss) ? (bool)(cond) : false)
+#define GJ(cond) ((FEAT & kChainJoint) ? (bool)(cond) : false)
+#define GO(cond) ((FEAT & kChainOut) ? (bool)(cond) : false)
   using frag = typename P::frag;
   using elem = typename P::elem;
   constexpr int NW = kChainWaves, PITCH = kChainPitch, RPW = 32 / NW;  // RPW: batch rows a wave gathers
@@ -237,7 +250,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // XCD x carries the CONSECUTIVE row blocks x * ceil(nb / 8) ...: the batch slice whose weight-gradient tiles
   // gemm_dw16* then runs on the same XCD, so that it finds the operands this kernel wrote in its own L2.
   const int nrb = (st.rows + 31) >> 5;
-  const int bidx = (int)blockIdx.x - st.blk0;
+  const int bidx = (int)blockIdx.x - ((FEAT & kChainJoint) ? st.blk0 : 0);
   const int rb = (bidx & 7) * ((nrb + 7) >> 3) + (bidx >> 3);
   if (rb >= nrb) return;  // (the grid is rounded up to a multiple of 8)
   const int m0 = rb * 32;
@@ -325,7 +338,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       for (int i = 0; i < 8; ++i) {
         const int k = lane + 64 * i;
         float t = xs[k < K0 ? k : K0 - 1];
-        if (i == 0 && st.tin) {  // par_transform on the (<= 8) input columns, as affine_in_kernel does it
+        if (i == 0 && GO(st.tin)) {  // par_transform on the (<= 8) input columns, as affine_in_kernel does it
           const int jc = lane < K0 ? lane : 0;
           const float zf = st.tin->zero_floor[jc];
           if (zf > 0.f && t == 0.f) t = zf;
@@ -342,13 +355,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       for (int i = 0; i < 8; ++i) {
         const int k = lane + 64 * i;  // <= 511 < PITCH, YP
         buf[0][m * PITCH + k] = (elem)v[r][i];
-        if (!st.y && !st.y_from_lds && !st.out) ystg[m * YP + k] = v[r][i];
+        if (!st.y && !GJ(st.y_from_lds) && !GO(st.out)) ystg[m * YP + k] = v[r][i];
       }
     }
-    if (st.y_from_lds) {  // rows of the previous model's captured layer (fp32, in the variational head's buffer)
+    if (GJ(st.y_from_lds)) {  // rows of the previous model's captured layer (fp32, in the variational head's buffer)
       const int DOl = a.lt[a.L - 1].N;
       for (int i = tid; i < 32 * DOl; i += 64 * NW) ystg[(i / DOl) * YP + i % DOl] = zs[(i / DOl) * ZP + i % DOl];
-    } else if (st.y && !st.out) {  // separate targets: a second pass through the same registers
+    } else if (st.y && !GO(st.out)) {  // separate targets: a second pass through the same registers
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         const int kmax = m0 + RPW * wave + r < st.rows ? DO : 0;
@@ -481,7 +494,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   };
 
   // ---- forward
-  const int LF = st.nfwd > 0 ? st.nfwd : a.L;
+  const int LF = GJ(st.nfwd > 0) ? st.nfwd : a.L;
   for (int l = 0; l < LF; ++l) {
     const ChainLayer& ly = a.lt[l];
     const bool last = l == a.L - 1;
@@ -507,14 +520,14 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       }
       const Job nxt = t + NW < ly.NT ? fwd_job(l, t + NW) : fwd_from(l + 1);
       const bool odd = contract(fw + ly.fw_off + ((long long)t * ly.KS) * 64 + lane, act, nch, acc, nxt);
-      if (ly.gauss) {  // keep (mu | lv) in fp32: the sampling pass below turns them into z
+      if (GG(ly.gauss)) {  // keep (mu | lv) in fp32: the sampling pass below turns them into z
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + 8 * g + 4 * lh;
           if (n < ZP) *reinterpret_cast<f32x4*>(zs + li * ZP + n) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
         }
       } else if (!last) {
-        if (l == a.zcap_layer) {  // joint step: this layer's outputs are the next model's targets (fp32)
+        if (GJ(l == a.zcap_layer)) {  // joint step: this layer's outputs are the next model's targets (fp32)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int n = n0 + 8 * g + 4 * lh;
@@ -537,7 +550,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
           uint2 pk = {P::pack2(acc[4 * g], acc[4 * g + 1]), P::pack2(acc[4 * g + 2], acc[4 * g + 3])};
           *reinterpret_cast<uint2*>(out + li * PITCH + n) = pk;
         }
-      } else if (st.out) {
+      } else if (GO(st.out)) {
         // FORWARD mode: the tile (32 rows x 32 features, this lane: one row, 4 x 4 features) goes through this wave's
         // 4.5 KB of the (unused) target area as [row][feature] and leaves as 16-byte stores -- eight lanes per row,
         // 128 contiguous bytes -- instead of 32 rows x 16 bytes per instruction
@@ -590,7 +603,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       settle(odd);
     }
     CFINE(4 * l + 2);
-    if (ly.gauss) {  // z = mu + exp(lv/2) eps -> the next layer's operand image; KL_i -> the row's loss
+    if (GG(ly.gauss)) {  // z = mu + exp(lv/2) eps -> the next layer's operand image; KL_i -> the row's loss
       chain_barrier();
       // one (batch row, latent dimension) per thread (latent <= 32 = 1,024 / 32): the draw of eps -- a hash, a logarithm,
       // a cosine -- was a serial loop over the latent dimensions in 32 threads (5 us of a 58-us step, forward + backward)
@@ -614,13 +627,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     }
     // (Columns the tiles did not cover, up to the next contraction's padded range, keep what they held: the weights of
     // those k-steps are zero, and every 16-bit value an image ever holds is finite -- see the one-time clear above.)
-    if (last && !st.out) {  // this lane's share of the row losses joins the other waves' behind the same barrier
+    if (last && !GO(st.out)) {  // this lane's share of the row losses joins the other waves' behind the same barrier
       lsum += __shfl_xor(lsum, 32, 64);
       if (lh == 0) red[wave][li] = lsum * rwl[li];
     }
     chain_barrier();
     CFINE(4 * l + 3);
-    if (ly.gauss && tid < 32) {
+    if (GG(ly.gauss) && tid < 32) {
       float kl = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) kl += red[w][tid];
@@ -630,14 +643,14 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     chain_stamp(a, 2 + l);
   }
 
-  if (LF < a.L || st.out) return;  // the encoder alone (joint step: its latents are in `zs`), or FORWARD mode
+  if (GJ(LF < a.L) || GO(st.out)) return;  // the encoder alone (joint step: its latents are in `zs`), or FORWARD mode
   // ---- loss: lanes -> rows (written before the last layer's barrier, above) -> workgroup (fixed order) -> one
   // fixed-point atomic per workgroup
   if (tid < 32) {
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) s += red[w][tid];
-    s += klb[tid];
+    if (FEAT & kChainGauss) s += klb[tid];
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (tid == 0) atomicAdd(a.loss_acc, (unsigned long long)(long long)llrint((double)s * 4294967296.0));
@@ -669,7 +682,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     const elem* act = buf[cur];
     elem* out = buf[cur ^ 1];
     const int nch = ly.NS >> 2;
-    if (ly.gauss) { gauss_backward(buf[cur], ly.N >> 1, ly.NS * 16); chain_barrier(); }
+    if (GG(ly.gauss)) { gauss_backward(buf[cur], ly.N >> 1, ly.NS * 16); chain_barrier(); }
     flush_t(act, ly.N, ly.dzt16, ly.KT);  // gs * dZ of this layer's output -> operand of its weight gradient
     for (int t = wave; t < ly.KT; t += NW) {
       const int k0 = 32 * t;
@@ -698,8 +711,11 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     cur ^= 1;
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
-  if (a.lt[0].gauss) { gauss_backward(buf[cur], a.lt[0].N >> 1, a.lt[0].NS * 16); chain_barrier(); }
+  if (GG(a.lt[0].gauss)) { gauss_backward(buf[cur], a.lt[0].N >> 1, a.lt[0].NS * 16); chain_barrier(); }
   flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
+#undef GG
+#undef GJ
+#undef GO
 }
 
 // ---- weight gradients from the fragment-ordered operands: [dW; db](k, n) = sum_b HT(k, b) dZT(n, b).

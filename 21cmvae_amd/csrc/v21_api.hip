@@ -1450,6 +1450,33 @@ static ChainStep chain_step(const float* x, long long ldx, const float* y, long 
   if (vae) st.sc = step_ctx(vae);
   return st;
 }
+// every instantiation of the 16-bit chain kernels (train_chain.h: FEAT) needs the dynamic-LDS attribute once per device
+template <class P>
+static int chain_attr_of() {
+  const void* fs[] = {(const void*)train_chain_kernel<P, 0>, (const void*)train_chain_kernel<P, kChainGauss>,
+                      (const void*)train_chain_kernel<P, kChainOut | kChainGauss>,
+                      (const void*)train_chain_group_kernel<P, false>, (const void*)train_chain_group_kernel<P, true>,
+                      (const void*)train_chain_joint_kernel<P, false>, (const void*)train_chain_joint_kernel<P, true>};
+  for (const void* f : fs) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+  return V21_OK;
+}
+static void launch_joint_kernel(int prec, bool gauss, dim3 grid, dim3 block, hipStream_t st, const ChainModel* tab, const ChainStep& sa,
+                                const ChainStep& sb) {
+  if (prec == V21_PREC_F16) {
+    if (gauss) hipLaunchKernelGGL((train_chain_joint_kernel<PrecF16, true>), grid, block, kChainLdsBytes, st, tab, sa, sb);
+    else hipLaunchKernelGGL((train_chain_joint_kernel<PrecF16, false>), grid, block, kChainLdsBytes, st, tab, sa, sb);
+  } else {
+    if (gauss) hipLaunchKernelGGL((train_chain_joint_kernel<PrecBF16, true>), grid, block, kChainLdsBytes, st, tab, sa, sb);
+    else hipLaunchKernelGGL((train_chain_joint_kernel<PrecBF16, false>), grid, block, kChainLdsBytes, st, tab, sa, sb);
+  }
+}
+// one model's chain launch: training / validation (FEAT 0 or kChainGauss) or FORWARD mode (kChainOut | kChainGauss)
+template <class P>
+static void launch_chain_kernel(int feat, dim3 grid, dim3 block, hipStream_t st, const ChainArgs& a) {
+  if (feat == 0) hipLaunchKernelGGL((train_chain_kernel<P, 0>), grid, block, kChainLdsBytes, st, a);
+  else if (feat == kChainGauss) hipLaunchKernelGGL((train_chain_kernel<P, kChainGauss>), grid, block, kChainLdsBytes, st, a);
+  else hipLaunchKernelGGL((train_chain_kernel<P, kChainOut | kChainGauss>), grid, block, kChainLdsBytes, st, a);
+}
 static int chain_attr(int prec) {
   static bool done_dev[64][3] = {};  // per (device, precision): function attributes are per device
   int dev = 0;
@@ -1460,13 +1487,9 @@ static int chain_attr(int prec) {
     HIPCHK(hipFuncSetAttribute((const void*)train_chain32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC32LdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain32s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC32sLdsBytes));
   } else if (prec == V21_PREC_F16) {
-    HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
-    HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
-    HIPCHK(hipFuncSetAttribute((const void*)train_chain_joint_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+    CHK(chain_attr_of<PrecF16>());
   } else {
-    HIPCHK(hipFuncSetAttribute((const void*)train_chain_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
-    HIPCHK(hipFuncSetAttribute((const void*)train_chain_group_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
-    HIPCHK(hipFuncSetAttribute((const void*)train_chain_joint_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
+    CHK(chain_attr_of<PrecBF16>());
   }
   done[prec] = true;
   return V21_OK;
@@ -1488,8 +1511,12 @@ static int launch_chain(v21_trainer* t, const float* x, long long ldx, const flo
   a.ncons = ((rows + 31) / 32 + 7) / 8 * 8;  // whole rounds of the 8 XCDs
   a.npref = chain_prefetchers(a.ncons, 1);
   const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
-  if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
-  else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, t->ctx->stream, a);
+  // (train_chain.h: FEAT -- a trainer's launch never needs the joint step's or FORWARD mode's code, and the variational
+  //  head's only when the stack has one; V21_CHAIN_PLAIN=0: everything through the variational instantiation)
+  static const bool plain_ok = !(getenv("V21_CHAIN_PLAIN") && getenv("V21_CHAIN_PLAIN")[0] == '0');
+  const int feat = plain_ok && t->gl < 0 ? 0 : kChainGauss;
+  if (t->prec == V21_PREC_F16) launch_chain_kernel<PrecF16>(feat, grid, block, t->ctx->stream, a);
+  else launch_chain_kernel<PrecBF16>(feat, grid, block, t->ctx->stream, a);
   HIPCHK(hipGetLastError());
   return V21_OK;
 }
@@ -1618,8 +1645,8 @@ static int forward_chain(v21_mlp* m, const float* d_x, long long ldx, long long 
   a.ncons = (int)(((n + 31) / 32 + 7) / 8 * 8);
   a.npref = chain_prefetchers(a.ncons, 1);
   const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
-  if (prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, st, a);
-  else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, a);
+  if (prec == V21_PREC_F16) launch_chain_kernel<PrecF16>(kChainOut | kChainGauss, grid, block, st, a);
+  else launch_chain_kernel<PrecBF16>(kChainOut | kChainGauss, grid, block, st, a);
   HIPCHK(hipGetLastError());
   return V21_OK;
 }
@@ -2163,8 +2190,9 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
     a.npref = chain_prefetchers(a.ncons, 1);
     CHK(chain_attr(t->prec));
     const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
-    if (t->prec == V21_PREC_F16) hipLaunchKernelGGL(train_chain_kernel<PrecF16>, grid, block, kChainLdsBytes, st, a);
-    else hipLaunchKernelGGL(train_chain_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, a);
+    const int feat = t->gl < 0 && !(getenv("V21_CHAIN_PLAIN") && getenv("V21_CHAIN_PLAIN")[0] == '0') ? 0 : kChainGauss;  // (see launch_chain)
+    if (t->prec == V21_PREC_F16) launch_chain_kernel<PrecF16>(feat, grid, block, st, a);
+    else launch_chain_kernel<PrecBF16>(feat, grid, block, st, a);
     HIPCHK(hipGetLastError());
     long long acc = 0;  // 2^-32 fixed point (order-independent sum over the workgroups)
     HIPCHK(hipMemcpyAsync(&acc, t->d_ticket, sizeof acc, hipMemcpyDeviceToHost, st));
@@ -2476,10 +2504,15 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long l
     csp.ncons = ((rows + 31) / 32 + 7) / 8 * 8;
     csp.npref = chain_prefetchers(csp.ncons, G);
     const dim3 grid(csp.ncons + 8 * csp.npref, G), block(64 * kChainWaves);
-    if (t0->prec == V21_PREC_F16)
-      hipLaunchKernelGGL(train_chain_group_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
-    else
-      hipLaunchKernelGGL(train_chain_group_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
+    bool gauss = false;  // (train_chain.h: FEAT)
+    for (v21_trainer* t : s->tr) gauss = gauss || t->gl >= 0;
+    if (t0->prec == V21_PREC_F16) {
+      if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, true>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
+      else hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, false>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
+    } else {
+      if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, true>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
+      else hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, false>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
+    }
     HIPCHK(hipGetLastError());
     if (s->ctx->nranks == 1)  // nothing to exchange: all gradients, all Adam updates, all packed copies in one launch
       return launch_dw_adam_group(s->tr, s->d_dwadam, s->h_dwadam, rows, brows, step_index, st);
@@ -2708,10 +2741,7 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
       sb.blk0 = sa.ncons;                   // the emulator's row blocks follow the autoencoder's in the grid
       sa.npref = sb.npref = chain_prefetchers(2 * sa.ncons, 1);
       const dim3 grid(2 * sa.ncons + 8 * sa.npref), block(64 * kChainWaves);
-      if (ta->prec == V21_PREC_F16)
-        hipLaunchKernelGGL(train_chain_joint_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
-      else
-        hipLaunchKernelGGL(train_chain_joint_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+      launch_joint_kernel(ta->prec, ta->gl >= 0, grid, block, st, (const ChainModel*)j->d_tab, sa, sb);
       HIPCHK(hipGetLastError());
     }
     if (R == 1) {
@@ -2788,10 +2818,7 @@ extern "C" int v21_joint_eval(v21_joint* j, double* losses) {
   sb.blk0 = sa.ncons;
   sa.npref = sb.npref = chain_prefetchers(2 * sa.ncons, 1);
   const dim3 grid(2 * sa.ncons + 8 * sa.npref), block(64 * kChainWaves);
-  if (ta->prec == V21_PREC_F16)
-    hipLaunchKernelGGL(train_chain_joint_kernel<PrecF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
-  else
-    hipLaunchKernelGGL(train_chain_joint_kernel<PrecBF16>, grid, block, kChainLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+  launch_joint_kernel(ta->prec, ta->gl >= 0, grid, block, st, (const ChainModel*)j->d_tab, sa, sb);
   HIPCHK(hipGetLastError());
   long long acc[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(&acc[0], ta->d_ticket, sizeof(long long), hipMemcpyDeviceToHost, st));
