@@ -138,7 +138,7 @@ __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
 #define CFINE(i)
 #endif
 // FEAT: which features of the general body an instantiation carries (see train_chain_body)
-constexpr int kChainGauss = 1, kChainJoint = 2, kChainOut = 4, kChainAll = 7;
+constexpr int kChainGauss = 1, kChainJoint = 2, kChainOut = 4, kChainAll = 7, kChainFwd = 8;  // (kChainFwd REMOVES code: no backward pass)
 template <class P, int FEAT = kChainAll>
 __device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st);
 
@@ -219,7 +219,8 @@ __device__ __forceinline__ chain_s4 chain_tr_read(const void* p) {
 
 // FEAT: the features this instantiation carries -- kChainGauss: a variational layer (sampling, KL, its backward);
 // kChainJoint: the joint step's captured latents, targets from LDS, encoder-only passes, shifted block numbers;
-// kChainOut: FORWARD mode (outputs to global memory, fused parameter transform; no loss, no backward pass).  The flag set is
+// kChainOut: FORWARD mode (outputs to global memory, fused parameter transform; no loss, no backward pass); kChainFwd: the
+// launch is forward-only (validation, FORWARD mode: st.fwd_only is set) -- the backward pass is not compiled.  The flag set is
 // a promise of the host (which model, which launch), and it folds every branch on an absent feature away at compile time:
 // the general body (all three) sits at its 128 vector registers with 43 scalar registers spilled into lanes of one of
 // them and 5 vector registers in scratch; FEAT = 0 -- what a trainer of the reference's stacks launches -- has 15 and 0,
@@ -409,7 +410,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     // (A wave that has ENDED leaves the barrier count on gfx950 -- the loader waves of gemm_dw16_lds_kernel below rely
     //  on that when they return before the compute waves' last s_barrier.  Here nothing ends: this `return` leaves the
     //  lambda, and every wave of the workgroup goes on to the layer's barrier.)
-    if (wave < w0 || st.fwd_only) return;
+    if (wave < w0 || (FEAT & kChainFwd) || st.fwd_only) return;
     auto read_frag = [&](int id) __attribute__((always_inline)) -> chain_s8 {
       const int ft = id >> 1, q2 = id & 1;
       const int r0 = 16 * q2 + 8 * (g >> 1);
@@ -657,7 +658,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   }
 
   chain_stamp(a, 2 + a.L);
-  if (st.fwd_only) return;
+  if ((FEAT & kChainFwd) || st.fwd_only) return;
   // gs * dL/dz (latent wide, in `b`) -> gs * dL/d[mu | lv] in place:  d mu = dz + beta mu,
   // d lv = dz eps exp(lv/2)/2 + beta (exp lv - 1)/2, beta = kl_weight / B (the KL term's own gradient)
   auto gauss_backward = [&](elem* b, int LAT, int pad) __attribute__((always_inline)) {

@@ -1454,7 +1454,8 @@ static ChainStep chain_step(const float* x, long long ldx, const float* y, long 
 template <class P>
 static int chain_attr_of() {
   const void* fs[] = {(const void*)train_chain_kernel<P, 0>, (const void*)train_chain_kernel<P, kChainGauss>,
-                      (const void*)train_chain_kernel<P, kChainOut | kChainGauss>,
+                      (const void*)train_chain_kernel<P, kChainFwd>, (const void*)train_chain_kernel<P, kChainFwd | kChainGauss>,
+                      (const void*)train_chain_kernel<P, kChainFwd | kChainOut | kChainGauss>,
                       (const void*)train_chain_group_kernel<P, false>, (const void*)train_chain_group_kernel<P, true>,
                       (const void*)train_chain_joint_kernel<P, false>, (const void*)train_chain_joint_kernel<P, true>};
   for (const void* f : fs) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
@@ -1475,7 +1476,9 @@ template <class P>
 static void launch_chain_kernel(int feat, dim3 grid, dim3 block, hipStream_t st, const ChainArgs& a) {
   if (feat == 0) hipLaunchKernelGGL((train_chain_kernel<P, 0>), grid, block, kChainLdsBytes, st, a);
   else if (feat == kChainGauss) hipLaunchKernelGGL((train_chain_kernel<P, kChainGauss>), grid, block, kChainLdsBytes, st, a);
-  else hipLaunchKernelGGL((train_chain_kernel<P, kChainOut | kChainGauss>), grid, block, kChainLdsBytes, st, a);
+  else if (feat == kChainFwd) hipLaunchKernelGGL((train_chain_kernel<P, kChainFwd>), grid, block, kChainLdsBytes, st, a);
+  else if (feat == (kChainFwd | kChainGauss)) hipLaunchKernelGGL((train_chain_kernel<P, kChainFwd | kChainGauss>), grid, block, kChainLdsBytes, st, a);
+  else hipLaunchKernelGGL((train_chain_kernel<P, kChainFwd | kChainOut | kChainGauss>), grid, block, kChainLdsBytes, st, a);
 }
 static int chain_attr(int prec) {
   static bool done_dev[64][3] = {};  // per (device, precision): function attributes are per device
@@ -1645,8 +1648,8 @@ static int forward_chain(v21_mlp* m, const float* d_x, long long ldx, long long 
   a.ncons = (int)(((n + 31) / 32 + 7) / 8 * 8);
   a.npref = chain_prefetchers(a.ncons, 1);
   const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
-  if (prec == V21_PREC_F16) launch_chain_kernel<PrecF16>(kChainOut | kChainGauss, grid, block, st, a);
-  else launch_chain_kernel<PrecBF16>(kChainOut | kChainGauss, grid, block, st, a);
+  if (prec == V21_PREC_F16) launch_chain_kernel<PrecF16>(kChainFwd | kChainOut | kChainGauss, grid, block, st, a);
+  else launch_chain_kernel<PrecBF16>(kChainFwd | kChainOut | kChainGauss, grid, block, st, a);
   HIPCHK(hipGetLastError());
   return V21_OK;
 }
@@ -2190,7 +2193,7 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
     a.npref = chain_prefetchers(a.ncons, 1);
     CHK(chain_attr(t->prec));
     const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
-    const int feat = t->gl < 0 && !(getenv("V21_CHAIN_PLAIN") && getenv("V21_CHAIN_PLAIN")[0] == '0') ? 0 : kChainGauss;  // (see launch_chain)
+    const int feat = kChainFwd | (t->gl < 0 && !(getenv("V21_CHAIN_PLAIN") && getenv("V21_CHAIN_PLAIN")[0] == '0') ? 0 : kChainGauss);  // (see launch_chain)
     if (t->prec == V21_PREC_F16) launch_chain_kernel<PrecF16>(feat, grid, block, st, a);
     else launch_chain_kernel<PrecBF16>(feat, grid, block, st, a);
     HIPCHK(hipGetLastError());
