@@ -40,7 +40,12 @@ __host__ __device__ constexpr int chain32_frags(int d) { return 2 * (((d + 15) /
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// FEAT (train_chain.h): kChainOut = this instantiation carries FORWARD mode; kChainFwd = it is forward-only (no backward
+// pass compiled).  Training launches use 0, validation kChainFwd, Model.predict kChainOut | kChainFwd.
+template <int FEAT>
 __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const ChainStep& st) {
+#define GO(cond) ((FEAT & kChainOut) ? (bool)(cond) : false)
+#define FWD_ONLY ((FEAT & kChainFwd) ? true : (bool)st.fwd_only)
   constexpr int NW = kC32Waves, ROWS = kC32Rows, PITCH = kC32Pitch;
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   float(*buf)[ROWS * PITCH] = reinterpret_cast<float(*)[ROWS * PITCH]>(chain_smem);
@@ -84,7 +89,7 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     return Job{bw + ly.bw_off + ((long long)u * ly.NS) * 64 + lane, a.w, 0};
   };
   auto bwd_from = [&](int l) __attribute__((always_inline)) -> Job {
-    if (!st.fwd_only)
+    if (!FWD_ONLY)
       for (; l >= 1; --l)
         if (wave < bwd_units(l)) return bwd_job(l, wave);
     return Job{fw + lane, a.w, 0};  // nothing left: any valid address (the data is never used)
@@ -131,7 +136,7 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     for (int i = 0; i < 8; ++i) {
       const int k = lane + 64 * i;
       float t = xs[k < K0 ? k : K0 - 1];
-      if (i == 0 && st.tin) {  // par_transform on the (<= 8) input columns, as affine_in_kernel does it
+      if (i == 0 && GO(st.tin)) {  // par_transform on the (<= 8) input columns, as affine_in_kernel does it
         const int jc = lane < K0 ? lane : 0;
         const float zf = st.tin->zero_floor[jc];
         if (zf > 0.f && t == 0.f) t = zf;
@@ -144,9 +149,9 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     for (int i = 0; i < 8; ++i) {
       const int k = lane + 64 * i;  // <= 511 < PITCH
       buf[0][wave * PITCH + k] = v[i];
-      if (!st.y && !st.out) ystg[wave * PITCH + k] = v[i];
+      if (!st.y && !GO(st.out)) ystg[wave * PITCH + k] = v[i];
     }
-    if (st.y && !st.out) {
+    if (st.y && !GO(st.out)) {
       const int ymax = mq < st.rows ? DO : 0;
       const float* ys = st.y + srow * st.ldy;
 #pragma unroll
@@ -175,7 +180,7 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     const int ngrp = (F + 15) >> 4;
     float* d = reinterpret_cast<float*>(dst);
     const int w0 = tiles < NW ? tiles : 0;
-    if (wave < w0 || st.fwd_only) return;
+    if (wave < w0 || FWD_ONLY) return;
     const int fq = lane >> 2, r4 = 4 * (lane & 3);
     for (int id = wave - w0; id < ngrp; id += NW - w0) {
       const int f = 16 * id + fq;
@@ -284,7 +289,7 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
           *reinterpret_cast<f32x4*>(out + m * PITCH + n0 + 16 * s + 4 * kq) = acc[s];
         }
         if (ly.relu && ly.mask_tile >= 0) masks[ly.mask_tile + t][lane] = (unsigned short)bits;
-      } else if (st.out) {
+      } else if (GO(st.out)) {
         // FORWARD mode: z * out_std + out_mean straight from the accumulators: a row's 64 consecutive bytes per MFMA tile
         typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
@@ -344,7 +349,7 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
         finish(0, acc);
       }
     }
-    if (last && !st.out) {  // this lane's share of the row losses (lanes m, m + 16, m + 32, m + 48 hold one row)
+    if (last && !GO(st.out)) {  // this lane's share of the row losses (lanes m, m + 16, m + 32, m + 48 hold one row)
       lsum += __shfl_xor(lsum, 16, 64);
       lsum += __shfl_xor(lsum, 32, 64);
       if (kq == 0) red[wave][m] = lsum * rwl[m];
@@ -353,7 +358,7 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     cur ^= 1;
     chain_stamp(a, 2 + l);
   }
-  if (st.out) return;
+  if (GO(st.out)) return;
 
   // ---- loss: lanes -> rows -> workgroup (fixed order) -> one fixed-point atomic per workgroup
   if (tid < ROWS) {
@@ -365,7 +370,7 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     if (tid == 0) atomicAdd(a.loss_acc, (unsigned long long)(long long)llrint((double)s * 4294967296.0));
   }
   chain_stamp(a, 2 + a.L);
-  if (st.fwd_only) return;
+  if (FWD_ONLY) return;
 
   // ---- backward: layer l consumes dZ_l (in buf[cur]) and produces dZ_{l-1}
   for (int l = a.L - 1; l >= 1; --l) {
@@ -416,11 +421,14 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
   flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
+#undef GO
+#undef FWD_ONLY
 }
 
+template <int FEAT>
 __global__ void __launch_bounds__(64 * kC32Waves) train_chain32_kernel(const ChainArgs a) {
   if ((int)blockIdx.x >= a.ncons) { chain_prefetch(a, a); return; }
-  train_chain32_body(a, a);
+  train_chain32_body<FEAT>(a, a);
 }
 // once per step on a data-parallel rank (the loss numerator must ride in the gradient arena BEFORE the exchange);
 // a single rank lets the Adam kernel do it

@@ -1487,7 +1487,8 @@ static int chain_attr(int prec) {
   bool* done = done_dev[dev & 63];
   if (done[prec]) return V21_OK;
   if (prec == V21_PREC_F32) {
-    HIPCHK(hipFuncSetAttribute((const void*)train_chain32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC32LdsBytes));
+    for (const void* f : {(const void*)train_chain32_kernel<0>, (const void*)train_chain32_kernel<kChainFwd>, (const void*)train_chain32_kernel<kChainFwd | kChainOut>})
+      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kC32LdsBytes));
     HIPCHK(hipFuncSetAttribute((const void*)train_chain32s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC32sLdsBytes));
   } else if (prec == V21_PREC_F16) {
     CHK(chain_attr_of<PrecF16>());
@@ -1574,7 +1575,10 @@ static int launch_chain32_args(ChainArgs& a, hipStream_t st, bool small = false)
   a.ncons = (int)((((long long)a.rows + kC32Rows - 1) / kC32Rows + 7) / 8 * 8);  // whole rounds of the 8 XCDs
   a.npref = chain_prefetchers(a.ncons, 1);
   const dim3 grid(a.ncons + 8 * a.npref), block(64 * kC32Waves);
-  hipLaunchKernelGGL(train_chain32_kernel, grid, block, kC32LdsBytes, st, a);
+  // (train_chain32.h: FEAT -- FORWARD mode, validation, training)
+  if (a.out) hipLaunchKernelGGL((train_chain32_kernel<kChainFwd | kChainOut>), grid, block, kC32LdsBytes, st, a);
+  else if (a.fwd_only) hipLaunchKernelGGL((train_chain32_kernel<kChainFwd>), grid, block, kC32LdsBytes, st, a);
+  else hipLaunchKernelGGL((train_chain32_kernel<0>), grid, block, kC32LdsBytes, st, a);
   HIPCHK(hipGetLastError());
   return V21_OK;
 }
