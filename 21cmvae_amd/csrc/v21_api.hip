@@ -2197,7 +2197,8 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
     a.npref = chain_prefetchers(a.ncons, 1);
     CHK(chain_attr(t->prec));
     const dim3 grid(a.ncons + 8 * a.npref), block(64 * kChainWaves);
-    const int feat = kChainFwd | (t->gl < 0 && !(getenv("V21_CHAIN_PLAIN") && getenv("V21_CHAIN_PLAIN")[0] == '0') ? 0 : kChainGauss);  // (see launch_chain)
+    static const bool plain_ok = !(getenv("V21_CHAIN_PLAIN") && getenv("V21_CHAIN_PLAIN")[0] == '0');  // (see launch_chain)
+    const int feat = kChainFwd | (t->gl < 0 && plain_ok ? 0 : kChainGauss);
     if (t->prec == V21_PREC_F16) launch_chain_kernel<PrecF16>(feat, grid, block, st, a);
     else launch_chain_kernel<PrecBF16>(feat, grid, block, st, a);
     HIPCHK(hipGetLastError());
