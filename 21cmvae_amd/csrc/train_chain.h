@@ -403,7 +403,6 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // yields: they then all end at ~10 k where the oldest ended at 5 k and the youngest at 9.4 k; the layer's weights pass
   // the CU's load path at ~38 B/clk either way.)
   auto flush_t = [&](const elem* act, int F, void* dst, int tiles) __attribute__((always_inline)) {
-    const int nfrag = 2 * ((F + 31) >> 5);
     frag* d = reinterpret_cast<frag*>(dst);
     const int g = lane >> 4, i = lane & 15;
     const int w0 = tiles < NW ? tiles : 0;  // waves [0, w0) have a tile (every wave has one: all of them flush)
@@ -411,32 +410,33 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     //  on that when they return before the compute waves' last s_barrier.  Here nothing ends: this `return` leaves the
     //  lambda, and every wave of the workgroup goes on to the layer's barrier.)
     if (wave < w0 || (FEAT & kChainFwd) || st.fwd_only) return;
-    auto read_frag = [&](int id) __attribute__((always_inline)) -> chain_s8 {
-      const int ft = id >> 1, q2 = id & 1;
-      const int r0 = 16 * q2 + 8 * (g >> 1);
-      const elem* p = act + (r0 + (i >> 2)) * PITCH + 32 * ft + 16 * (g & 1) + 4 * (i & 3);
-      const chain_s4 lo = chain_tr_read(p), hi = chain_tr_read(p + 4 * PITCH);
-      return chain_s8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    };
-    auto write_frag = [&](int id, chain_s8 v) __attribute__((always_inline)) {
-      const int ft = id >> 1, q2 = id & 1;
-      const int r0 = 16 * q2 + 8 * (g >> 1);
+    // A flushing wave takes whole feature tiles (both 16-row halves of a tile: the two fragments of a turn), ft = its
+    // number among the flushing waves, + their count, ...: the LDS and global addresses then advance by constants (the
+    // first cut worked every fragment's address out from its number: a 64-bit product and ~40 scalar instructions per
+    // fragment, 880 for the lone flushing wave of a 15-tile layer).
+    const int nfl = NW - w0, ntile = (F + 31) >> 5;
+    const int r0 = 8 * (g >> 1);  // (+ 16 for the second half)
+    const elem* p = act + (r0 + (i >> 2)) * PITCH + 16 * (g & 1) + 4 * (i & 3) + 32 * (wave - w0);
+    frag* q = d + ((long long)(wave - w0) * a.BS + (m0 >> 4)) * 64 + lane;
+    const long long qstep = (long long)nfl * a.BS * 64;
+    __builtin_amdgcn_s_setprio(3);  // (the waves without a tile are the YOUNGEST of the workgroup: see above)
+    for (int ft = wave - w0; ft < ntile; ft += nfl, p += 32 * nfl, q += qstep) {
+      const chain_s4 lo0 = chain_tr_read(p), hi0 = chain_tr_read(p + 4 * PITCH);
+      const chain_s4 lo1 = chain_tr_read(p + 16 * PITCH), hi1 = chain_tr_read(p + 20 * PITCH);
+      chain_s8 v0 = {lo0[0], lo0[1], lo0[2], lo0[3], hi0[0], hi0[1], hi0[2], hi0[3]};
+      chain_s8 v1 = {lo1[0], lo1[1], lo1[2], lo1[3], hi1[0], hi1[1], hi1[2], hi1[3]};
       if (vrows < 32) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (r0 + j >= vrows) v[j] = 0;
+        for (int j = 0; j < 8; ++j) {
+          if (r0 + j >= vrows) v0[j] = 0;
+          if (16 + r0 + j >= vrows) v1[j] = 0;
+        }
       }
-      if (32 * ft + (lane & 31) < F)
-        d[((long long)ft * a.BS + (m0 >> 4) + q2) * 64 + lane] = __builtin_bit_cast(frag, v);
-    };
-    const int nfl = NW - w0;
-    int id = wave - w0;
-    __builtin_amdgcn_s_setprio(3);  // (the waves without a tile are the YOUNGEST of the workgroup: see above)
-    for (; id + nfl < nfrag; id += 2 * nfl) {
-      const chain_s8 v0 = read_frag(id), v1 = read_frag(id + nfl);
-      write_frag(id, v0); write_frag(id + nfl, v1);
+      if (32 * ft + (lane & 31) < F) {
+        q[0] = __builtin_bit_cast(frag, v0);
+        q[64] = __builtin_bit_cast(frag, v1);
+      }
     }
-    if (id < nfrag) write_frag(id, read_frag(id));
     __builtin_amdgcn_s_setprio(0);
   };
 
