@@ -467,7 +467,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-batch", type=int, default=4096)
-    ap.add_argument("--train-steps", type=int, default=40)
+    ap.add_argument("--train-steps", type=int, default=200,
+                    help="timed optimizer steps of the training legs (40 until r3: the one host sync at the end was ~1 us per step of a 45-us step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -719,7 +720,7 @@ def main():
                         transport = "host-staged over the process group (in-library RCCL failed on some rank: %s)" % (err,)
                         par.init_engine_comm(ctx, backend="host")
                 tl = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
-                               args.train_batch, args.precision, args.train_steps, 5)
+                               args.train_batch, args.precision, args.train_steps, 20)
                 tl["transport"] = transport
                 ae_params = sum(k * n + n for k, n in zip(AE_DIMS[:-1], AE_DIMS[1:]))
                 tl["roofline"] = train_roofline(tl, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
@@ -729,7 +730,7 @@ def main():
                 if world > 1:  # the other exchange: reduce-scatter -> Adam on each rank's slice -> all-gather
                     ctx.comm_set_sharded(True)
                     ts = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
-                                   args.train_batch, args.precision, args.train_steps, 5)
+                                   args.train_batch, args.precision, args.train_steps, 20)
                     ts["collective"] = "reduce-scatter + all-gather, Adam on 1/%d of the arena per rank" % world
                     ts["transport"] = transport
                     out["train_sharded_adam"] = ts
@@ -741,13 +742,13 @@ def main():
                     out["train_ref_batch256_f32"] = t32
                     # does the step scale with the batch?  (the MFMA fraction must RISE with the batch)
                     t16k = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier, sync_all, 16384,
-                                     args.precision, max(10, args.train_steps // 2), 5)
+                                     args.precision, max(10, args.train_steps // 2), 10)
                     t16k["roofline"] = train_roofline(t16k, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
                                                       "kernel_stats_train_b16384_%s.csv" % args.precision,
                                                       "pmc_train_b16384_%s.json" % args.precision)
                     out["train_b16384"] = t16k
                     out["train_variational"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
-                                                         sync_all, args.train_batch, args.precision, args.train_steps, 5,
+                                                         sync_all, args.train_batch, args.precision, args.train_steps, 20,
                                                          variational=True)
             except Exception as e:  # the headline metric must survive a failure of the auxiliary leg
                 out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
