@@ -297,6 +297,13 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   const int mq = m0 + RPW * wave + (lane & (RPW - 1));
   long long srow = mq < st.rows ? first + mq : first + m0;  // clamped: always a valid position
   if (st.idx) srow = st.idx[srow];
+  // (r3, measured and dropped: THREE chunk buffers in rotation -- two chunks of a tile in flight while the third feeds the
+  // MFMAs, the registers taken from the activation operands (a ring of four fragments read three k-steps ahead instead of
+  // two sets of four) -- with the contraction instantiated for the three rotation phases, so that no registers move.
+  // Correct, and 2-3x slower: which buffer holds the next tile's first chunk across an epilogue depends on the tile's
+  // chunk count modulo 3, so all 48 registers stay live there, and 300-700 vector registers go to scratch in the hot
+  // paths: 103-146 us per step.  A deeper weight prefetch needs a kernel with fewer than 16 waves, or tiles whose chunk
+  // counts are multiples of three.)
   frag wa[4], wb[4];  // chunk in use / chunk in flight (the roles alternate)
   float bnext;        // bias values of the wave's next forward tile (in flight with its first chunk)
   {
