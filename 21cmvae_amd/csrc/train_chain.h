@@ -132,6 +132,21 @@ __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
   }
 }
 
+// diagnostic builds (wrong results): the kernel without its weight loads / without its MFMAs.  r3, autoencoder stack, 4,096
+// rows, cycles of workgroup 0 (scripts/train_probe.py): whole kernel 51.5 k; without the weight loads 38.9 k; without
+// loads AND MFMAs 33.6 k -- the gather (6.2 k), the activation operands read from LDS by every wave for its tile (32 KB
+// per wave and layer), flush, epilogues and barriers are two thirds of the kernel; with the loads but without MFMAs 60.9 k:
+// a chunk then has no matrix work to hide behind and a wave pays ~1.5 k cycles per chunk, eight chunks per big layer.
+#ifdef V21_C16_NOLOAD
+#define C16LOAD(dst, src) asm volatile("" : "+v"(dst))
+#else
+#define C16LOAD(dst, src) dst = src
+#endif
+#ifdef V21_C16_NOMFMA
+#define C16MFMA(w, b) do { const f32x4 w4_ = __builtin_bit_cast(f32x4, w), b4_ = __builtin_bit_cast(f32x4, b); asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[0]) : "v"(w4_[0]), "v"(b4_[0])); } while (0)
+#else
+#define C16MFMA(w, b) acc = P::template mfma<false>(w, b, acc)
+#endif
 #ifdef V21_CHAIN_FINE  // (diagnostic build: per-wave stamps of workgroup 0, scripts/diag/chain_wave_stamps.py)
 #define CFINE(i) do { if (blockIdx.x == 0 && lane == 0 && a.stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); a.stamps[64 + (i) * 16 + wave] = t_; } } while (0)
 #else
@@ -462,7 +477,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       {
         const frag* p = wsrc + (long long)(4 * (c + 1)) * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wb[j] = p[j * 64];
+        for (int j = 0; j < 4; ++j) C16LOAD(wb[j], p[j * 64]);
       }
       // (without the fence hipcc hoists the first MFMA -- and with it the wait for the CURRENT chunk -- above these
       // loads: the next chunk would leave only after this one has landed, and the prefetch distance collapses)
@@ -470,11 +485,11 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
 #pragma unroll
       for (int j = 0; j < 4; ++j) bn[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 1) + j) * 16);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = P::template mfma<false>(wa[j], bc[j], acc);
+      for (int j = 0; j < 4; ++j) C16MFMA(wa[j], bc[j]);
       {
         const frag* p = c + 2 < nch ? wsrc + (long long)(4 * (c + 2)) * 64 : nxt.w;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wa[j] = p[j * 64];
+        for (int j = 0; j < 4; ++j) C16LOAD(wa[j], p[j * 64]);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (c + 2 < nch) {
@@ -482,14 +497,14 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
         for (int j = 0; j < 4; ++j) bc[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 2) + j) * 16);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = P::template mfma<false>(wb[j], bn[j], acc);
+      for (int j = 0; j < 4; ++j) C16MFMA(wb[j], bn[j]);
     }
     if (c < nch) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wb[j] = nxt.w[j * 64];
+      for (int j = 0; j < 4; ++j) C16LOAD(wb[j], nxt.w[j * 64]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = P::template mfma<false>(wa[j], bc[j], acc);
+      for (int j = 0; j < 4; ++j) C16MFMA(wa[j], bc[j]);
       return true;
     }
     return false;
