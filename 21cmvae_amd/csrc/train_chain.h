@@ -317,8 +317,11 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // two sets of four) -- with the contraction instantiated for the three rotation phases, so that no registers move.
   // Correct, and 2-3x slower: which buffer holds the next tile's first chunk across an epilogue depends on the tile's
   // chunk count modulo 3, so all 48 registers stay live there, and 300-700 vector registers go to scratch in the hot
-  // paths: 103-146 us per step.  A deeper weight prefetch needs a kernel with fewer than 16 waves, or tiles whose chunk
-  // counts are multiples of three.)
+  // paths: 103-146 us per step.  With EIGHT waves of up to 256 registers (kChainWaves = 8: each wave takes two tiles of
+  // a big layer one after the other) the same ring compiles to 255 registers, nothing spilled -- and is no faster: the big
+  // layers take 10.3 / 11.4 / 8.5 k cycles against 9.7 / 9.8 / 8.0 k, the small ones more (every tile padded to two
+  // chunks): 48.3 against 44.3 us per step.  Eight waves with the two-buffer scheme: 45.2 us -- half the waves, twice the
+  // tiles each, the same time per layer.  The chunk round trips are not what a big layer waits for.)
   frag wa[4], wb[4];  // chunk in use / chunk in flight (the roles alternate)
   float bnext;        // bias values of the wave's next forward tile (in flight with its first chunk)
   {
