@@ -68,6 +68,7 @@ V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so V21_DW32_LDS=0 $PY scripts/diag/dwadam_
 V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/dwadam_stamps.py 4096 f16 > $OUT/phase_stamps_dw16_adam_b4096_f16.txt 2>&1
 [ -x scripts/diag/l1_stream_probe ] && scripts/diag/l1_stream_probe > $OUT/l1_stream_probe.txt 2>&1
 [ -x scripts/diag/mfma4_rate_probe ] && scripts/diag/mfma4_rate_probe > $OUT/mfma4_rate_probe.txt 2>&1
+[ -x scripts/diag/cold_stream_probe ] && scripts/diag/cold_stream_probe > $OUT/cold_stream_probe.txt 2>&1
 rm -rf $OUT/t256r16
 rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t4096 $OUT/t256 $OUT/t256h $OUT/t16k $OUT/tpmc_* $OUT/sq_* $OUT/fwd $OUT/joint
 ls -la $OUT
