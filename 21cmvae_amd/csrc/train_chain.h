@@ -137,10 +137,17 @@ __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
 // loads AND MFMAs 33.6 k -- the gather (6.2 k), the activation operands read from LDS by every wave for its tile (32 KB
 // per wave and layer), flush, epilogues and barriers are two thirds of the kernel; with the loads but without MFMAs 60.9 k:
 // a chunk then has no matrix work to hide behind and a wave pays ~1.5 k cycles per chunk, eight chunks per big layer.
+// Without the operand reads as well (-DV21_C16_NOLDS): 32.4 k -- a layer with no contraction at all still takes 2 k cycles
+// (bias permutes, epilogue, search for the next tile, barrier), 4.4-4.9 k where few waves carry the flush.
 #ifdef V21_C16_NOLOAD
 #define C16LOAD(dst, src) asm volatile("" : "+v"(dst))
 #else
 #define C16LOAD(dst, src) dst = src
+#endif
+#ifdef V21_C16_NOLDS
+#define C16LDS(dst, src) asm volatile("" : "+v"(dst))
+#else
+#define C16LDS(dst, src) dst = src
 #endif
 #ifdef V21_C16_NOMFMA
 #define C16MFMA(w, b) do { const f32x4 w4_ = __builtin_bit_cast(f32x4, w), b4_ = __builtin_bit_cast(f32x4, b); asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[0]) : "v"(w4_[0]), "v"(b4_[0])); } while (0)
@@ -486,7 +493,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       // loads: the next chunk would leave only after this one has landed, and the prefetch distance collapses)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bn[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 1) + j) * 16);
+      for (int j = 0; j < 4; ++j) C16LDS(bn[j], *reinterpret_cast<const frag*>(ap + (4 * (c + 1) + j) * 16));
 #pragma unroll
       for (int j = 0; j < 4; ++j) C16MFMA(wa[j], bc[j]);
       {
@@ -497,7 +504,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
       __builtin_amdgcn_sched_barrier(0);
       if (c + 2 < nch) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bc[j] = *reinterpret_cast<const frag*>(ap + (4 * (c + 2) + j) * 16);
+        for (int j = 0; j < 4; ++j) C16LDS(bc[j], *reinterpret_cast<const frag*>(ap + (4 * (c + 2) + j) * 16));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) C16MFMA(wb[j], bn[j]);
