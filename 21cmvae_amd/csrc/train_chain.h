@@ -479,6 +479,10 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   auto contract = [&](const frag* wsrc, const elem* act, int nch, f32x16& acc, const Job nxt) __attribute__((always_inline)) -> bool {
     const elem* ap = act + li * PITCH + 8 * lh;
     bnext = nxt.bok ? *nxt.b : 0.f;  // (the caller has consumed this tile's values; issued first: it returns first)
+    // (r3, measured and dropped: TWO accumulators, even and odd k-steps.  In isolation -- scripts/diag/chain_loop_probe.hip:
+    // this loop alone, one workgroup of 16 waves on a warm L2 -- four dependent MFMAs per chunk hold the stream at 47-49
+    // B/clk where two accumulators reach the bare stream's 55-56; in the kernel the step went from 44.0 to 45.0 us, with
+    // the registers for it taken from the activation operands (a ring of four fragments, three k-steps ahead) 45.5.)
     frag bc[4], bn[4];  // activation fragments of the next chunk are read from LDS under the MFMAs of this one
 #pragma unroll
     for (int j = 0; j < 4; ++j) bc[j] = *reinterpret_cast<const frag*>(ap + j * 16);
