@@ -483,6 +483,11 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
     // this loop alone, one workgroup of 16 waves on a warm L2 -- four dependent MFMAs per chunk hold the stream at 47-49
     // B/clk where two accumulators reach the bare stream's 55-56; in the kernel the step went from 44.0 to 45.0 us, with
     // the registers for it taken from the activation operands (a ring of four fragments, three k-steps ahead) 45.5.)
+    // (r3, also measured and dropped: the next tile's SECOND chunk requested before the layer's barrier too -- after a
+    // barrier every wave starts with an empty pipeline, and the probe with a barrier and an epilogue per tile gains 8-9 %
+    // from it (45.7 -> 49.9 B/clk).  In the kernel the second chunk's buffer is then sometimes filled already when a tile
+    // starts, the first load of the loop becomes conditional, and behind that branch hipcc drains vmcnt(0) before the
+    // tile's first MFMAs: 55.6 us per step.  Unconditional, it needs every tile to have an even number >= 2 of chunks.)
     frag bc[4], bn[4];  // activation fragments of the next chunk are read from LDS under the MFMAs of this one
 #pragma unroll
     for (int j = 0; j < 4; ++j) bc[j] = *reinterpret_cast<const frag*>(ap + j * 16);

@@ -69,6 +69,7 @@ V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/dwadam_stamps.py 4096 
 [ -x scripts/diag/l1_stream_probe ] && scripts/diag/l1_stream_probe > $OUT/l1_stream_probe.txt 2>&1
 [ -x scripts/diag/mfma4_rate_probe ] && scripts/diag/mfma4_rate_probe > $OUT/mfma4_rate_probe.txt 2>&1
 [ -x scripts/diag/cold_stream_probe ] && scripts/diag/cold_stream_probe > $OUT/cold_stream_probe.txt 2>&1
+[ -x scripts/diag/chain_loop_probe ] && scripts/diag/chain_loop_probe > $OUT/chain_loop_probe.txt 2>&1
 rm -rf $OUT/t256r16
 rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t4096 $OUT/t256 $OUT/t256h $OUT/t16k $OUT/tpmc_* $OUT/sq_* $OUT/fwd $OUT/joint
 ls -la $OUT
