@@ -44,6 +44,11 @@ namespace v21 {
 #endif
 
 constexpr int kC32sRows = 8;
+// Steps of up to this many rows take the 4-row form (<= 256 workgroups: one round of the chip).  Batch 256 on the
+// autoencoder stack: 79.4 k -> 63.1 k cycles (the big layers 18-19 k -> 14-15 k each: what the stream alone needs with
+// one chunk of prefetch), step 49.9 -> 43.3 us; 512 rows 56.5 -> 51.3; 1,024 rows 70.5 -> 69.2; 2,048 rows (two rounds
+// of workgroups) 90.0 -> 114.8: stays with 8 rows.
+constexpr int kC32sRows4Max = 1024;
 constexpr int kC32sWaves = 16;
 constexpr int kC32sMaxBatch = 2048;  // 256 workgroups: one round of the chip (2,048 rows: 92.8 us per step against the 16-row kernel's 106.8)
 constexpr int kC32sMaskTiles = 120;
@@ -151,8 +156,12 @@ inline void c32s_build_jobs(const ChainModel& a, C32sJob* tab) {
   }
 }
 
+// ROWS = 8: two groups of four rows share every weight word (two MFMAs per word); ROWS = 4: one group -- twice the
+// workgroups, half the matrix work in each, the same weight stream through each CU (the LDS carve-up stays the 8-row one).
+template <int ROWS>
 __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const ChainStep& st) {
-  constexpr int NW = kC32sWaves, ROWS = kC32sRows, PITCH = kC32Pitch;
+  static_assert(ROWS == 4 || ROWS == 8, "one or two groups of four rows");
+  constexpr int NW = kC32sWaves, PITCH = kC32Pitch, G = ROWS / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
   float(*buf)[ROWS * PITCH] = reinterpret_cast<float(*)[ROWS * PITCH]>(chain_smem);
   float* ystg = reinterpret_cast<float*>(chain_smem + kC32sBufBytes);
@@ -252,21 +261,22 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   C32sJob jnext = row(1);  // (collected by the barrier's wait, see the layer loop)
   chain_barrier();
   chain_stamp(a, 1);
-  float lsum[2] = {0.f, 0.f};
+  float lsum[G] = {};
   int cur = 0;
 
   // The 8 rows x F features in `act` -> the fp32 operand of the weight gradient (dst[f * BS + batch row], gemm_nt.h): a lane
   // takes one feature and four consecutive rows and stores them as one 16-byte word (32 features x 32 contiguous bytes per
   // instruction).  Done by the waves without a unit in the contraction that follows; rows past the batch are zeros.
   auto flush_t = [&](const float* act, int F, void* dst, int units) __attribute__((always_inline)) {
-    const int ngrp = (F + 31) >> 5;
+    constexpr int FPI = 64 / G;  // features per instruction
+    const int ngrp = (F + FPI - 1) / FPI;
     float* d = reinterpret_cast<float*>(dst);
     const int w0 = units < NW ? units : 0;
     if (wave < w0 || st.fwd_only) return;
-    const int fq = lane >> 1, r4 = 4 * (lane & 1);
+    const int fq = G == 2 ? lane >> 1 : lane, r4 = G == 2 ? 4 * (lane & 1) : 0;
     __builtin_amdgcn_s_setprio(3);  // (the waves without a unit are the youngest of the workgroup, and the SIMDs issue oldest first)
     for (int id = wave - w0; id < ngrp; id += NW - w0) {
-      const int f = 32 * id + fq;
+      const int f = FPI * id + fq;
       const int fc = f < F ? f : F - 1;
       f32x4 v;
 #pragma unroll
@@ -284,18 +294,20 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   // flight, roles alternate); the activation words of the next fragment are read under the 8 MFMAs of this one.
   // (Units padded to whole PAIRS of chunks, so that the two buffers never change roles and no register move waits for a
   // chunk in flight: measured slower -- +3 % of stream in the 451-wide layers, a zero chunk in the 9-wide one.)
-  auto contract = [&](const f32x4* wsrc, const float* act, int nch, f32x4 (&acc)[2], const Job nxt, int f0) __attribute__((always_inline)) -> bool {
+  auto contract = [&](const f32x4* wsrc, const float* act, int nch, f32x4 (&acc)[G], const Job nxt, int f0) __attribute__((always_inline)) -> bool {
     const float* ap = act + jr * PITCH + 4 * f0;
     load_bias(nxt, bnext);  // (the caller has consumed this unit's values)
-    f32x4 b0 = *reinterpret_cast<const f32x4*>(ap), b1 = *reinterpret_cast<const f32x4*>(ap + 4 * PITCH), n0v, n1v;
+    f32x4 bq[G], nq[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bq[g] = *reinterpret_cast<const f32x4*>(ap + 4 * g * PITCH);
     auto chunk = [&](f32x4 (&w)[4], int kc, bool more) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int fn = 4 * kc + j + 1;  // the next fragment of this unit (read ahead; past the unit: a harmless re-read)
 #ifndef V21_C32S_NOLDS
         if (j < 3 || more) {
-          n0v = *reinterpret_cast<const f32x4*>(ap + 4 * fn);
-          n1v = *reinterpret_cast<const f32x4*>(ap + 4 * PITCH + 4 * fn);
+#pragma unroll
+          for (int g = 0; g < G; ++g) nq[g] = *reinterpret_cast<const f32x4*>(ap + 4 * g * PITCH + 4 * fn);
         }
         // (the reads stay AHEAD of this fragment's MFMAs: left to itself the scheduler now and then sinks them to just
         // before their use, and the wait that follows exposes an LDS round trip per fragment -- 18.8 vs 21.5 k cycles per
@@ -303,16 +315,17 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifdef V21_C32S_NOMFMA  // (one VALU instruction per fragment keeps the loads alive)
-        asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[0][0]) : "v"(w[j][0]), "v"(b0[0]), "v"(b1[0]));
+        asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[0][0]) : "v"(w[j][0]), "v"(bq[0][0]), "v"(bq[G - 1][0]));
 #else
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[0] = mfma4(w[j][e], b0[e], acc[0]);
-          acc[1] = mfma4(w[j][e], b1[e], acc[1]);
+#pragma unroll
+          for (int g = 0; g < G; ++g) acc[g] = mfma4(w[j][e], bq[g][e], acc[g]);
         }
 #endif
 #ifndef V21_C32S_NOLDS
-        b0 = n0v; b1 = n1v;
+#pragma unroll
+        for (int g = 0; g < G; ++g) bq[g] = nq[g];
 #endif
       }
     };
@@ -348,17 +361,22 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
       for (int j = 0; j < 4; ++j) wa[j] = wb[j];
     }
   };
-  auto put_partial = [&](const f32x4 (&acc)[2]) __attribute__((always_inline)) {
+  auto put_partial = [&](const f32x4 (&acc)[G]) __attribute__((always_inline)) {
     f32x4* pb = part + (wave * 64 + lane) * 2;
-    pb[0] = acc[0]; pb[1] = acc[1];
-  };
-  auto sum_partials = [&](int n, f32x4 (&acc)[2]) __attribute__((always_inline)) {  // waves wave .. wave + n - 1, fixed order
-    const f32x4* pb = part + (wave * 64 + lane) * 2;
-    acc[0] = pb[0]; acc[1] = pb[1];
-    for (int w = 1; w < n; ++w) {
-      const f32x4 p0 = pb[w * 128], p1 = pb[w * 128 + 1];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { acc[0][r] += p0[r]; acc[1][r] += p1[r]; }
+    for (int g = 0; g < G; ++g) pb[g] = acc[g];
+  };
+  auto sum_partials = [&](int n, f32x4 (&acc)[G]) __attribute__((always_inline)) {  // waves wave .. wave + n - 1, fixed order
+    const f32x4* pb = part + (wave * 64 + lane) * 2;
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = pb[g];
+    for (int w = 1; w < n; ++w) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 p = pb[w * 128 + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[g][r] += p[r];
+      }
     }
   };
 
@@ -369,12 +387,12 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     float* out = buf[cur ^ 1];
     const C32sJob jb = jnext;
     const int parts = jb.parts, t = jb.t;
-    auto finish = [&](int t, f32x4 (&acc)[2]) __attribute__((always_inline)) {
+    auto finish = [&](int t, f32x4 (&acc)[G]) __attribute__((always_inline)) {
       const int n = 64 * t + 4 * blk;
       if (!last) {
         unsigned bits = 0;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < G; ++g) {
           if (jb.mask_tile >= 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -387,7 +405,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
         if (jb.mask_tile >= 0) masks[jb.mask_tile + t][lane] = (unsigned short)bits;
       } else {  // loss_i = w_i sum_j (p - y)^2,  dL/dp = scale w_i (p - y)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < G; ++g) {
           const float gsc = st.scale * rwl[4 * g + jr];
           const f32x4 yq = *reinterpret_cast<const f32x4*>(ystg + (4 * g + jr) * PITCH + n);
           f32x4 dd;
@@ -404,7 +422,9 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     FINE(4 * l);
     flush_t(act, jb.flush_f, (void*)(((unsigned long long)jb.flush_hi << 32) | jb.flush_lo), jb.units);  // this layer's input -> operand of its weight gradient
     if (jb.nch > 0) {
-      f32x4 acc[2] = {bnext, bnext};
+      f32x4 acc[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = bnext;
       FINE(4 * l + 1);
       const bool odd = contract(fw + jb.w_off + lane, act, jb.nch, acc, next_of(jb), jb.f0);
       if (parts == 1) finish(t, acc);
@@ -416,14 +436,14 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
       chain_barrier();
       FINE(4 * l + 3);
       if (jb.nch > 0 && jb.s == 0) {
-        f32x4 acc[2];
+        f32x4 acc[G];
         sum_partials(parts, acc);
         finish(t, acc);
       }
     }
     if (last) {  // this lane's share of the row losses (the 16 lanes with the same jr hold one row of each group)
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < G; ++g) {
         float v = lsum[g];
 #pragma unroll
         for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
@@ -445,7 +465,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
 #pragma unroll
     for (int w = 0; w < NW; ++w) sl += red[w][tid];
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) sl += __shfl_xor(sl, o, 64);
+    for (int o = ROWS / 2; o > 0; o >>= 1) sl += __shfl_xor(sl, o, 64);
     if (tid == 0) atomicAdd(a.loss_acc, (unsigned long long)(long long)llrint((double)sl * 4294967296.0));
   }
   chain_stamp(a, 2 + a.L);
@@ -457,11 +477,11 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     float* out = buf[cur ^ 1];
     const C32sJob jb = jnext;
     const int parts = jb.parts, t = jb.t;
-    auto finish = [&](int t, f32x4 (&acc)[2]) __attribute__((always_inline)) {
+    auto finish = [&](int t, f32x4 (&acc)[G]) __attribute__((always_inline)) {
       const int k = 64 * t + 4 * blk;
       const unsigned bits = jb.mask_tile >= 0 ? masks[jb.mask_tile + t][lane] : 0xFFu;
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = acc[g][r];
@@ -472,7 +492,9 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     };
     flush_t(act, jb.flush_f, (void*)(((unsigned long long)jb.flush_hi << 32) | jb.flush_lo), jb.units);  // dZ of this layer's output -> operand of its weight gradient
     if (jb.nch > 0) {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
       const bool odd = contract(bw + jb.w_off + lane, act, jb.nch, acc, next_of(jb), jb.f0);
       if (parts == 1) finish(t, acc);
       else put_partial(acc);
@@ -481,7 +503,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     if (parts > 1) {
       chain_barrier();
       if (jb.nch > 0 && jb.s == 0) {
-        f32x4 acc[2];
+        f32x4 acc[G];
         sum_partials(parts, acc);
         finish(t, acc);
       }
@@ -494,9 +516,10 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
 }
 
+template <int ROWS>
 __global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_kernel(const ChainArgs a) {
   if ((int)blockIdx.x >= a.ncons) { chain_prefetch(a, a); return; }
-  train_chain32s_body(a, a);
+  train_chain32s_body<ROWS>(a, a);
 }
 
 }  // namespace v21

@@ -1489,7 +1489,8 @@ static int chain_attr(int prec) {
   if (prec == V21_PREC_F32) {
     for (const void* f : {(const void*)train_chain32_kernel<0>, (const void*)train_chain32_kernel<kChainFwd>, (const void*)train_chain32_kernel<kChainFwd | kChainOut>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kC32LdsBytes));
-    HIPCHK(hipFuncSetAttribute((const void*)train_chain32s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC32sLdsBytes));
+    for (const void* f : {(const void*)train_chain32s_kernel<8>, (const void*)train_chain32s_kernel<4>})
+      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kC32sLdsBytes));
   } else if (prec == V21_PREC_F16) {
     CHK(chain_attr_of<PrecF16>());
   } else {
@@ -1565,10 +1566,14 @@ static int build_chain32s_jobs(v21_trainer* t) {
 }
 static int launch_chain32_args(ChainArgs& a, hipStream_t st, bool small = false) {
   CHK(chain_attr(V21_PREC_F32));
-  if (small) {  // the 8-row kernel (train_chain32s.h)
-    a.ncons = (int)((((long long)a.rows + kC32sRows - 1) / kC32sRows + 7) / 8 * 8);
+  if (small) {  // the 8-row kernel (train_chain32s.h), or its 4-row form
+    const char* er = getenv("V21_C32S_ROWS");  // (tests force either form on every case)
+    const int force_rows = er ? atoi(er) : 0;
+    const int rpw = force_rows == 4 || force_rows == 8 ? force_rows : (a.rows <= kC32sRows4Max ? 4 : 8);
+    a.ncons = (int)((((long long)a.rows + rpw - 1) / rpw + 7) / 8 * 8);
     a.npref = chain_prefetchers(a.ncons, 1);
-    hipLaunchKernelGGL(train_chain32s_kernel, dim3(a.ncons + 8 * a.npref), dim3(64 * kC32sWaves), kC32sLdsBytes, st, a);
+    if (rpw == 4) hipLaunchKernelGGL(train_chain32s_kernel<4>, dim3(a.ncons + 8 * a.npref), dim3(64 * kC32sWaves), kC32sLdsBytes, st, a);
+    else hipLaunchKernelGGL(train_chain32s_kernel<8>, dim3(a.ncons + 8 * a.npref), dim3(64 * kC32sWaves), kC32sLdsBytes, st, a);
     HIPCHK(hipGetLastError());
     return V21_OK;
   }

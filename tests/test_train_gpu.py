@@ -567,7 +567,7 @@ def test_one_launch_gradient_adam_kernel_state_and_packed_copies(ctx, prec, dims
         ostate.m[:] = m; ostate.v[:] = v
 
 
-@pytest.mark.parametrize("rows", ["rows16", "rows8"])
+@pytest.mark.parametrize("rows", ["rows16", "rows8", "rows4"])
 @pytest.mark.parametrize("case", ["autoencoder_ragged", "direct_7_to_451", "latent_emulator", "batch_4096", "single_row"])
 def test_f32_chain_kernel_matches_per_layer_path_and_oracle(ctx, case, rows, monkeypatch):
     """csrc/train_chain32.h (the fp32 chain: 16-row blocks on the 16 x 16 x 4 MFMA, weight gradients in one grouped NT
@@ -577,7 +577,8 @@ def test_f32_chain_kernel_matches_per_layer_path_and_oracle(ctx, case, rows, mon
     weights after the step, Adam moments; then two more epochs with a partial last batch and the forward-only
     validation launch."""
     import os
-    monkeypatch.setenv("V21_CHAIN32S", "1" if rows == "rows8" else "0")
+    monkeypatch.setenv("V21_CHAIN32S", "0" if rows == "rows16" else "1")
+    monkeypatch.setenv("V21_C32S_ROWS", "4" if rows == "rows4" else "8")
     native, synth = pkg("_native"), pkg("synth")
     if case == "direct_7_to_451":
         dims, act, n = [7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0], 300
