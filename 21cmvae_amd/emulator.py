@@ -106,7 +106,14 @@ def load_dataset(path=None):
     """The six arrays of ``dataset_21cmVAE.h5``.  The reference reads that file at import and
     downloads it when missing; this package NEVER downloads: the file is looked for at
     ``path``, ``$V21_DATASET`` or next to this module, and otherwise the constructors
-    require the arrays to be passed explicitly."""
+    require the arrays to be passed explicitly.
+
+    The arrays are shared by every emulator built without explicit data and are READ-ONLY
+    (the reference's module-level arrays are writable; an in-place edit here raises numpy's
+    "assignment destination is read-only" -- pass an edited copy to the constructor instead).
+    That is what lets a default-constructed emulator skip the per-call checksum of the
+    training set: nobody holds a writable handle on these buffers, so the cached statistics
+    (``preprocess._cached``) are exact on identity alone."""
     global _dataset
     if _dataset is not None and path is None:
         return _dataset
@@ -115,7 +122,7 @@ def load_dataset(path=None):
         if c and os.path.exists(c):
             from . import h5lite
             with h5lite.File(c) as hf:
-                _dataset = {k: hf[k][:] for k in _DATASET_KEYS}
+                _dataset = {k: pp.freeze(hf[k][:]) for k in _DATASET_KEYS}
             return _dataset
     return None
 

@@ -119,3 +119,17 @@ def test_dataset_file_round_trip(tmp_path, monkeypatch):
     for k in data:
         assert got[k].dtype == data[k].dtype and got[k].shape == data[k].shape
         np.testing.assert_array_equal(got[k], data[k])
+    # the shared arrays are read-only, so the statistics cache needs no per-call checksum of them (preprocess._cached);
+    # with the flag flipped back the buffer is hashed again and an in-place edit is noticed
+    pp = importlib.import_module("21cmvae_amd.preprocess")
+    sig = got["signal_train"]
+    assert pp._fingerprint(sig)[2] == "frozen" and pp._fingerprint(got["par_train"])[2] == "frozen"
+    with pytest.raises(ValueError):
+        sig[0, 0] = 1.0
+    s0 = pp.SignalStats.of(sig)
+    assert pp.SignalStats.of(sig) is s0
+    sig.flags.writeable = True
+    assert pp._fingerprint(sig)[2] != "frozen"
+    sig[0, 0] += 1.0
+    s1 = pp.SignalStats.of(sig)
+    assert s1 is not s0 and s1.mean[0] != s0.mean[0]
