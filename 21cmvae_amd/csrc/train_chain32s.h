@@ -293,7 +293,13 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   // starting at fragment f0 of the tile's contraction.  Weight chunks roll as in train_chain_body (wa in use / wb in
   // flight, roles alternate); the activation words of the next fragment are read under the 8 MFMAs of this one.
   // (Units padded to whole PAIRS of chunks, so that the two buffers never change roles and no register move waits for a
-  // chunk in flight: measured slower -- +3 % of stream in the 451-wide layers, a zero chunk in the 9-wide one.)
+  // chunk in flight: measured slower -- +3 % of stream in the 451-wide layers, a zero chunk in the 9-wide one.
+  // BOTH buffers requested before the step's barrier -- the job row names the wave's next two chunks, a buffer is refilled
+  // as soon as its MFMAs are issued, after an odd unit the buffers are exchanged at the head of the wave's next unit: no
+  // gain, 44.3 against 43.3 us at batch 256 (4 rows), 93.7 against 90.0 at 2,048 (8 rows).  The steady state is the same
+  // sequence of requests, and what a unit saves at its start it pays where the exchange, and the bias values requested an
+  // unknown number of loads earlier, make hipcc wait for everything in flight.  The big layers move their weights at
+  // 47-51 B/clk; the same two-buffer loop alone reaches 56 (scripts/diag/chain_loop_probe.hip), a pure stream 63.)
   auto contract = [&](const f32x4* wsrc, const float* act, int nch, f32x4 (&acc)[G], const Job nxt, int f0) __attribute__((always_inline)) -> bool {
     const float* ap = act + jr * PITCH + 4 * f0;
     load_bias(nxt, bnext);  // (the caller has consumed this unit's values)
