@@ -13,6 +13,10 @@
 // meet in the same 64 KB (the operands are dead by then), and the epilogue is gemm_nt.h's: Adam on the tile's arena
 // elements (their m, v, w requested before the operands), the 8-row format's packed words as 16-byte stores.
 // One workgroup per 32 x 32 tile of [dW; db]; K = rows of the step <= 256 (larger steps: gemm_nt_dwadam_kernel).
+// (Measured and dropped: the same whole rows through REGISTERS -- sixteen coalesced 16-byte loads per lane, then sixteen
+// ds_write_b128 at the swizzled positions; bit-identical, 43.3-43.4 against 42.9-43.0 us per step at batch 256.  The
+// ~280 cycles per row request are not the LDS-DMA mechanism: the rows were written by the chain kernel a launch ago and
+// come from beyond this XCD's L2 either way.)
 #pragma once
 #include "gemm_nt.h"
 
