@@ -26,6 +26,8 @@ rocprofv3 --kernel-trace --stats -d $OUT/t256 -o t --output-format csv -- $PY $R
 cp $OUT/t256/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f32.csv
 V21_CHAIN32S=0 rocprofv3 --kernel-trace --stats -d $OUT/t256r16 -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 256 f32 200 > $OUT/train_probe_b256_f32_rows16_kernel.txt 2>&1
 cp $OUT/t256r16/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f32_rows16_kernel.csv
+V21_C32S_ROWS=8 rocprofv3 --kernel-trace --stats -d $OUT/t256r8 -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 256 f32 200 > $OUT/train_probe_b256_f32_rows8_kernel.txt 2>&1
+cp $OUT/t256r8/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f32_rows8_kernel.csv
 rocprofv3 --kernel-trace --stats -d $OUT/t256h -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 256 f16 200 > $OUT/train_probe_b256_f16.txt 2>&1
 cp $OUT/t256h/t_kernel_stats.csv $OUT/kernel_stats_train_b256_f16.csv
 rocprofv3 --kernel-trace --stats -d $OUT/t16k -o t --output-format csv -- $PY $ROOT/scripts/train_probe.py 16384 f16 100 > $OUT/train_probe_b16384_f16.txt 2>&1
@@ -62,7 +64,8 @@ cd $ROOT
 V21_LIB=$ROOT/21cmvae_amd/libv21_stamp.so $PY scripts/diag_stamps.py f16 > $OUT/stamps_fused_f16x2sp_block_tile_cycles.txt 2>&1
 # 5. per-wave stamps of the chain kernels (diagnostic build) and the two micro-benchmarks their analysis rests on
 V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/chain_wave_stamps.py 4096 f16 > $OUT/wave_stamps_chain_b4096_f16.txt 2>&1
-V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/chain_wave_stamps.py 256 f32 > $OUT/wave_stamps_chain_b256_f32_rows8_kernel.txt 2>&1
+V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/chain_wave_stamps.py 256 f32 > $OUT/wave_stamps_chain_b256_f32.txt 2>&1
+V21_C32S_ROWS=8 V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/chain_wave_stamps.py 256 f32 > $OUT/wave_stamps_chain_b256_f32_rows8_kernel.txt 2>&1
 V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/dwadam_stamps.py 256 f32 > $OUT/phase_stamps_dwadam_b256_f32.txt 2>&1
 V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so V21_DW32_LDS=0 $PY scripts/diag/dwadam_stamps.py 256 f32 > $OUT/phase_stamps_dwadam_b256_f32_register_operands.txt 2>&1
 V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/dwadam_stamps.py 4096 f16 > $OUT/phase_stamps_dw16_adam_b4096_f16.txt 2>&1
@@ -70,6 +73,6 @@ V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/dwadam_stamps.py 4096 
 [ -x scripts/diag/mfma4_rate_probe ] && scripts/diag/mfma4_rate_probe > $OUT/mfma4_rate_probe.txt 2>&1
 [ -x scripts/diag/cold_stream_probe ] && scripts/diag/cold_stream_probe > $OUT/cold_stream_probe.txt 2>&1
 [ -x scripts/diag/chain_loop_probe ] && scripts/diag/chain_loop_probe > $OUT/chain_loop_probe.txt 2>&1
-rm -rf $OUT/t256r16
+rm -rf $OUT/t256r16 $OUT/t256r8
 rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t4096 $OUT/t256 $OUT/t256h $OUT/t16k $OUT/tpmc_* $OUT/sq_* $OUT/fwd $OUT/joint
 ls -la $OUT
