@@ -25,35 +25,40 @@ namespace v21 {
 constexpr int kDw32MaxRows = 256;
 
 #ifdef V21_CHAIN_FINE  // (diagnostic build: phase stamps of a few workgroups, scripts/diag/dwadam_stamps.py)
-#define D32FINE(i) do { if ((threadIdx.x & 63) == 0 && ad.dbg && (blockIdx.x % 47) == 0 && blockIdx.x / 47 < 8) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ad.dbg[((blockIdx.x / 47) * 8 + (i)) * 4 + (threadIdx.x >> 6)] = t_; } } while (0)
+#define D32FINE(i) do { if ((threadIdx.x & 63) == 0 && ad.dbg && (blk % 47) == 0 && blk / 47 < 8) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ad.dbg[((blk / 47) * 8 + (i)) * 4 + (threadIdx.x >> 6)] = t_; } } while (0)
 #else
 #define D32FINE(i)
 #endif
-__global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, const NtAdamInfo ad) {
+// what changes from step to step in a sweep (the per-model blocks stay in device memory)
+struct Dw32Model { NtGroupBig grp; NtAdamInfo ad; };
+struct Dw32Step { int rows; int slot; float alpha[kSweepMax]; };
+// `kov` >= 0: a sweep's launch -- the contraction length, the step size and the loss slot come from the step block
+__device__ __forceinline__ void dwadam32_body(const NtGroupBig& grp, const NtAdamInfo& ad, const int blk, const int kov, const float alpha_ov, const int slot_ov) {
   __shared__ __attribute__((aligned(16))) float smem[64 * 256];  // operand rows, then the four partial tiles
   D32FINE(0);
   typedef float f32x4v __attribute__((ext_vector_type(4)));
-  if (ad.loss_acc && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (ad.loss_acc && blk == 0 && threadIdx.x == 0) {
     const float f = (float)((double)(long long)*ad.loss_acc * (1.0 / 4294967296.0));
     *ad.loss_out = f;
-    if (ad.loss_out2 && (ad.sc.desc || ad.loss_slot >= 0)) ad.loss_out2[ad.sc.desc ? ad.sc.desc[*ad.sc.cur].slot : ad.loss_slot] = f;
+    const int slot = kov >= 0 ? slot_ov : ad.loss_slot;
+    if (ad.loss_out2 && (ad.sc.desc || slot >= 0)) ad.loss_out2[ad.sc.desc ? ad.sc.desc[*ad.sc.cur].slot : slot] = f;
     *ad.loss_acc = 0ull;
   }
   int pi = 0;  // (no dependent chain of scalar loads: the whole table, then compares)
 #pragma unroll
-  for (int i = 1; i < kNtMaxGroup; ++i) pi += (i < grp.count && (int)blockIdx.x >= grp.first[i]) ? 1 : 0;
-  const int bid = blockIdx.x - grp.first[pi];
+  for (int i = 1; i < kNtMaxGroup; ++i) pi += (i < grp.count && blk >= grp.first[i]) ? 1 : 0;
+  const int bid = blk - grp.first[pi];
   // everything the kernel needs of its problem and of the Adam block, read once (both are indexed by `pi` in the
   // kernel-argument segment: every later use would be a scalar load of its own)
   const NtArgs& g = grp.p[pi];
   const NtAdamLayer& al = ad.lt[pi];
   const float* gA = g.A; const float* gB = g.B;
   const long long lda = g.lda, ldb = g.ldb, ldc = g.ldc;
-  const int M = g.M, N = g.N, K = g.K, nx = g.nx;
+  const int M = g.M, N = g.N, K = kov >= 0 ? kov : g.K, nx = g.nx;
   float* gC = g.C;
   const long long arena_off = al.arena_off, fw_off = al.fw_off, bw_off = al.bw_off;
   const int aK = al.K, KS = al.KS, NS = al.NS, fmt = ad.fmt;
-  const float alpha = ad.sc.desc ? ad.sc.desc[*ad.sc.cur].alpha : ad.alpha, omb1 = ad.omb1, omb2 = ad.omb2, eps = ad.eps;
+  const float alpha = kov >= 0 ? alpha_ov : (ad.sc.desc ? ad.sc.desc[*ad.sc.cur].alpha : ad.alpha), omb1 = ad.omb1, omb2 = ad.omb2, eps = ad.eps;
   float* aw_ = ad.w; float* am_ = ad.m; float* av_ = ad.v; float* afw = ad.fw; float* abw = ad.bw;
 
   const int lane = threadIdx.x & 63;
@@ -198,6 +203,16 @@ __global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, con
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   D32FINE(5);
+}
+__global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, const NtAdamInfo ad) { dwadam32_body(grp, ad, (int)blockIdx.x, -1, 0.f, -1); }
+// a sweep of f32 models: blockIdx.y = model (its problem and Adam blocks in device memory), blockIdx.x = tile of the model.
+// (One model per XCD -- workgroup b = tile b / models of model b % models, as train_chain32s_group_kernel deals its row
+// blocks -- was slower: 59.8 against 53.3 us for 8 autoencoders of 128 .. 512 hidden units; the XCD with the largest
+// model's tiles ends last.)
+__global__ void __launch_bounds__(256) dwadam32_group_kernel(const Dw32Model* __restrict__ tab, const Dw32Step st) {
+  const Dw32Model& md = tab[blockIdx.y];
+  if ((int)blockIdx.x >= md.grp.first[md.grp.count]) return;
+  dwadam32_body(md.grp, md.ad, (int)blockIdx.x, st.rows, st.alpha[blockIdx.y], st.slot);
 }
 
 }  // namespace v21

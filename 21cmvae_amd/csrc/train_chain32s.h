@@ -159,7 +159,7 @@ inline void c32s_build_jobs(const ChainModel& a, C32sJob* tab) {
 // ROWS = 8: two groups of four rows share every weight word (two MFMAs per word); ROWS = 4: one group -- twice the
 // workgroups, half the matrix work in each, the same weight stream through each CU (the LDS carve-up stays the 8-row one).
 template <int ROWS>
-__device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const ChainStep& st) {
+__device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const ChainStep& st, const int bidx) {
   static_assert(ROWS == 4 || ROWS == 8, "one or two groups of four rows");
   constexpr int NW = kC32sWaves, PITCH = kC32Pitch, G = ROWS / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
@@ -175,7 +175,6 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   const int jr = lane & 3, blk = lane >> 2;  // batch row within a group of four, feature block of the tile
   const long long first = st.sc.desc ? st.sc.desc[*st.sc.cur].first : st.first;
   const int nrb = (st.rows + ROWS - 1) / ROWS;
-  const int bidx = (int)blockIdx.x - st.blk0;
   const int rb = (bidx & 7) * ((nrb + 7) >> 3) + (bidx >> 3);  // XCD-major row blocks (speed only)
   if (rb >= nrb) return;
   const int m0 = rb * ROWS;
@@ -525,7 +524,16 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
 template <int ROWS>
 __global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_kernel(const ChainArgs a) {
   if ((int)blockIdx.x >= a.ncons) { chain_prefetch(a, a); return; }
-  train_chain32s_body<ROWS>(a, a);
+  train_chain32s_body<ROWS>(a, a, (int)blockIdx.x - a.blk0);
+}
+// a sweep: `models` per-model blocks in device memory (as train_chain_group_kernel); no prefetchers.  Workgroup b carries
+// row block b / models of model b % models: workgroups are dealt to the XCDs round-robin, so with 8 models (or a divisor
+// or multiple of 8) a model's row blocks share ONE XCD and its weights are fetched into one L2 -- with blockIdx.y = model
+// every XCD streamed every model's weights (8 x 2.5 MB through a 4-MB L2): 68.8 us per launch of 8 models.
+template <int ROWS>
+__global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_group_kernel(const ChainModel* __restrict__ tab, const ChainStep st, const int models) {
+  const int b = (int)blockIdx.x;
+  train_chain32s_body<ROWS>(tab[b % models], st, b / models);
 }
 
 }  // namespace v21

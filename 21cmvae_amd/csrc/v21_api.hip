@@ -1489,7 +1489,8 @@ static int chain_attr(int prec) {
   if (prec == V21_PREC_F32) {
     for (const void* f : {(const void*)train_chain32_kernel<0>, (const void*)train_chain32_kernel<kChainFwd>, (const void*)train_chain32_kernel<kChainFwd | kChainOut>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kC32LdsBytes));
-    for (const void* f : {(const void*)train_chain32s_kernel<8>, (const void*)train_chain32s_kernel<4>})
+    for (const void* f : {(const void*)train_chain32s_kernel<8>, (const void*)train_chain32s_kernel<4>,
+                          (const void*)train_chain32s_group_kernel<8>, (const void*)train_chain32s_group_kernel<4>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kC32sLdsBytes));
   } else if (prec == V21_PREC_F16) {
     CHK(chain_attr_of<PrecF16>());
@@ -2338,6 +2339,11 @@ struct v21_sweep {
   std::vector<ChainModel> h_chain;
   DwAdamModel* d_dwadam = nullptr;  // single rank: gradients + Adam in one grouped launch (dw_adam.h)
   std::vector<DwAdamModel> h_dwadam;
+  // f32 members on the small-batch chain (train_chain32s.h): one grouped chain launch + one grouped gradient / Adam launch
+  // (dw_adam32.h) per step on a single rank, steps of <= kDw32MaxRows rows
+  bool chain32s = false;
+  Dw32Model* d_dw32 = nullptr;
+  std::vector<Dw32Model> h_dw32;
 };
 
 extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** out) {
@@ -2368,7 +2374,10 @@ extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** o
   for (int k = 0; k < count; ++k) s->chain = s->chain && trainers[k]->chain;
   for (int k = 0; k < count; ++k) s->h_adam.push_back(adam_args(trainers[k], true, 0.f, s->chain));
   HIPCHK(hipMemcpyAsync(s->d_adam, s->h_adam.data(), s->h_adam.size() * sizeof(AdamArgs), hipMemcpyHostToDevice, s->ctx->stream));
-  if (s->chain) HIPCHK(hipMalloc((void**)&s->d_chain, (size_t)count * sizeof(ChainModel)));
+  s->chain32s = !s->chain;
+  for (int k = 0; k < count; ++k) s->chain32s = s->chain32s && trainers[k]->chain32s && trainers[k]->mlp->L <= kNtMaxGroup;
+  if (s->chain || s->chain32s) HIPCHK(hipMalloc((void**)&s->d_chain, (size_t)count * sizeof(ChainModel)));
+  if (s->chain32s) HIPCHK(hipMalloc((void**)&s->d_dw32, (size_t)count * sizeof(Dw32Model)));
   HIPCHK(hipStreamSynchronize(s->ctx->stream));
   *out = s;
   return V21_OK;
@@ -2380,6 +2389,7 @@ extern "C" int v21_sweep_destroy(v21_sweep* s) {
   hipFree(s->d_adam);
   if (s->d_chain) hipFree(s->d_chain);
   if (s->d_dwadam) hipFree(s->d_dwadam);
+  if (s->d_dw32) hipFree(s->d_dw32);
   delete s;
   return V21_OK;
 }
@@ -2567,6 +2577,77 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long l
   return V21_OK;
 }
 
+// f32 members (train_chain32s.h): the problem and Adam blocks of one model's gradient launch, as train_on_rows_chain32
+// builds them per step -- without what changes from step to step (contraction length, step size, loss slot: Dw32Step).
+// false: this model's gradient launch would take 64 x 64 tiles (gemm_nt_dwadam_kernel<2>): the sweep then keeps the
+// per-layer path, so that a member trains bit for bit as it would on its own.
+static bool build_dw32_model(v21_trainer* t, Dw32Model& md, int& blocks) {
+  v21_mlp* m = t->mlp;
+  const int L = m->L;
+  md = Dw32Model{};
+  blocks = 0;
+  if (L > kNtMaxGroup) return false;
+  long long work = 0;
+  md.grp.count = L;
+  for (int l = 0; l < L; ++l) {
+    NtArgs& g = md.grp.p[l];
+    g.A = t->d_ht[l]; g.lda = t->Bp;
+    g.B = t->d_dzt[l + 1]; g.ldb = t->Bp;
+    g.C = t->d_g + m->w_off[l]; g.ldc = m->nw(l);
+    g.M = m->dims[l] + 1; g.N = m->nw(l);
+    g.ep = NT_DW; g.nz = 1; g.tile = 32;
+    g.nx = (g.N + 31) / 32; g.ny = (g.M + 31) / 32;
+    g.a_scale = g.b_scale = g.out_scale = 1.f;
+    work += (long long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    md.grp.first[l] = blocks;
+    blocks += g.nx * g.ny;
+    md.ad.lt[l] = NtAdamLayer{m->w_off[l], t->fw_off[l], t->bw_off[l], m->dims[l], t->c32_frags(m->dims[l]), t->c32_frags(m->nw(l))};
+  }
+  md.grp.first[L] = blocks;
+  if (work >= 192) return false;
+  NtAdamInfo& ad = md.ad;
+  ad.w = m->d_w; ad.m = t->d_m; ad.v = t->d_v; ad.fw = (float*)t->d_fw; ad.bw = (float*)t->d_bw;
+  ad.omb1 = 1.0f - t->adam.beta1; ad.omb2 = 1.0f - t->adam.beta2; ad.eps = t->adam.eps;
+  ad.loss_acc = (unsigned long long*)t->d_ticket; ad.loss_out = t->d_g + t->P; ad.loss_out2 = t->d_steploss;
+  ad.loss_slot = -1;
+  ad.fmt = 4;
+  return true;
+}
+// one optimizer step of every f32 member in TWO launches: the chain of every model (blockIdx.y = model), then every
+// weight gradient + Adam + packed streams + batch loss
+static int sweep_step_chain32(v21_sweep* s, const ChainStep& cs, long long step_index, int max_blocks) {
+  hipStream_t st = s->ctx->stream;
+  const int G = (int)s->tr.size(), rows = cs.rows;
+  for (v21_trainer* t : s->tr) CHK(ensure_copies(t, false));
+  CHK(chain_attr(V21_PREC_F32));
+  // 4 rows per workgroup while every model's row blocks fit the chip in one round (train_chain32s.h)
+  const char* er = getenv("V21_C32S_ROWS");
+  const int force_rows = er ? atoi(er) : 0;
+  const int rpw = force_rows == 4 || force_rows == 8 ? force_rows : ((long long)G * ((rows + 3) / 4) <= 256 ? 4 : 8);
+  ChainStep csp = cs;
+  csp.ncons = ((rows + rpw - 1) / rpw + 7) / 8 * 8;
+  csp.npref = 0;
+  const dim3 grid(csp.ncons * G), block(64 * kC32sWaves);
+  if (rpw == 4) hipLaunchKernelGGL(train_chain32s_group_kernel<4>, grid, block, kC32sLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
+  else hipLaunchKernelGGL(train_chain32s_group_kernel<8>, grid, block, kC32sLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
+  HIPCHK(hipGetLastError());
+  Dw32Step ds{};
+  ds.rows = rows; ds.slot = (int)step_index;
+  for (int k = 0; k < G; ++k) {
+    v21_trainer* t = s->tr[k];
+    t->iter += 1;
+    ds.alpha[k] = adam_alpha(t->adam, t->iter);
+  }
+  hipLaunchKernelGGL(dwadam32_group_kernel, dim3(max_blocks, G), dim3(256), 0, st, (const Dw32Model*)s->d_dw32, ds);
+  HIPCHK(hipGetLastError());
+  for (v21_trainer* t : s->tr) {
+    t->copies_ok = true; t->nt_ok = false;
+    invalidate_streams(t->mlp);
+    t->mlp->wpad_ok = true;
+  }
+  return V21_OK;
+}
+
 extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch, double* losses) {
   if (!s || !losses) return fail(V21_ERR_ARG, "null argument");
   v21_trainer* t0 = s->tr[0];
@@ -2616,6 +2697,30 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
     }
     if (R == 1) CHK(refresh_dw_adam_table(s->tr, &s->d_dwadam, s->h_dwadam, st));
   }
+  bool group32 = s->chain32s && R == 1 && batch <= kDw32MaxRows && !(getenv("V21_SWEEP32_GROUP") && getenv("V21_SWEEP32_GROUP")[0] == '0');
+  int max_blocks32 = 0;
+  if (group32) {
+    std::vector<ChainModel> tab;
+    std::vector<Dw32Model> dtab(s->tr.size());
+    for (size_t k = 0; k < s->tr.size(); ++k) {
+      tab.push_back(chain_model32(s->tr[k]));
+      tab.back().stamps = nullptr;
+      int blocks = 0;
+      group32 = group32 && build_dw32_model(s->tr[k], dtab[k], blocks);
+      max_blocks32 = std::max(max_blocks32, blocks);
+    }
+    if (group32) {
+      const bool c_new = tab.size() != s->h_chain.size() || memcmp(tab.data(), s->h_chain.data(), tab.size() * sizeof(ChainModel)) != 0;
+      const bool d_new = dtab.size() != s->h_dw32.size() || memcmp(dtab.data(), s->h_dw32.data(), dtab.size() * sizeof(Dw32Model)) != 0;
+      if (c_new || d_new) {
+        HIPCHK(hipStreamSynchronize(st));  // (a step in flight may still read the old tables)
+        s->h_chain = tab; s->h_dw32 = dtab;
+        HIPCHK(hipMemcpyAsync(s->d_chain, s->h_chain.data(), tab.size() * sizeof(ChainModel), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->d_dw32, s->h_dw32.data(), dtab.size() * sizeof(Dw32Model), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+      }
+    }
+  }
   for (long long sidx = 0; sidx < steps; ++sidx) {
     const long long first = sidx * batch;
     const int brows = (int)std::min<long long>(batch, n - first);
@@ -2626,6 +2731,13 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
                                 brows, dout, nullptr, lo - first);
       cs.step_off = (unsigned long long)sidx;  // the table holds every model's step counter as of the epoch's start
       CHK(sweep_step_chain(s, cs, brows, sidx));
+      continue;
+    }
+    if (group32) {
+      ChainStep cs = chain_step(t0->d_x[0], din, t0->y_is_x[0] ? nullptr : t0->d_y[0], dout, t0->d_rw[0], d_idx, lo, rows,
+                                brows, dout, nullptr, lo - first);
+      cs.gs = 1.0f;  // fp32 operands: no scaling of the gradients
+      CHK(sweep_step_chain32(s, cs, sidx, max_blocks32));
       continue;
     }
     if (rows > 0)

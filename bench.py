@@ -711,6 +711,11 @@ def main():
             out["sweep"] = sweep_leg(native, ctx, args.precision)
         except Exception as e:
             out["sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0 and args.precision != "f32":  # the same sweep in the reference's arithmetic (grouped launches of train_chain32s.h / dw_adam32.h)
+            try:
+                out["sweep_f32"] = sweep_leg(native, ctx, "f32")
+            except Exception as e:
+                out["sweep_f32"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if dist is not None:  # every rank takes part, whether its own leg failed or not
             t = torch.tensor([out["sweep"].get("model_steps_per_s_grouped", 0.0)], dtype=torch.float64, device=_pg_device(dist))
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
