@@ -56,7 +56,10 @@ constexpr int kC32sBufBytes = 2 * kC32sRows * kC32Pitch * 4;
 constexpr int kC32sYBytes = kC32sRows * kC32Pitch * 4;
 constexpr int kC32sMaskBytes = kC32sMaskTiles * 64 * 2;
 constexpr int kC32sPartBytes = kC32sWaves * 64 * 8 * 4;  // partial tiles of a split contraction: [wave][lane][8 floats]
-constexpr int kC32sLdsBytes = kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes + kC32sWaves * kC32sRows * 4 + kC32sRows * 4 + 64;
+constexpr int kC32sZPitch = 2 * kChainMaxLatent + 4;  // joint step: the encoder's latents of the block's rows (fp32, <= 64 wide)
+constexpr int kC32sZOff = kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes + kC32sWaves * kC32sRows * 4 + kC32sRows * 4 + 64;
+constexpr int kC32sLdsBytes = kC32sZOff + kC32sRows * kC32sZPitch * 4;
+static_assert(kC32sZOff % 16 == 0, "LDS areas are 16-byte aligned");
 // fragments (4 k each) per 64-feature tile over a contraction range of d, whole chunks of four
 __host__ __device__ constexpr int chain32s_frags(int d) { return ((d + 3) / 4 + 3) / 4 * 4; }
 
@@ -169,6 +172,8 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   f32x4* part = reinterpret_cast<f32x4*>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes);
   float(*red)[ROWS] = reinterpret_cast<float(*)[ROWS]>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes);
   float* rwl = reinterpret_cast<float*>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes + NW * ROWS * 4);
+  float* zs = reinterpret_cast<float*>(chain_smem + kC32sZOff);  // joint step (train_chain32s_joint_kernel)
+  constexpr int ZP = kC32sZPitch;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,7 +247,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     for (int i = 0; i < 8; ++i) {
       const int k = lane + 64 * i;  // <= 511 < PITCH
       buf[0][wave * PITCH + k] = v[i];
-      if (!st.y) ystg[wave * PITCH + k] = v[i];
+      if (!st.y && !st.y_from_lds) ystg[wave * PITCH + k] = v[i];
     }
     if (st.y) {
       const int ymax = mq < st.rows ? DO : 0;
@@ -256,6 +261,10 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
 #pragma unroll
       for (int i = 0; i < 8; ++i) ystg[wave * PITCH + lane + 64 * i] = v[i];
     }
+  }
+  if (st.y_from_lds) {  // joint step: the targets are the latents the encoder pass of this workgroup left in `zs`
+    const int DOl = a.lt[a.L - 1].N;
+    for (int i = tid; i < ROWS * DOl; i += 64 * NW) ystg[(i / DOl) * PITCH + i % DOl] = zs[(i / DOl) * ZP + i % DOl];
   }
   C32sJob jnext = row(1);  // (collected by the barrier's wait, see the layer loop)
   chain_barrier();
@@ -386,7 +395,8 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   };
 
   // ---- forward
-  for (int l = 0; l < a.L; ++l) {
+  const int LF = st.nfwd > 0 ? st.nfwd : a.L;  // (joint step: the encoder alone)
+  for (int l = 0; l < LF; ++l) {
     const bool last = l == a.L - 1;
     const float* act = buf[cur];
     float* out = buf[cur ^ 1];
@@ -464,6 +474,12 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     chain_stamp(a, 2 + l);
   }
 
+  if (LF < a.L) {  // joint step, the encoder alone: its last layer's outputs (the image the last barrier completed) are
+                   // the targets of the model that follows in this workgroup
+    const int W = a.lt[LF - 1].N;
+    for (int i = tid; i < ROWS * W; i += 64 * NW) zs[(i / W) * ZP + i % W] = buf[cur][(i / W) * PITCH + i % W];
+    return;
+  }
   // ---- loss: lanes -> rows -> workgroup (fixed order) -> one fixed-point atomic per workgroup
   if (tid < ROWS) {
     float sl = 0.f;
@@ -525,6 +541,20 @@ template <int ROWS>
 __global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_kernel(const ChainArgs a) {
   if ((int)blockIdx.x >= a.ncons) { chain_prefetch(a, a); return; }
   train_chain32s_body<ROWS>(a, a, (int)blockIdx.x - a.blk0);
+}
+// joint step (train_chain.h: train_chain_joint_kernel; BASELINE configs[2]) in the reference's arithmetic: blocks
+// [0, ncons) carry the autoencoder's row blocks, blocks [ncons, 2 ncons) the emulator's -- first the ENCODER alone on the
+// block's rows (forward layers [0, zcap_layer]; its latents stay in LDS), then the emulator's chain with those latents as
+// targets.  tab[0] = autoencoder, tab[1] = emulator (device memory); no prefetchers, no variational layer.
+template <int ROWS>
+__global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_joint_kernel(const ChainModel* __restrict__ tab, const ChainStep sa, const ChainStep sb) {
+  const int b = (int)blockIdx.x;
+  if (b < sa.ncons) { train_chain32s_body<ROWS>(tab[0], sa, b); return; }
+  ChainStep se = sa;
+  se.fwd_only = 1; se.nfwd = tab[0].zcap_layer + 1;
+  train_chain32s_body<ROWS>(tab[0], se, b - sa.ncons);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the latents are written; the encoder's last LDS reads precede the emulator's gather
+  train_chain32s_body<ROWS>(tab[1], sb, b - sa.ncons);
 }
 // a sweep: `models` per-model blocks in device memory (as train_chain_group_kernel); no prefetchers.  Workgroup b carries
 // row block b / models of model b % models: workgroups are dealt to the XCDs round-robin, so with 8 models (or a divisor

@@ -1490,7 +1490,8 @@ static int chain_attr(int prec) {
     for (const void* f : {(const void*)train_chain32_kernel<0>, (const void*)train_chain32_kernel<kChainFwd>, (const void*)train_chain32_kernel<kChainFwd | kChainOut>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kC32LdsBytes));
     for (const void* f : {(const void*)train_chain32s_kernel<8>, (const void*)train_chain32s_kernel<4>,
-                          (const void*)train_chain32s_group_kernel<8>, (const void*)train_chain32s_group_kernel<4>})
+                          (const void*)train_chain32s_group_kernel<8>, (const void*)train_chain32s_group_kernel<4>,
+                          (const void*)train_chain32s_joint_kernel<8>, (const void*)train_chain32s_joint_kernel<4>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kC32sLdsBytes));
   } else if (prec == V21_PREC_F16) {
     CHK(chain_attr_of<PrecF16>());
@@ -1832,7 +1833,8 @@ static int launch_nt_many(int prec, std::vector<NtArgs>& probs, hipStream_t st);
 // gradient in one grouped NT launch on the fp32 operands the chain left, Adam (which also rebuilds the packed fp32
 // streams and, on a single rank, publishes the batch loss)
 static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
-                                 const int* d_idx, long long first, int rows, int brows, float* loss_out, long long row0) {
+                                 const int* d_idx, long long first, int rows, int brows, float* loss_out, long long row0,
+                                 bool chain_done = false /* the joint step: the chain of this model ran in the joint launch */) {
   v21_mlp* m = t->mlp;
   hipStream_t st = t->ctx->stream;
   const int L = m->L, dout = m->dims[L];
@@ -1842,12 +1844,14 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
                         loss_out < t->d_steploss + t->steploss_cap;
   int fold = 1;
   if (rows > 0) {
-    CHK(ensure_copies(t, false));
-    ChainArgs a{};
-    static_cast<ChainModel&>(a) = chain_model32(t);
-    static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, dout, t, row0);
-    a.gs = 1.0f;  // fp32 operands: no scaling of the gradients
-    CHK(launch_chain32_args(a, st, t->chain32s));
+    if (!chain_done) {
+      CHK(ensure_copies(t, false));
+      ChainArgs a{};
+      static_cast<ChainModel&>(a) = chain_model32(t);
+      static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, dout, t, row0);
+      a.gs = 1.0f;  // fp32 operands: no scaling of the gradients
+      CHK(launch_chain32_args(a, st, t->chain32s));
+    }
     int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
     const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
     nslice = (rows + k_chunk - 1) / k_chunk;
@@ -2613,6 +2617,45 @@ static bool build_dw32_model(v21_trainer* t, Dw32Model& md, int& blocks) {
   ad.fmt = 4;
   return true;
 }
+// every weight gradient + Adam + packed streams + batch loss of several f32 models in one launch (dw_adam32.h)
+static int launch_dw32_group(const std::vector<v21_trainer*>& trs, const Dw32Model* d_tab, int rows, long long step_index, int max_blocks,
+                             hipStream_t st) {
+  const int G = (int)trs.size();
+  Dw32Step ds{};
+  ds.rows = rows; ds.slot = (int)step_index;
+  for (int k = 0; k < G; ++k) {
+    v21_trainer* t = trs[k];
+    t->iter += 1;
+    ds.alpha[k] = adam_alpha(t->adam, t->iter);
+  }
+  hipLaunchKernelGGL(dwadam32_group_kernel, dim3(max_blocks, G), dim3(256), 0, st, d_tab, ds);
+  HIPCHK(hipGetLastError());
+  for (v21_trainer* t : trs) {
+    t->copies_ok = true; t->nt_ok = false;
+    invalidate_streams(t->mlp);
+    t->mlp->wpad_ok = true;
+  }
+  return V21_OK;
+}
+// builds / refreshes the device table of launch_dw32_group; *ok = false: a member's gradient launch takes 64 x 64 tiles
+static int refresh_dw32_table(const std::vector<v21_trainer*>& trs, Dw32Model* d_tab, std::vector<Dw32Model>& h_tab, int* max_blocks, bool* ok,
+                              hipStream_t st) {
+  std::vector<Dw32Model> dtab(trs.size());
+  *max_blocks = 0; *ok = true;
+  for (size_t k = 0; k < trs.size(); ++k) {
+    int blocks = 0;
+    *ok = *ok && build_dw32_model(trs[k], dtab[k], blocks);
+    *max_blocks = std::max(*max_blocks, blocks);
+  }
+  if (!*ok) return V21_OK;
+  if (dtab.size() != h_tab.size() || memcmp(dtab.data(), h_tab.data(), dtab.size() * sizeof(Dw32Model)) != 0) {
+    HIPCHK(hipStreamSynchronize(st));  // (a step in flight may still read the old table)
+    h_tab = dtab;
+    HIPCHK(hipMemcpyAsync(d_tab, h_tab.data(), dtab.size() * sizeof(Dw32Model), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return V21_OK;
+}
 // one optimizer step of every f32 member in TWO launches: the chain of every model (blockIdx.y = model), then every
 // weight gradient + Adam + packed streams + batch loss
 static int sweep_step_chain32(v21_sweep* s, const ChainStep& cs, long long step_index, int max_blocks) {
@@ -2631,21 +2674,7 @@ static int sweep_step_chain32(v21_sweep* s, const ChainStep& cs, long long step_
   if (rpw == 4) hipLaunchKernelGGL(train_chain32s_group_kernel<4>, grid, block, kC32sLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
   else hipLaunchKernelGGL(train_chain32s_group_kernel<8>, grid, block, kC32sLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
   HIPCHK(hipGetLastError());
-  Dw32Step ds{};
-  ds.rows = rows; ds.slot = (int)step_index;
-  for (int k = 0; k < G; ++k) {
-    v21_trainer* t = s->tr[k];
-    t->iter += 1;
-    ds.alpha[k] = adam_alpha(t->adam, t->iter);
-  }
-  hipLaunchKernelGGL(dwadam32_group_kernel, dim3(max_blocks, G), dim3(256), 0, st, (const Dw32Model*)s->d_dw32, ds);
-  HIPCHK(hipGetLastError());
-  for (v21_trainer* t : s->tr) {
-    t->copies_ok = true; t->nt_ok = false;
-    invalidate_streams(t->mlp);
-    t->mlp->wpad_ok = true;
-  }
-  return V21_OK;
+  return launch_dw32_group(s->tr, s->d_dw32, rows, step_index, max_blocks, st);
 }
 
 extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch, double* losses) {
@@ -2699,26 +2728,18 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
   }
   bool group32 = s->chain32s && R == 1 && batch <= kDw32MaxRows && !(getenv("V21_SWEEP32_GROUP") && getenv("V21_SWEEP32_GROUP")[0] == '0');
   int max_blocks32 = 0;
+  if (group32) CHK(refresh_dw32_table(s->tr, s->d_dw32, s->h_dw32, &max_blocks32, &group32, st));
   if (group32) {
     std::vector<ChainModel> tab;
-    std::vector<Dw32Model> dtab(s->tr.size());
-    for (size_t k = 0; k < s->tr.size(); ++k) {
-      tab.push_back(chain_model32(s->tr[k]));
+    for (v21_trainer* t : s->tr) {
+      tab.push_back(chain_model32(t));
       tab.back().stamps = nullptr;
-      int blocks = 0;
-      group32 = group32 && build_dw32_model(s->tr[k], dtab[k], blocks);
-      max_blocks32 = std::max(max_blocks32, blocks);
     }
-    if (group32) {
-      const bool c_new = tab.size() != s->h_chain.size() || memcmp(tab.data(), s->h_chain.data(), tab.size() * sizeof(ChainModel)) != 0;
-      const bool d_new = dtab.size() != s->h_dw32.size() || memcmp(dtab.data(), s->h_dw32.data(), dtab.size() * sizeof(Dw32Model)) != 0;
-      if (c_new || d_new) {
-        HIPCHK(hipStreamSynchronize(st));  // (a step in flight may still read the old tables)
-        s->h_chain = tab; s->h_dw32 = dtab;
-        HIPCHK(hipMemcpyAsync(s->d_chain, s->h_chain.data(), tab.size() * sizeof(ChainModel), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(s->d_dw32, s->h_dw32.data(), dtab.size() * sizeof(Dw32Model), hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
-      }
+    if (tab.size() != s->h_chain.size() || memcmp(tab.data(), s->h_chain.data(), tab.size() * sizeof(ChainModel)) != 0) {
+      HIPCHK(hipStreamSynchronize(st));  // (a step in flight may still read the old table)
+      s->h_chain = tab;
+      HIPCHK(hipMemcpyAsync(s->d_chain, s->h_chain.data(), tab.size() * sizeof(ChainModel), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
     }
   }
   for (long long sidx = 0; sidx < steps; ++sidx) {
@@ -2773,13 +2794,18 @@ struct v21_joint {
   std::vector<ChainModel> h_tab;
   DwAdamModel* d_dwadam = nullptr;  // gradients + Adam of both models in one grouped launch (dw_adam.h)
   std::vector<DwAdamModel> h_dwadam;
+  bool f32 = false;  // both trainers on the small-batch f32 chain (train_chain32s.h: train_chain32s_joint_kernel)
+  Dw32Model* d_dw32 = nullptr;  // ... and, on a single rank with steps of <= kDw32MaxRows rows, both models' gradients + Adam in one launch
+  std::vector<Dw32Model> h_dw32;
 };
 extern "C" int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_layer, v21_joint** out) {
   if (!ae || !em || !out) return fail(V21_ERR_ARG, "null argument");
   if (ae == em || ae->ctx != em->ctx || ae->prec != em->prec || ae->max_batch != em->max_batch)
     return fail(V21_ERR_ARG, "the two trainers must be distinct and share context, precision and max_batch");
-  if (!ae->chain || !em->chain || em->gl >= 0)
-    return fail(V21_ERR_UNSUPPORTED, "the joint step runs on the chain kernel: f16 / bf16, widths <= %d, no variational layer in the emulator", kChainMaxDim);
+  const bool f32 = ae->chain32s && em->chain32s && ae->gl < 0 && em->gl < 0;
+  if (!f32 && (!ae->chain || !em->chain || em->gl >= 0))
+    return fail(V21_ERR_UNSUPPORTED, "the joint step runs on the chain kernels: f16 / bf16 (widths <= %d, no variational layer in the emulator), or "
+                "f32 with max_batch <= %d and no variational layer", kChainMaxDim, kC32sMaxBatch);
   const v21_mlp* ma = ae->mlp;
   const v21_mlp* me = em->mlp;
   // the latent layer: linear, or the variational head (V21_ACT_GAUSS) -- the emulator then learns z_mean, what
@@ -2792,7 +2818,7 @@ extern "C" int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_lay
   if (ma->dims[0] != ma->dims[ma->L]) return fail(V21_ERR_ARG, "the first trainer must be an autoencoder (in == out width)");
   CHK(use(ae->ctx));
   v21_joint* j = new v21_joint();
-  j->ae = ae; j->em = em; j->latent_layer = latent_layer;
+  j->ae = ae; j->em = em; j->latent_layer = latent_layer; j->f32 = f32;
   hipError_t e = hipMalloc((void**)&j->d_tab, 2 * sizeof(ChainModel));
   if (e != hipSuccess) { delete j; return fail(V21_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
   *out = j;
@@ -2804,6 +2830,7 @@ extern "C" int v21_joint_destroy(v21_joint* j) {
   hipStreamSynchronize(j->ae->ctx->stream);
   hipFree(j->d_tab);
   if (j->d_dwadam) hipFree(j->d_dwadam);
+  if (j->d_dw32) hipFree(j->d_dw32);
   delete j;
   return V21_OK;
 }
@@ -2840,15 +2867,24 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
       t->steploss_cap = steps;
     }
   {
-    std::vector<ChainModel> tab = {chain_model(ta), chain_model(te)};
+    std::vector<ChainModel> tab = j->f32 ? std::vector<ChainModel>{chain_model32(ta), chain_model32(te)}
+                                         : std::vector<ChainModel>{chain_model(ta), chain_model(te)};
     tab[0].zcap_layer = j->latent_layer;
+    if (j->f32) tab[0].stamps = tab[1].stamps = nullptr;
     if (tab.size() != j->h_tab.size() || memcmp(tab.data(), j->h_tab.data(), 2 * sizeof(ChainModel)) != 0) {
+      HIPCHK(hipStreamSynchronize(st));
       j->h_tab = tab;
       HIPCHK(hipMemcpyAsync(j->d_tab, j->h_tab.data(), 2 * sizeof(ChainModel), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
     }
   }
-  if (R == 1) CHK(refresh_dw_adam_table({ta, te}, &j->d_dwadam, j->h_dwadam, st));
+  if (R == 1 && !j->f32) CHK(refresh_dw_adam_table({ta, te}, &j->d_dwadam, j->h_dwadam, st));
+  bool group32 = j->f32 && R == 1 && batch <= kDw32MaxRows;
+  int max_blocks32 = 0;
+  if (group32) {
+    if (!j->d_dw32) HIPCHK(hipMalloc((void**)&j->d_dw32, 2 * sizeof(Dw32Model)));
+    CHK(refresh_dw32_table({ta, te}, j->d_dw32, j->h_dw32, &max_blocks32, &group32, st));
+  }
   CHK(chain_attr(ta->prec));
   const int dsig = ta->mlp->dims[0], dpar = te->mlp->dims[0], dlat = te->mlp->dims[te->mlp->L];
   for (long long s = 0; s < steps; ++s) {
@@ -2857,6 +2893,32 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
     const long long lo = first + (long long)brows * rk / R, hi = first + (long long)brows * (rk + 1) / R;
     const int rows = (int)(hi - lo);                                // this rank's share (data parallel: SURVEY 8e)
     for (v21_trainer* t : {ta, te}) CHK(ensure_copies(t, false));
+    if (j->f32) {
+      // the reference's arithmetic: one joint chain launch (train_chain32s_joint_kernel), then each model's gradients and
+      // Adam as after a chain step of its own (train_on_rows_chain32: one launch on a single rank; the exchange otherwise)
+      if (rows > 0) {
+        ChainStep sa = chain_step(ta->d_x[0], dsig, nullptr, dsig, ta->d_rw[0], d_idx, lo, rows, brows, dsig, nullptr, lo - first);
+        ChainStep sb = chain_step(te->d_x[0], dpar, nullptr, dlat, te->d_rw[0], d_idx, lo, rows, brows, dlat, nullptr, lo - first);
+        sa.gs = sb.gs = 1.0f;
+        sb.y_from_lds = 1;
+        const char* er = getenv("V21_C32S_ROWS");
+        const int force_rows = er ? atoi(er) : 0;
+        const int rpw = force_rows == 4 || force_rows == 8 ? force_rows : (2 * ((rows + 3) / 4) <= 256 ? 4 : 8);
+        sa.ncons = sb.ncons = ((rows + rpw - 1) / rpw + 7) / 8 * 8;
+        const dim3 grid(2 * sa.ncons), block(64 * kC32sWaves);
+        if (rpw == 4) hipLaunchKernelGGL(train_chain32s_joint_kernel<4>, grid, block, kC32sLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+        else hipLaunchKernelGGL(train_chain32s_joint_kernel<8>, grid, block, kC32sLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+        HIPCHK(hipGetLastError());
+      }
+      if (group32) {
+        CHK(launch_dw32_group({ta, te}, j->d_dw32, rows, s, max_blocks32, st));
+        continue;
+      }
+      for (v21_trainer* t : {ta, te}) {
+        CHK(train_on_rows_chain32(t, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, rows, brows, t->d_steploss + s, 0, true));
+      }
+      continue;
+    }
     if (rows > 0) {
       ChainStep sa = chain_step(ta->d_x[0], dsig, nullptr, dsig, ta->d_rw[0], d_idx, lo, rows, brows, dsig, nullptr, lo - first);
       ChainStep sb = chain_step(te->d_x[0], dpar, nullptr, dlat, te->d_rw[0], d_idx, lo, rows, brows, dlat, nullptr, lo - first);
@@ -2923,8 +2985,10 @@ extern "C" int v21_joint_eval(v21_joint* j, double* losses) {
   if (n > (1ll << 30)) return fail(V21_ERR_ARG, "too many rows for one validation launch");
   for (v21_trainer* t : {ta, te}) CHK(ensure_copies(t, false));
   {
-    std::vector<ChainModel> tab = {chain_model(ta), chain_model(te)};
+    std::vector<ChainModel> tab = j->f32 ? std::vector<ChainModel>{chain_model32(ta), chain_model32(te)}
+                                         : std::vector<ChainModel>{chain_model(ta), chain_model(te)};
     tab[0].zcap_layer = j->latent_layer;
+    if (j->f32) tab[0].stamps = tab[1].stamps = nullptr;
     tab[0].sample = 0;  // evaluation passes draw no noise
     if (tab.size() != j->h_tab.size() || memcmp(tab.data(), j->h_tab.data(), 2 * sizeof(ChainModel)) != 0) {
       HIPCHK(hipStreamSynchronize(st));
@@ -2939,11 +3003,23 @@ extern "C" int v21_joint_eval(v21_joint* j, double* losses) {
   ChainStep sb = chain_step(te->d_x[1], dpar, nullptr, dlat, te->d_rw[1], nullptr, 0, (int)n, (int)n, dlat);
   sa.fwd_only = sb.fwd_only = 1;
   sb.y_from_lds = 1;
-  sa.ncons = sb.ncons = (int)(((n + 31) / 32 + 7) / 8 * 8);
-  sb.blk0 = sa.ncons;
-  sa.npref = sb.npref = chain_prefetchers(2 * sa.ncons, 1);
-  const dim3 grid(2 * sa.ncons + 8 * sa.npref), block(64 * kChainWaves);
-  launch_joint_kernel(ta->prec, ta->gl >= 0, grid, block, st, (const ChainModel*)j->d_tab, sa, sb);
+  if (j->f32) {
+    // (4-row blocks, as the batches of v21_trainer_evaluate take: the same rows meet in the same partial sums, and the
+    //  autoencoder's validation loss is bit for bit the one it reports alone)
+    const char* er = getenv("V21_C32S_ROWS");
+    const int rpw = er && atoi(er) == 8 ? 8 : 4;
+    sa.gs = sb.gs = 1.0f;
+    sa.ncons = sb.ncons = (int)(((n + rpw - 1) / rpw + 7) / 8 * 8);
+    const dim3 grid(2 * sa.ncons), block(64 * kC32sWaves);
+    if (rpw == 4) hipLaunchKernelGGL(train_chain32s_joint_kernel<4>, grid, block, kC32sLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+    else hipLaunchKernelGGL(train_chain32s_joint_kernel<8>, grid, block, kC32sLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+  } else {
+    sa.ncons = sb.ncons = (int)(((n + 31) / 32 + 7) / 8 * 8);
+    sb.blk0 = sa.ncons;
+    sa.npref = sb.npref = chain_prefetchers(2 * sa.ncons, 1);
+    const dim3 grid(2 * sa.ncons + 8 * sa.npref), block(64 * kChainWaves);
+    launch_joint_kernel(ta->prec, ta->gl >= 0, grid, block, st, (const ChainModel*)j->d_tab, sa, sb);
+  }
   HIPCHK(hipGetLastError());
   long long acc[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(&acc[0], ta->d_ticket, sizeof(long long), hipMemcpyDeviceToHost, st));

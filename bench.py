@@ -795,7 +795,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_train and not args.no_extras:
         try:
             out["fit_reference_recipe"] = [fit_leg("f32"), fit_leg("f16")]
-            out["fit_n30000"] = [fit_leg("f16", n_train=30000), fit_leg("f16", n_train=30000, joint=True)]
+            out["fit_n30000"] = [fit_leg("f16", n_train=30000), fit_leg("f16", n_train=30000, joint=True),
+                                 fit_leg("f32", n_train=30000), fit_leg("f32", n_train=30000, joint=True)]
         except Exception as e:
             out["fit_reference_recipe"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:

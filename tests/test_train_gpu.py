@@ -976,7 +976,7 @@ def test_joint_step_is_phase_two_when_the_encoder_is_frozen(ctx):
         native.Joint(tra, native.Trainer(st32, "f32", batch), latent_layer=1)
 
 
-@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("prec", ["f16", "bf16", "f32"])
 def test_joint_step_full_width_against_the_oracle(ctx, prec):
     """BASELINE configs[2] at its real widths: autoencoder 451 -> 352 -> 9 -> 32 -> 352 -> 451 + latent emulator
     7 -> [352, 352, 352, 224] -> 9, batch 256 with a partial last batch (600 rows = 256 + 256 + 88).
@@ -984,7 +984,8 @@ def test_joint_step_full_width_against_the_oracle(ctx, prec):
         against the float64 oracle's fit on the oracle's latents, and the autoencoder must not move;
     (b) both models training: the autoencoder's half is bit-identical to the autoencoder trained alone (the two
         families of row blocks share nothing), and the emulator's first-step loss is its float64 loss against the
-        encoder's latents of that step."""
+        encoder's latents of that step.
+    f32 (the reference's arithmetic; csrc/train_chain32s.h: train_chain32s_joint_kernel): the same at the f32 tolerances."""
     native, synth = pkg("_native"), pkg("synth")
     n, batch = 600, 256
     sig = synth.make_signals(n, seed=5)
@@ -1001,7 +1002,7 @@ def test_joint_step_full_width_against_the_oracle(ctx, prec):
         h = np.maximum(h, 0) if a_ else h
     z = h                                                     # the oracle's latents of the initial encoder
     wz = ora.mse_row_weight(z.astype(np.float32)).astype(np.float32)
-    tol_l, tol_n = (5e-3, 3e-2) if prec == "f16" else (4e-2, 1e-1)
+    tol_l, tol_n = {"f16": (5e-3, 3e-2), "bf16": (4e-2, 1e-1), "f32": (5e-5, 2e-3)}[prec]
 
     def trainer(dims, act, Ws, bs, lr):
         st = native.Stack(ctx, dims, act)
@@ -1027,7 +1028,7 @@ def test_joint_step_full_width_against_the_oracle(ctx, prec):
     w0 = ora.flatten_params(We, be).astype(np.float64)
     dj, do = ste.get_weights() - w0, ora.flatten_params(W, b) - w0
     cos = float(dj @ do / (np.linalg.norm(dj) * np.linalg.norm(do)))
-    assert cos > (0.99 if prec == "f16" else 0.9) and abs(np.linalg.norm(dj) / np.linalg.norm(do) - 1) < tol_n, cos
+    assert cos > {"f16": 0.99, "bf16": 0.9, "f32": 0.9999}[prec] and abs(np.linalg.norm(dj) / np.linalg.norm(do) - 1) < tol_n, cos
     assert tra.get_state()[0] == tre.get_state()[0] == 6
     # the one-launch validation of both models (v21_joint_eval): the autoencoder's is its own forward-only pass, bit for
     # bit; the emulator's is its loss against the (frozen) encoder's latents of the validation signals
@@ -1037,7 +1038,7 @@ def test_joint_step_full_width_against_the_oracle(ctx, prec):
     assert va == tra.evaluate(1, batch)
     tre.set_data(1, par[:nv], z[:nv].astype(np.float32), wz[:nv])
     vx = tre.evaluate(1, batch)
-    assert abs(ve - vx) / vx < (3e-3 if prec == "f16" else 3e-2), (ve, vx)
+    assert abs(ve - vx) / vx < {"f16": 3e-3, "bf16": 3e-2, "f32": 2e-5}[prec], (ve, vx)
     # ---- (b) both models training
     sta, tra = trainer(ae_dims, ae_act, Wa, ba, 1e-3)
     ste, tre = trainer(em_dims, em_act, We, be, 1e-3)
@@ -1097,13 +1098,15 @@ def test_joint_step_with_a_variational_autoencoder(ctx):
     assert float(d1 @ d2 / (np.linalg.norm(d1) * np.linalg.norm(d2))) > 0.995
 
 
-def test_autoencoder_emulator_joint_training_through_the_class_surface(ctx):
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_autoencoder_emulator_joint_training_through_the_class_surface(ctx, prec):
     """AutoEncoderEmulator.train(joint=True): both histories fill, the models learn, early stopping of the
-    autoencoder freezes it and the emulator goes on (the reference's phase 2), predict works afterwards."""
+    autoencoder freezes it and the emulator goes on (the reference's phase 2), predict works afterwards.  f16 and the
+    reference's arithmetic (f32: train_chain32s_joint_kernel)."""
     synth, emu, optm, cbm = pkg("synth"), pkg("emulator"), pkg("optimizers"), pkg("callbacks")
     data = synth.make_dataset(1200, 200, 100)
     pkg("engine").set_random_seed(3)
-    ae = emu.AutoEncoderEmulator(precision="f16", enc_hidden_dims=[64], dec_hidden_dims=[32, 64], em_hidden_dims=[64, 64], **data)
+    ae = emu.AutoEncoderEmulator(precision=prec, enc_hidden_dims=[64], dec_hidden_dims=[32, 64], em_hidden_dims=[64, 64], **data)
     ae.autoencoder.compile(optimizer=optm.Adam(2e-3), loss=emu.relative_mse_loss(ae.signal_train))
     ae.emulator.compile(optimizer=optm.Adam(2e-3), loss=emu.mean_squared_error)
 
