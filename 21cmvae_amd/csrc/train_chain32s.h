@@ -26,8 +26,8 @@
 // path's 63 B/clk), 18-19 k together; the six small layers, the gather and the loss are ~25 k of fixed cost.
 // Used for f32 trainers whose max_batch is <= kC32sMaxBatch (a trainer commits to ONE packed-stream format: this
 // kernel's `cprec = 4` streams, or the 16-row kernel's).  Same ChainModel / ChainStep blocks (ChainLayer::KS / NS =
-// fragments per 64-wide tile, NT / KT = 64-wide tiles); training and validation (fwd_only); no FORWARD mode, no
-// variational layer.
+// fragments per 64-wide tile, NT / KT = 64-wide tiles); training and validation (fwd_only); the variational head
+// (sampled latent + KL, as train_chain.h) since the end of r3; no FORWARD mode.
 #pragma once
 #include "train_chain32.h"
 
@@ -58,7 +58,7 @@ constexpr int kC32sMaskBytes = kC32sMaskTiles * 64 * 2;
 constexpr int kC32sPartBytes = kC32sWaves * 64 * 8 * 4;  // partial tiles of a split contraction: [wave][lane][8 floats]
 constexpr int kC32sZPitch = 2 * kChainMaxLatent + 4;  // joint step: the encoder's latents of the block's rows (fp32, <= 64 wide)
 constexpr int kC32sZOff = kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes + kC32sWaves * kC32sRows * 4 + kC32sRows * 4 + 64;
-constexpr int kC32sLdsBytes = kC32sZOff + kC32sRows * kC32sZPitch * 4;
+constexpr int kC32sLdsBytes = kC32sZOff + kC32sRows * kC32sZPitch * 4 + kC32sRows * 4;  // ... + kl_weight * KL per row (variational head)
 static_assert(kC32sZOff % 16 == 0, "LDS areas are 16-byte aligned");
 // fragments (4 k each) per 64-feature tile over a contraction range of d, whole chunks of four
 __host__ __device__ constexpr int chain32s_frags(int d) { return ((d + 3) / 4 + 3) / 4 * 4; }
@@ -172,8 +172,11 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   f32x4* part = reinterpret_cast<f32x4*>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes);
   float(*red)[ROWS] = reinterpret_cast<float(*)[ROWS]>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes);
   float* rwl = reinterpret_cast<float*>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes + NW * ROWS * 4);
-  float* zs = reinterpret_cast<float*>(chain_smem + kC32sZOff);  // joint step (train_chain32s_joint_kernel)
+  // joint step (train_chain32s_joint_kernel): the encoder's latents; variational head: (mu | lv) of the block's rows
+  // (a stack has one or the other: v21_joint_create)
+  float* zs = reinterpret_cast<float*>(chain_smem + kC32sZOff);
   constexpr int ZP = kC32sZPitch;
+  float* klb = zs + kC32sRows * ZP;  // kl_weight * KL_i
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -192,6 +195,8 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   struct Job { const f32x4* w; const float* b; int nb; };  // first fragment; bias of the tile (nb features have one)
   typedef const C32sJob __attribute__((address_space(4)))* jobptr;
   const jobptr jobs = (jobptr)(unsigned long long)a.jobs + wave;
+  int gl = -1;  // the variational head (V21_ACT_GAUSS: Dense outputs [z_mean | z_log_var]) or -1
+  for (int l = 0; l + 1 < a.L; ++l) gl = a.lt[l].gauss ? l : gl;
   // (a row is fetched one step before it is used: the scalar loads of a step's row miss the constant cache -- every
   // wave has its own 64 bytes per step -- and ~600 cycles at the head of each of nine steps were exactly that)
   auto row = [&](int r) __attribute__((always_inline)) -> C32sJob {
@@ -471,6 +476,27 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     jnext = row(2 + l);
     chain_barrier();
     cur ^= 1;
+    if (l == gl) {  // z = mu + exp(lv / 2) eps replaces mu in the image ((mu | lv) kept for the backward pass); KL_i -> the row's loss
+      // one (batch row, latent dimension) per thread; the columns past z keep lv: finite values against zero weights
+      const int LAT = a.lt[l].N >> 1;
+      float* img = buf[cur];
+      float* kls = reinterpret_cast<float*>(part);  // (free between two steps)
+      const int row = tid & (ROWS - 1), d = tid / ROWS;
+      if (d < LAT) {
+        const float mu = img[row * PITCH + d], lv = img[row * PITCH + LAT + d];
+        const float sd = expf(0.5f * lv);
+        const float e = a.sample ? gauss_eps(a.seed, a.step + st.step_off, st.row0 + m0 + row, d) : 0.f;
+        zs[row * ZP + d] = mu; zs[row * ZP + LAT + d] = lv;
+        img[row * PITCH + d] = mu + sd * e;
+        kls[d * ROWS + row] = -0.5f * (1.0f + lv - mu * mu - sd * sd);
+      }
+      chain_barrier();
+      if (tid < ROWS) {
+        float kl = 0.f;
+        for (int dd = 0; dd < LAT; ++dd) kl += kls[dd * ROWS + tid];  // fixed order
+        klb[tid] = m0 + tid < st.rows ? a.kl_weight * kl : 0.f;
+      }
+    }
     chain_stamp(a, 2 + l);
   }
 
@@ -485,6 +511,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     float sl = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) sl += red[w][tid];
+    if (gl >= 0) sl += klb[tid];
 #pragma unroll
     for (int o = ROWS / 2; o > 0; o >>= 1) sl += __shfl_xor(sl, o, 64);
     if (tid == 0) atomicAdd(a.loss_acc, (unsigned long long)(long long)llrint((double)sl * 4294967296.0));
@@ -492,8 +519,25 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   chain_stamp(a, 2 + a.L);
   if (st.fwd_only) return;
 
+  // dL/dz (latent wide, in `img`) -> dL/d[mu | lv] in place: d mu = dz + beta mu, d lv = dz eps exp(lv / 2) / 2 +
+  // beta (exp lv - 1) / 2, beta = kl_weight / B (the KL term's own gradient) -- train_chain.h: gauss_backward
+  auto gauss_backward = [&](float* img) __attribute__((always_inline)) {
+    const int LAT = a.lt[gl].N >> 1;
+    const int row = tid & (ROWS - 1), d = tid / ROWS;
+    if (d < LAT) {
+      const float mu = zs[row * ZP + d], lv = zs[row * ZP + LAT + d];
+      const float sd = expf(0.5f * lv);
+      const float e = a.sample ? gauss_eps(a.seed, a.step + st.step_off, st.row0 + m0 + row, d) : 0.f;
+      const float g = img[row * PITCH + d];
+      const float kb = m0 + row < st.rows ? st.gs * a.kl_weight * st.inv_b : 0.f;
+      img[row * PITCH + d] = g + kb * mu;
+      img[row * PITCH + LAT + d] = g * e * 0.5f * sd + kb * 0.5f * (sd * sd - 1.0f);
+    }
+    chain_barrier();
+  };
   // ---- backward: layer l consumes dZ_l (in buf[cur]) and produces dZ_{l-1}
   for (int l = a.L - 1; l >= 1; --l) {
+    if (l == gl) gauss_backward(buf[cur]);
     const float* act = buf[cur];
     float* out = buf[cur ^ 1];
     const C32sJob jb = jnext;
@@ -534,6 +578,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
     cur ^= 1;
     chain_stamp(a, 3 + a.L + (a.L - 1 - l));
   }
+  if (gl == 0) gauss_backward(buf[cur]);
   flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
 }
 

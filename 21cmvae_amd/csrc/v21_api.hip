@@ -971,13 +971,15 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
   }
   {  // eligibility of the fp32 chain kernel (train_chain32.h)
     const char* env = getenv("V21_TRAIN_CHAIN");
-    bool ok = precision == V21_PREC_F32 && !(env && env[0] == '0') && t->gl < 0;
+    bool ok = precision == V21_PREC_F32 && !(env && env[0] == '0');
     int mask_tiles = 0;
     for (int l = 0; l <= L && ok; ++l) ok = m->dims[l] <= kChainMaxDim;
     // a trainer of small batches (the reference's 256 rows) takes the 8-row kernel: twice the workgroups, half the
     // matrix work in each (train_chain32s.h); V21_CHAIN32S = 0 / 1 overrides the choice
     const char* es = getenv("V21_CHAIN32S");
     t->chain32s = es ? es[0] == '1' : max_batch <= kC32sMaxBatch;
+    // a variational head: the small-batch kernel carries it (latent <= kChainMaxLatent), the 16-row kernel does not
+    if (t->gl >= 0) ok = ok && t->chain32s && m->dims[t->gl + 1] <= kChainMaxLatent;
     for (int l = 0; l + 1 < L; ++l) mask_tiles += m->act[l] == V21_ACT_RELU ? t->c32_tiles(m->dims[l + 1]) : 0;
     ok = ok && mask_tiles <= (t->chain32s ? kC32sMaskTiles : kC32MaskTiles);
     if (!ok) t->chain32s = false;
@@ -1554,6 +1556,10 @@ static ChainModel chain_model32(v21_trainer* t) {
   a.stamps = t->stamps_on ? t->d_stamps : nullptr;
   a.zcap_layer = -1;
   a.jobs = t->d_jobs;
+  if (t->gl >= 0) {
+    a.lt[t->gl].gauss = 1;
+    a.kl_weight = t->kl_weight; a.sample = t->sample; a.seed = t->seed; a.step = (unsigned long long)t->iter;
+  }
   return a;
 }
 // the 8-row kernel's job table (once per trainer: it depends on the layer widths only)
@@ -2181,6 +2187,7 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
     CHK(ensure_copies(t, false));
     ChainArgs a{};
     static_cast<ChainModel&>(a) = chain_model32(t);
+    a.sample = 0;  // a variational head evaluates z = z_mean (include/v21.h)
     static_cast<ChainStep&>(a) = chain_step(t->d_x[which], din, t->y_is_x[which] ? nullptr : t->d_y[which], dout,
                                             t->d_rw[which], nullptr, 0, (int)n, (int)n, dout);
     a.fwd_only = 1;
@@ -3004,10 +3011,11 @@ extern "C" int v21_joint_eval(v21_joint* j, double* losses) {
   sa.fwd_only = sb.fwd_only = 1;
   sb.y_from_lds = 1;
   if (j->f32) {
-    // (4-row blocks, as the batches of v21_trainer_evaluate take: the same rows meet in the same partial sums, and the
+    // (the row blocks v21_trainer_eval's launch takes for n rows: the same rows meet in the same partial sums, and the
     //  autoencoder's validation loss is bit for bit the one it reports alone)
     const char* er = getenv("V21_C32S_ROWS");
-    const int rpw = er && atoi(er) == 8 ? 8 : 4;
+    const int force_rows = er ? atoi(er) : 0;
+    const int rpw = force_rows == 4 || force_rows == 8 ? force_rows : (n <= kC32sRows4Max ? 4 : 8);
     sa.gs = sb.gs = 1.0f;
     sa.ncons = sb.ncons = (int)(((n + rpw - 1) / rpw + 7) / 8 * 8);
     const dim3 grid(2 * sa.ncons), block(64 * kC32sWaves);

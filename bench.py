@@ -775,6 +775,9 @@ def main():
                     out["train_variational"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
                                                          sync_all, args.train_batch, args.precision, args.train_steps, 20,
                                                          variational=True)
+                    # ... and in the reference's arithmetic at its batch (the variational head inside train_chain32s_kernel)
+                    out["train_variational_ref_batch256_f32"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
+                                                                          sync_all, 256, "f32", 200, 10, variational=True)
             except Exception as e:  # the headline metric must survive a failure of the auxiliary leg
                 out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world > 1:

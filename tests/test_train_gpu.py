@@ -668,8 +668,9 @@ def test_f32_chain_kernel_matches_per_layer_path_and_oracle(ctx, case, rows, mon
 
 def test_chain_path_is_actually_used(ctx):
     """Trainers of stacks up to 512 wide run a chain kernel (its stamps exist): f16 / bf16 (variational heads up to 32
-    latent dimensions) and, from r3 on, f32 without a variational layer (train_chain32.h); wider stacks, wider latents
-    and variational f32 stacks take the per-layer path."""
+    latent dimensions) and, from r3 on, f32 (train_chain32.h; a variational head only on the small-batch kernel of
+    train_chain32s.h); wider stacks, wider latents and variational f32 trainers of more than 2,048 rows per step take the
+    per-layer path."""
     native = pkg("_native")
     st = native.Stack(ctx, [16, 32, 16], [1, 0])
     x = np.zeros((8, 16), np.float32); w = np.ones(8, np.float32)
@@ -683,10 +684,15 @@ def test_chain_path_is_actually_used(ctx):
     s32 = t32.chain_stamps(6)
     assert s32[0] > 0 and np.all(np.diff(s32.astype(np.int64)[:5]) > 0)
     for stack, prec in ((native.Stack(ctx, [16, 600, 16], [1, 0]), "f32"), (native.Stack(ctx, [16, 600, 16], [1, 0]), "f16"),
-                        (native.Stack(ctx, [16, 40, 16], [2, 0]), "bf16"), (native.Stack(ctx, [16, 8, 16], [2, 0]), "f32")):
-        t2 = native.Trainer(stack, prec, 8)
+                        (native.Stack(ctx, [16, 40, 16], [2, 0]), "bf16"), (native.Stack(ctx, [16, 40, 16], [2, 0]), "f32"),
+                        (native.Stack(ctx, [16, 8, 16], [2, 0]), "f32_max_batch_4096")):
+        t2 = native.Trainer(stack, prec[:3] if prec.startswith("f32") else prec, 4096 if prec.endswith("4096") else 8)
         with pytest.raises(native.EngineError):
             t2.enable_stamps()
+    # a variational f32 stack of up to 32 latent dimensions and 2,048 rows per step: the small-batch f32 chain (train_chain32s.h)
+    tv = native.Trainer(native.Stack(ctx, [16, 8, 16], [2, 0]), "f32", 8)
+    tv.set_vae(1e-3, sample=True, seed=3); tv.set_data(0, x, None, w); tv.enable_stamps(); tv.run_epoch(None, 8)
+    assert tv.chain_stamps(6)[0] > 0
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16"])
@@ -723,10 +729,14 @@ def test_data_parallel_arithmetic_without_a_communicator(ctx, prec):
     assert err < tol, err
 
 
-@pytest.mark.parametrize("prec", ["f16", "bf16"])
-def test_variational_stack_on_the_chain_kernel(ctx, prec):
-    """A13 on the one-launch path: sampled latent + KL inside train_chain_kernel, against the float64
-    oracle fed the same counter-based noise, and against the per-layer path in the same precision."""
+@pytest.mark.parametrize("prec", ["f16", "bf16", "f32", "f32_rows8"])
+def test_variational_stack_on_the_chain_kernel(ctx, prec, monkeypatch):
+    """A13 on the one-launch path: sampled latent + KL inside train_chain_kernel (f32: train_chain32s_kernel, both row
+    heights), against the float64 oracle fed the same counter-based noise, and against the per-layer path in the same
+    precision."""
+    if prec.startswith("f32"):
+        monkeypatch.setenv("V21_C32S_ROWS", "8" if prec == "f32_rows8" else "4")
+        prec = "f32"
     import os
     synth = pkg("synth")
     dims = [451, 96, 9, 32, 451]
@@ -760,7 +770,7 @@ def test_variational_stack_on_the_chain_kernel(ctx, prec):
     W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
     lo, go = ora.vae_loss_and_grads(W, b, 1, y.astype(np.float64), y.astype(np.float64), w.astype(np.float64), eps, kl_weight)
     (lc, gc), (ln, gn) = res[True], res[False]
-    ltol, ctol = (3e-3, 0.9995) if prec == "f16" else (3e-2, 0.995)
+    ltol, ctol = {"f16": (3e-3, 0.9995), "bf16": (3e-2, 0.995), "f32": (2e-5, 0.999999)}[prec]
     assert abs(lc - lo) / lo < ltol and abs(lc - ln) / ln < ltol, (lc, ln, lo)
     assert _cos(gc, go) > ctol and _cos(gc, gn) > ctol, (_cos(gc, go), _cos(gc, gn))
     # the KL term's own gradient reaches the z_log_var columns (they get nothing from the decoder when eps = 0)
