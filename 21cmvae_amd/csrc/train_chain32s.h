@@ -173,7 +173,7 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   float(*red)[ROWS] = reinterpret_cast<float(*)[ROWS]>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes);
   float* rwl = reinterpret_cast<float*>(chain_smem + kC32sBufBytes + kC32sYBytes + kC32sMaskBytes + kC32sPartBytes + NW * ROWS * 4);
   // joint step (train_chain32s_joint_kernel): the encoder's latents; variational head: (mu | lv) of the block's rows
-  // (a stack has one or the other: v21_joint_create)
+  // (the encoder pass of a variational autoencoder leaves both at once: the latents ARE z_mean)
   float* zs = reinterpret_cast<float*>(chain_smem + kC32sZOff);
   constexpr int ZP = kC32sZPitch;
   float* klb = zs + kC32sRows * ZP;  // kl_weight * KL_i
@@ -502,8 +502,11 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
 
   if (LF < a.L) {  // joint step, the encoder alone: its last layer's outputs (the image the last barrier completed) are
                    // the targets of the model that follows in this workgroup
-    const int W = a.lt[LF - 1].N;
-    for (int i = tid; i < ROWS * W; i += 64 * NW) zs[(i / W) * ZP + i % W] = buf[cur][(i / W) * PITCH + i % W];
+    // (a variational head: z_mean -- what encoder.predict returns -- is in `zs` already)
+    if (LF - 1 != gl) {
+      const int W = a.lt[LF - 1].N;
+      for (int i = tid; i < ROWS * W; i += 64 * NW) zs[(i / W) * ZP + i % W] = buf[cur][(i / W) * PITCH + i % W];
+    }
     return;
   }
   // ---- loss: lanes -> rows -> workgroup (fixed order) -> one fixed-point atomic per workgroup
@@ -590,7 +593,8 @@ __global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_kernel(const C
 // joint step (train_chain.h: train_chain_joint_kernel; BASELINE configs[2]) in the reference's arithmetic: blocks
 // [0, ncons) carry the autoencoder's row blocks, blocks [ncons, 2 ncons) the emulator's -- first the ENCODER alone on the
 // block's rows (forward layers [0, zcap_layer]; its latents stay in LDS), then the emulator's chain with those latents as
-// targets.  tab[0] = autoencoder, tab[1] = emulator (device memory); no prefetchers, no variational layer.
+// targets.  tab[0] = autoencoder, tab[1] = emulator (device memory); no prefetchers.  The latent layer may be the
+// autoencoder's variational head (the emulator then learns z_mean); the emulator has none.
 template <int ROWS>
 __global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_joint_kernel(const ChainModel* __restrict__ tab, const ChainStep sa, const ChainStep sb) {
   const int b = (int)blockIdx.x;

@@ -2809,10 +2809,10 @@ extern "C" int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_lay
   if (!ae || !em || !out) return fail(V21_ERR_ARG, "null argument");
   if (ae == em || ae->ctx != em->ctx || ae->prec != em->prec || ae->max_batch != em->max_batch)
     return fail(V21_ERR_ARG, "the two trainers must be distinct and share context, precision and max_batch");
-  const bool f32 = ae->chain32s && em->chain32s && ae->gl < 0 && em->gl < 0;
+  const bool f32 = ae->chain32s && em->chain32s && em->gl < 0;
   if (!f32 && (!ae->chain || !em->chain || em->gl >= 0))
     return fail(V21_ERR_UNSUPPORTED, "the joint step runs on the chain kernels: f16 / bf16 (widths <= %d, no variational layer in the emulator), or "
-                "f32 with max_batch <= %d and no variational layer", kChainMaxDim, kC32sMaxBatch);
+                "f32 with max_batch <= %d (variational head: latent <= %d)", kChainMaxDim, kC32sMaxBatch, kChainMaxLatent);
   const v21_mlp* ma = ae->mlp;
   const v21_mlp* me = em->mlp;
   // the latent layer: linear, or the variational head (V21_ACT_GAUSS) -- the emulator then learns z_mean, what

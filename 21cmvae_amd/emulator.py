@@ -336,8 +336,8 @@ class AutoEncoderEmulator(_EmulatorBase):
         reference's second phase.  Keras bookkeeping per model (History, callbacks, epoch losses, validation
         after every epoch -- the emulator's against the current encoder's latents of the validation set).
         Needs mean_squared_error on the emulator; any precision (f32: the reference's arithmetic, batches of up to
-        2,048 rows, no variational layer).  In f16 / bf16 a variational autoencoder
-        (``AutoEncoder(variational=True)``) is fine: the emulator learns z_mean, what ``encoder.predict`` returns.
+        2,048 rows).  A variational autoencoder (``AutoEncoder(variational=True)``) is fine: the emulator learns
+        z_mean, what ``encoder.predict`` returns.
         With a data-parallel communicator on the context every rank trains on its share of every batch."""
         from . import _native as nat, callbacks as cb_mod, engine
         ae, em = self.autoencoder, self.emulator

@@ -188,7 +188,7 @@ int v21_trainer_get_grad(v21_trainer* tr, float* g, size_t n);
  * reference's second phase.  `ae` holds the signals (set_data(0, signals, NULL, w)), `em` the parameters of the
  * same rows (its y argument is ignored); latent_layer = index of the encoder's linear output layer in `ae`'s
  * stack (linear, or the V21_ACT_GAUSS head: the emulator then learns z_mean).  Two f16 / bf16 trainers (chain kernel), or
- * two f32 trainers of max_batch <= 2,048 without a variational layer (the reference's arithmetic); with a
+ * two f32 trainers of max_batch <= 2,048 (the reference's arithmetic); with a
  * communicator on the context every rank carries its share of every batch and each model's gradients are exchanged as
  * in a plain step.  losses[0] = autoencoder, losses[1] = emulator. */
 typedef struct v21_joint v21_joint;

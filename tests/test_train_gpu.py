@@ -1064,8 +1064,9 @@ def test_joint_step_full_width_against_the_oracle(ctx, prec):
     assert np.isfinite(le) and le > 0
 
 
-def test_joint_step_with_a_variational_autoencoder(ctx):
-    """The joint step with a (z_mean | z_log_var) head in the autoencoder: the emulator's targets are z_mean of the
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_joint_step_with_a_variational_autoencoder(ctx, prec):
+    """The joint step with a (z_mean | z_log_var) head in the autoencoder (f16: train_chain.h; f32: train_chain32s.h): the emulator's targets are z_mean of the
     encoder of that step (what encoder.predict returns).  With the autoencoder frozen the emulator's epoch equals a
     separate trainer fed the float64 z_mean; with kl_weight = 0 and no sampling the autoencoder's half equals the
     deterministic autoencoder's."""
@@ -1080,10 +1081,10 @@ def test_joint_step_with_a_variational_autoencoder(ctx):
     sta = native.Stack(ctx, ae_dims, ae_act)
     flat = (np.random.default_rng(3).normal(size=sta.num_params) * 0.05).astype(np.float32)
     sta.set_weights(flat)
-    tra = native.Trainer(sta, "f16", batch); tra.set_adam(lr=0.0); tra.set_vae(1e-3, sample=True, seed=5)
+    tra = native.Trainer(sta, prec, batch); tra.set_adam(lr=0.0); tra.set_vae(1e-3, sample=True, seed=5)
     We, be = ora.init_mlp(em_dims, seed=12)
     ste = native.Stack(ctx, em_dims, em_act); ste.set_weights(ora.flatten_params(We, be))
-    tre = native.Trainer(ste, "f16", batch); tre.set_adam(lr=2e-3)
+    tre = native.Trainer(ste, prec, batch); tre.set_adam(lr=2e-3)
     # float64 z_mean of the (frozen) encoder: Dense 451 -> 64 (ReLU), Dense 64 -> 18, first 9 columns
     o = 0
     W0 = flat[o:o + 451 * 64].reshape(451, 64).astype(np.float64); o += 451 * 64
@@ -1096,16 +1097,16 @@ def test_joint_step_with_a_variational_autoencoder(ctx):
     tre.set_data(0, par, np.zeros((n, 9), np.float32), wz)
     joint = native.Joint(tra, tre, latent_layer=1)
     stx = native.Stack(ctx, em_dims, em_act); stx.set_weights(ora.flatten_params(We, be))
-    trx = native.Trainer(stx, "f16", batch); trx.set_adam(lr=2e-3)
+    trx = native.Trainer(stx, prec, batch); trx.set_adam(lr=2e-3)
     trx.set_data(0, par, zm.astype(np.float32), wz)
     for ep in range(2):
         perm = ora.epoch_permutation(n, 4, ep)
         la, le = joint.run_epoch(perm, batch)
         lx = trx.run_epoch(perm, batch)
-        assert np.isfinite(la) and abs(le - lx) / lx < 3e-3, (ep, le, lx)
+        assert np.isfinite(la) and abs(le - lx) / lx < (3e-3 if prec == "f16" else 2e-5), (ep, le, lx)
     np.testing.assert_array_equal(sta.get_weights(), flat)
     d1, d2 = ste.get_weights() - ora.flatten_params(We, be), stx.get_weights() - ora.flatten_params(We, be)
-    assert float(d1 @ d2 / (np.linalg.norm(d1) * np.linalg.norm(d2))) > 0.995
+    assert float(d1 @ d2 / (np.linalg.norm(d1) * np.linalg.norm(d2))) > (0.995 if prec == "f16" else 0.99999)
 
 
 @pytest.mark.parametrize("prec", ["f16", "f32"])
