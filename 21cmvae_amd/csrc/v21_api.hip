@@ -2371,8 +2371,9 @@ extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** o
       return fail(V21_ERR_ARG, "model %d: context, precision and max_batch must match model 0", k);
     if (m->L != m0->L || m->act != m0->act || m->dims[0] != m0->dims[0] || m->dims[m->L] != m0->dims[m0->L])
       return fail(V21_ERR_ARG, "model %d: depth, activations and in/out width must match model 0", k);
-    if (t->gl >= 0 && !t->chain)
-      return fail(V21_ERR_UNSUPPORTED, "variational stacks are swept on the chain path only (f16/bf16, latent <= %d)", kChainMaxLatent);
+    if (t->gl >= 0 && !t->chain && !(t->chain32 && t->chain32s))
+      return fail(V21_ERR_UNSUPPORTED, "variational stacks are swept on the chain kernels only (f16 / bf16, or f32 with max_batch <= %d; latent <= %d)",
+                  kC32sMaxBatch, kChainMaxLatent);
     for (int j = 0; j < k; ++j)
       if (trainers[j] == t) return fail(V21_ERR_ARG, "trainer %d listed twice", k);
   }
@@ -2736,6 +2737,11 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
   bool group32 = s->chain32s && R == 1 && batch <= kDw32MaxRows && !(getenv("V21_SWEEP32_GROUP") && getenv("V21_SWEEP32_GROUP")[0] == '0');
   int max_blocks32 = 0;
   if (group32) CHK(refresh_dw32_table(s->tr, s->d_dw32, s->h_dw32, &max_blocks32, &group32, st));
+  if (!s->chain && !group32)
+    for (v21_trainer* t : s->tr)
+      if (t->gl >= 0)
+        return fail(V21_ERR_UNSUPPORTED, "a sweep of variational f32 models takes the grouped chain launches only: one rank, batches of <= %d rows",
+                    kDw32MaxRows);
   if (group32) {
     std::vector<ChainModel> tab;
     for (v21_trainer* t : s->tr) {
@@ -2765,6 +2771,7 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
       ChainStep cs = chain_step(t0->d_x[0], din, t0->y_is_x[0] ? nullptr : t0->d_y[0], dout, t0->d_rw[0], d_idx, lo, rows,
                                 brows, dout, nullptr, lo - first);
       cs.gs = 1.0f;  // fp32 operands: no scaling of the gradients
+      cs.step_off = (unsigned long long)sidx;  // the table holds every model's step counter as of the epoch's start (noise key)
       CHK(sweep_step_chain32(s, cs, sidx, max_blocks32));
       continue;
     }
