@@ -55,7 +55,14 @@ cp $OUT/fwd/f_kernel_stats.csv $OUT/kernel_stats_forward_routes.csv
 # the joint step (configs[2]) against the two models one after the other
 rocprofv3 --kernel-trace --stats -d $OUT/joint -o j --output-format csv -- $PY $ROOT/scripts/joint_probe.py > $OUT/joint_probe.txt 2>&1
 cp $OUT/joint/j_kernel_stats.csv $OUT/kernel_stats_joint_b256_f16.csv
-echo "forward + joint done"
+rocprofv3 --kernel-trace --stats -d $OUT/joint32 -o j --output-format csv -- $PY $ROOT/scripts/joint_probe.py f32 > $OUT/joint_probe_f32.txt 2>&1
+cp $OUT/joint32/j_kernel_stats.csv $OUT/kernel_stats_joint_b256_f32.csv
+# the sweep of 8 autoencoder configs (BASELINE configs[4]): grouped launches against the members one by one, f16 and f32
+for pr in f16 f32; do
+  rocprofv3 --kernel-trace --stats -d $OUT/sweep_$pr -o s --output-format csv -- $PY $ROOT/scripts/sweep_probe.py $pr 3 > $OUT/sweep_probe_$pr.txt 2>&1
+  cp $OUT/sweep_$pr/s_kernel_stats.csv $OUT/kernel_stats_sweep_b256_$pr.csv
+done
+echo "forward + joint + sweep done"
 # 3b. is the headline kernel clock-bound?  the same launches on random and on all-zero operands
 cd $ROOT
 $PY scripts/power_probe.py > $OUT/power_probe_fused_random_vs_zero_operands.txt 2>&1
@@ -74,5 +81,5 @@ V21_LIB=$ROOT/21cmvae_amd/libv21_fine.so $PY scripts/diag/dwadam_stamps.py 4096 
 [ -x scripts/diag/cold_stream_probe ] && scripts/diag/cold_stream_probe > $OUT/cold_stream_probe.txt 2>&1
 [ -x scripts/diag/chain_loop_probe ] && scripts/diag/chain_loop_probe > $OUT/chain_loop_probe.txt 2>&1
 rm -rf $OUT/t256r16 $OUT/t256r8
-rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t4096 $OUT/t256 $OUT/t256h $OUT/t16k $OUT/tpmc_* $OUT/sq_* $OUT/fwd $OUT/joint
+rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t4096 $OUT/t256 $OUT/t256h $OUT/t16k $OUT/tpmc_* $OUT/sq_* $OUT/fwd $OUT/joint $OUT/joint32 $OUT/sweep_f16 $OUT/sweep_f32
 ls -la $OUT
