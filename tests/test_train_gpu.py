@@ -922,13 +922,14 @@ def test_latent_emulator_full_width_mse_matches_oracle(ctx, prec):
     assert tr.get_state()[0] == 6
 
 
-def test_joint_step_is_phase_two_when_the_encoder_is_frozen(ctx):
+@pytest.mark.parametrize("prec,batch", [("f16", 128), ("f32", 128), ("f32", 300)])
+def test_joint_step_is_phase_two_when_the_encoder_is_frozen(ctx, prec, batch):
     """v21_joint_*: with the autoencoder's learning rate at 0 a joint epoch must be the reference's second phase
     (emulator.py:753-764): the emulator trained on encoder(x) of exactly its batch rows.  Checked against (a) the
     float64 oracle's fit on the oracle's latents, (b) a separate device trainer fed those latents; the
     autoencoder must not move and must report the loss it reports alone."""
     native, synth = pkg("_native"), pkg("synth")
-    n, batch = 300, 128
+    n = 300   # (batch 300, f32: one step per epoch, more rows than the one-launch gradient kernel of dw_adam32.h takes)
     sig = synth.make_signals(n, seed=5)
     y = ora.preproc(sig, sig)
     par = rng_par = np.random.default_rng(8).uniform(-1, 1, size=(n, 7)).astype(np.float32)
@@ -948,7 +949,7 @@ def test_joint_step_is_phase_two_when_the_encoder_is_frozen(ctx):
     def trainer(dims, act, Ws, bs, lr):
         st = native.Stack(ctx, dims, act)
         st.set_weights(ora.flatten_params(Ws, bs))
-        tr = native.Trainer(st, "f16", batch)
+        tr = native.Trainer(st, prec, batch)
         tr.set_adam(lr=lr)
         return st, tr
     sta, tra = trainer(ae_dims, ae_act, Wa, ba, 0.0)        # frozen autoencoder
@@ -969,21 +970,21 @@ def test_joint_step_is_phase_two_when_the_encoder_is_frozen(ctx):
         W, b, hist = ora.fit(W, b, sto, par.astype(np.float64), z, wz.astype(np.float64), 1, batch, seed=9, dtype=np.float64,
                              start_epoch=ep)
         assert la == tra2.run_epoch(perm, batch)                      # the autoencoder half is the plain chain step
-        assert abs(le - hist["loss"][0]) / hist["loss"][0] < 5e-3, (ep, le, hist["loss"][0])
-        assert abs(le - lx) / lx < 2e-3, (ep, le, lx)                 # latents from f16 operands vs fp64: tiny shift
+        assert abs(le - hist["loss"][0]) / hist["loss"][0] < (5e-3 if prec == "f16" else 5e-5), (ep, le, hist["loss"][0])
+        assert abs(le - lx) / lx < (2e-3 if prec == "f16" else 2e-5), (ep, le, lx)   # latents from f16 operands vs fp64: tiny shift
     np.testing.assert_array_equal(sta.get_weights(), ora.flatten_params(Wa, ba))   # lr = 0: untouched
     w0 = ora.flatten_params(We, be).astype(np.float64)
     dj, dx, do = (ste.get_weights() - w0), (stx.get_weights() - w0), (ora.flatten_params(W, b) - w0)
     for d, what in ((dx, "separate trainer"), (do, "oracle")):
         cos = float(dj @ d / (np.linalg.norm(dj) * np.linalg.norm(d)))
-        assert cos > 0.995 and abs(np.linalg.norm(dj) / np.linalg.norm(d) - 1) < 2e-2, (what, cos)
-    assert tra.get_state()[0] == tre.get_state()[0] == 6
+        assert cos > (0.995 if prec == "f16" else 0.9999) and abs(np.linalg.norm(dj) / np.linalg.norm(d) - 1) < (2e-2 if prec == "f16" else 2e-3), (what, cos)
+    assert tra.get_state()[0] == tre.get_state()[0] == 2 * -(-n // batch)
     # argument checks
     with pytest.raises(native.EngineError):
         native.Joint(tra, tre, latent_layer=0)      # a ReLU layer, and 48 wide: not the emulator's output
     st32 = native.Stack(ctx, em_dims, em_act)
-    with pytest.raises(native.EngineError):
-        native.Joint(tra, native.Trainer(st32, "f32", batch), latent_layer=1)
+    with pytest.raises(native.EngineError):      # the two trainers must share a precision
+        native.Joint(tra, native.Trainer(st32, "f32" if prec == "f16" else "f16", batch), latent_layer=1)
 
 
 @pytest.mark.parametrize("prec", ["f16", "bf16", "f32"])
