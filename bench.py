@@ -711,7 +711,7 @@ def main():
             out["sweep"] = sweep_leg(native, ctx, args.precision)
         except Exception as e:
             out["sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if rank == 0 and args.precision != "f32":  # the same sweep in the reference's arithmetic (grouped launches of train_chain32s.h / dw_adam32.h)
+        if args.precision != "f32":  # the same sweep in the reference's arithmetic (grouped launches of train_chain32s.h / dw_adam32.h); every rank, like the leg above
             try:
                 out["sweep_f32"] = sweep_leg(native, ctx, "f32")
             except Exception as e:
