@@ -480,7 +480,9 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
       // one (batch row, latent dimension) per thread; the columns past z keep lv: finite values against zero weights
       const int LAT = a.lt[l].N >> 1;
       float* img = buf[cur];
-      float* kls = reinterpret_cast<float*>(part);  // (free between two steps)
+      // (KL terms in the first ROWS * LAT <= 256 floats of the partial-tile area: that is wave 0's own 2 KB of it, and
+      //  wave 0 -- whose first lanes sum the terms below -- writes partial tiles there only afterwards, in program order)
+      float* kls = reinterpret_cast<float*>(part);
       const int row = tid & (ROWS - 1), d = tid / ROWS;
       if (d < LAT) {
         const float mu = img[row * PITCH + d], lv = img[row * PITCH + LAT + d];
