@@ -1,11 +1,14 @@
-"""Randomised cross-check of the device paths against the float64 oracle (run on a GPU box; not part of the
-test suite: tests/ holds the fixed cases).  Forward: fused / small-batch / generic; training: chain and
+"""Randomised cross-check of the device paths against the float64 oracle (run on a GPU box: `python tests/fuzz_paths.py
+SEED CASES`; not collected by pytest -- the test_*.py files hold the fixed cases; it lives under tests/ because only test
+code may import oracle/).  Forward: fused / small-batch / generic; training: chain and
 per-layer paths, random depths, widths, batch sizes and activations.  f32 training runs the fp32 chain
 (train_chain32.h / train_chain32s.h) since r3, FWD_NO_SMALL on a stack without a compiled kernel the chain kernels in
 FORWARD mode.  Known, benign: f16 / bf16 training cases with ONE or TWO rows may report a gradient direction of 0.995-0.999
 against the float64 oracle -- a hidden unit whose pre-activation rounds to the other side of the ReLU kink in 16 bits flips
 its whole column of the weight gradient, and with one row nothing averages it out (1 / width of the direction per flip).
-Seeds 5, 11, 21, 31, 32 x 40-150 cases in r3: no other mismatch on any path."""
+Seeds 5, 11, 21, 31, 32 x 40-150 cases in r3: no other mismatch on any path.  End of r3, with the 4- and 8-row forms of the
+small-batch f32 chain and the variational head (f32 both row heights, f16) among the cases: seeds 41, 42, 51, 77 x 60-150
+cases, again only one-row 16-bit cases (3 of 350)."""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -57,4 +60,32 @@ for case in range(ncase):
         ltol = 1e-4 if prec == "f32" else (2e-2 if prec == "f16" else 1e-1)
         if not (c > ctol and abs(loss - lo) / lo < ltol):
             bad += 1; print("TRAIN MISMATCH", prec, dims, act, n, "cos", c, "loss", loss, lo)
+    # a variational head somewhere below the last layer (latent <= 32): f32 on the small-batch chain (train_chain32s.h,
+    # both row heights), f16 on train_chain.h -- against the float64 oracle fed the same counter-based noise
+    if L >= 2:
+        gl = int(rng.integers(0, L - 1))
+        vd = list(dims); vd[gl + 1] = int(rng.integers(1, 33))
+        vact = [2 if l == gl else (1 if l < L - 1 else 0) for l in range(L)]   # (the oracle's variational stack: ReLU on every other hidden layer)
+        vW, vb = [], []
+        for l in range(L):
+            nout = vd[l + 1] * (2 if l == gl else 1)
+            vW.append(ora.glorot_uniform(rng, vd[l], nout)); vb.append(rng.normal(scale=0.05, size=nout).astype(np.float32))
+        vflat = ora.flatten_params(vW, vb)
+        xv = rng.normal(size=(n, vd[0])).astype(np.float32); yv = rng.normal(size=(n, vd[-1])).astype(np.float32)
+        klw, seed, it0 = float(rng.choice([0.0, 1e-3, 1e-2])), int(rng.integers(1, 2**40)), int(rng.integers(0, 50))
+        eps = ora.gauss_eps(seed, it0, n, vd[gl + 1])
+        lo, go = ora.vae_loss_and_grads([a.astype(np.float64) for a in vW], [a.astype(np.float64) for a in vb], gl,
+                                        xv.astype(np.float64), yv.astype(np.float64), w.astype(np.float64), eps, klw)
+        for prec, rows, ctol, ltol in (("f32", "4", 0.999999, 1e-4), ("f32", "8", 0.999999, 1e-4), ("f16", "", 0.998, 2e-2)):
+            if rows:
+                os.environ["V21_C32S_ROWS"] = rows
+            st3 = native.Stack(ctx, vd, vact); st3.set_weights(vflat)
+            tr = native.Trainer(st3, prec, max(n, 2)); tr.set_adam(lr=0.0); tr.set_vae(klw, sample=True, seed=seed); tr.set_state(it0)
+            tr.set_data(0, xv, yv, w)
+            loss = tr.run_epoch(None, n)
+            g = tr.get_grad().astype(np.float64)
+            c = float(g @ go / (np.linalg.norm(g) * np.linalg.norm(go) + 1e-300))
+            if not (c > ctol and abs(loss - lo) / abs(lo) < ltol):
+                bad += 1; print("VARIATIONAL MISMATCH", prec, rows, vd, vact, n, "cos", c, "loss", loss, lo)
+        os.environ.pop("V21_C32S_ROWS", None)
 print("cases %d, mismatches %d" % (ncase, bad))
