@@ -12,7 +12,8 @@
 // q ^ (r & 15) -- sixteen rows, sixteen different 16-byte bank groups.  The four waves split the batch, the partial tiles
 // meet in the same 64 KB (the operands are dead by then), and the epilogue is gemm_nt.h's: Adam on the tile's arena
 // elements (their m, v, w requested before the operands), the 8-row format's packed words as 16-byte stores.
-// One workgroup per 32 x 32 tile of [dW; db]; K = rows of the step <= 256 (larger steps: gemm_nt_dwadam_kernel).
+// One workgroup per 32 x 32 tile of [dW; db]; K = rows of the step; steps of more than 256 rows pass through the same 64 KB
+// in slabs of 256 rows (end of r3: 512 rows 51.3 -> 48.4 us per step, 1,024 rows 69.2 -> 60.9, 2,048 rows 90.0 -> 81.8).
 // (Measured and dropped: the same whole rows through REGISTERS -- sixteen coalesced 16-byte loads per lane, then sixteen
 // ds_write_b128 at the swizzled positions; bit-identical, 43.3-43.4 against 42.9-43.0 us per step at batch 256.  The
 // ~280 cycles per row request are not the LDS-DMA mechanism: the rows were written by the chain kernel a launch ago and
@@ -22,7 +23,7 @@
 
 namespace v21 {
 
-constexpr int kDw32MaxRows = 256;
+constexpr int kDw32MaxRows = 2048;  // (slabs of 256 rows; = kC32sMaxBatch, the largest step of the trainers whose stream format it writes)
 
 #ifdef V21_CHAIN_FINE  // (diagnostic build: phase stamps of a few workgroups, scripts/diag/dwadam_stamps.py)
 #define D32FINE(i) do { if ((threadIdx.x & 63) == 0 && ad.dbg && (blk % 47) == 0 && blk / 47 < 8) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ad.dbg[((blk / 47) * 8 + (i)) * 4 + (threadIdx.x >> 6)] = t_; } } while (0)
@@ -85,12 +86,22 @@ __device__ __forceinline__ void dwadam32_body(const NtGroupBig& grp, const NtAda
   // (Phase stamps: the kernel-argument batch is read at ~2.1 k cycles, the Adam state requested at ~2.7 k, and the
   // sixteen row loads of a wave take until ~7.1 k to ISSUE -- ~280 cycles each, whether a row costs 30 instructions or 15,
   // and whether or not the table of first blocks is preloaded into SGPRs: the LDS-DMA requests themselves are paced.)
+  // Steps of more than 256 rows: the batch passes through the same 64 KB in SLABS of 256 rows (stage, contract, next slab;
+  // the accumulator stays in registers) -- one launch for any step a small-batch f32 trainer takes (<= 2,048 rows).
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const float* arow = smem + li * 256;
+  const float* brow = smem + (32 + li) * 256;
+  const int swz = li & 15;
+  for (int koff = 0; koff < K; koff += 256) {
+  if (koff > 0) __syncthreads();  // every wave is done with the previous slab
   unsigned voffA[4], voffB[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int c = lane ^ (wave + 4 * j);
-    voffA[j] = 4 * c + 4 > lda ? 0u : 16u * c;  // (past the row: any valid address; those k are >= K and zeroed below)
-    voffB[j] = 4 * c + 4 > ldb ? 0u : 16u * c;
+    voffA[j] = koff + 4 * c + 4 > lda ? 0u : 4u * koff + 16u * c;  // (past the row: any valid address; those k are >= K and zeroed below)
+    voffB[j] = koff + 4 * c + 4 > ldb ? 0u : 4u * koff + 16u * c;
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -109,24 +120,19 @@ __device__ __forceinline__ void dwadam32_body(const NtGroupBig& grp, const NtAda
   D32FINE(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // ---- contraction: wave w takes its quarter of the k-steps of 8
-  const int nsteps = (K + 7) >> 3, per = (nsteps + 3) >> 2;
+  // ---- contraction: wave w takes its quarter of the slab's k-steps of 8
+  const int nsteps = (min(K - koff, 256) + 7) >> 3, per = (nsteps + 3) >> 2;
   const int s0 = wave * per, s1 = min(nsteps, s0 + per);
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const float* arow = smem + li * 256;
-  const float* brow = smem + (32 + li) * 256;
-  const int swz = li & 15;
   for (int s = s0; s < s1; ++s) {
     const int q = ((2 * s + lh) ^ swz) << 2;
     f32x4v a4 = *reinterpret_cast<const f32x4v*>(arow + q), b4 = *reinterpret_cast<const f32x4v*>(brow + q);
-    const int kk = 8 * s + 4 * lh;
+    const int kk = koff + 8 * s + 4 * lh;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (kk + e >= K) { a4[e] = 0.f; b4[e] = 0.f; }  // (select, not multiply: the padding may hold anything)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
     }
+  }
   }
   D32FINE(2);
   __syncthreads();  // every wave is done with the operand rows: the partial tiles take their place

@@ -1858,7 +1858,14 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
       a.gs = 1.0f;  // fp32 operands: no scaling of the gradients
       CHK(launch_chain32_args(a, st, t->chain32s));
     }
-    int nslice = (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
+    // one rank, a step of <= kDw32MaxRows rows, 32 x 32 tiles: gradients, Adam, packed streams and batch loss in ONE
+    // launch whose workgroups walk the whole batch in slabs of 256 rows (dw_adam32.h)
+    static const bool lds_rows = !(getenv("V21_DW32_LDS") && getenv("V21_DW32_LDS")[0] == '0');
+    static const bool fused_ok = !(getenv("V21_DW32_ADAM") && getenv("V21_DW32_ADAM")[0] == '0');
+    long long work = 0;
+    for (int l = 0; l < L; ++l) work += (long long)((m->dims[l] + 1 + 63) / 64) * ((m->nw(l) + 63) / 64);
+    const bool dw32 = single && fused_ok && lds_rows && L <= kNtMaxGroup && work < 192 && rows <= kDw32MaxRows;
+    int nslice = dw32 ? 1 : (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
     const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
     nslice = (rows + k_chunk - 1) / k_chunk;
     std::vector<NtArgs> probs;
@@ -1873,13 +1880,11 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
     }
     // (one contraction slice = up to kNtMaxKPerWg rows.  Letting one workgroup walk 1,024 or 2,048 rows instead of the
     //  sliced three-launch path below: 71.3 against 70.6 us and 96.7 against 92.8 us per step -- no gain.)
-    if (single && nslice == 1 && L <= kNtMaxGroup && !(getenv("V21_DW32_ADAM") && getenv("V21_DW32_ADAM")[0] == '0')) {
+    if (single && nslice == 1 && L <= kNtMaxGroup && fused_ok) {
       // one rank, the batch is one contraction slice: gradients, Adam, the packed fp32 streams and the batch loss in ONE
       // launch (gemm_nt.h: NtAdamInfo) -- the step is 2 launches
       NtGroupBig grp{};
       grp.count = L;
-      long long work = 0;
-      for (int l = 0; l < L; ++l) work += (long long)((probs[l].M + 63) / 64) * ((probs[l].N + 63) / 64);
       const int T = work >= 192 ? 2 : 1;
       int blocks = 0;
       NtAdamInfo ad{};
@@ -1906,7 +1911,6 @@ static int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, 
 #ifdef V21_CHAIN_FINE
       ad.dbg = t->stamps_on ? t->d_stamps + 1024 : nullptr;
 #endif
-      static const bool lds_rows = !(getenv("V21_DW32_LDS") && getenv("V21_DW32_LDS")[0] == '0');
       if (T == 2) hipLaunchKernelGGL(gemm_nt_dwadam_kernel<2>, dim3(blocks), dim3(256), 0, st, grp, ad);
       else if (rows <= kDw32MaxRows && lds_rows) hipLaunchKernelGGL(dwadam32_kernel, dim3(blocks), dim3(256), 0, st, grp, ad);  // operands through LDS in whole rows (dw_adam32.h)
       else hipLaunchKernelGGL(gemm_nt_dwadam_kernel<1>, dim3(blocks), dim3(256), 0, st, grp, ad);
