@@ -1,5 +1,5 @@
 // dw_adam32.h -- every weight gradient of an f32 chain step + Adam + the packed fp32 streams + the batch loss, for steps of
-// up to 256 rows: the operands pass through LDS in whole rows (gfx950).
+// up to 2,048 rows: the operands pass through LDS in whole rows, 256 batch rows at a time (gfx950).
 //
 // gemm_nt_dwadam_kernel (gemm_nt.h) loads its MFMA operands straight into registers: lane (li, lh) of a wave takes 16
 // bytes of feature row li, so ONE wave instruction touches 32 rows x 32 bytes -- 32 cache lines for 1 KiB, and the CU's
