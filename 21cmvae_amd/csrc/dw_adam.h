@@ -102,7 +102,8 @@ __device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int 
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   DWFINE(1);
-  // Rounds of U steps (2 U fragments, 16 KiB in flight per wave).  A rolling refill of each consumed slot was
+  // Rounds of U steps (2 U fragments, 16 KiB in flight per wave).  (U = 10: 128 VGPRs, the step unchanged -- 44.4-44.5
+  // against 44.0-44.5 us at 4,096 rows; U = 12: 132 VGPRs, one workgroup per CU, 48.3 us.)  A rolling refill of each consumed slot was
   // measured SLOWER (19.3 vs 16.9 us at batch 4,096): the kernel is bound by the bytes one CU can pull (~55 GB/s
   // when most lines come from beyond L2; 666 KB per CU at batch 4,096), not by the round trips.
   // (r3: 64 x 32 tiles -- two A-tiles against one B-tile per workgroup, the B fragments loaded once for two MFMAs:
