@@ -72,6 +72,9 @@ inline C32sSplit c32s_split(int tiles, int nch) {
   // 4 x 4 x 1 MFMA against 8.4 with four, scripts/diag/mfma4_rate_probe.hip) and costs the meeting of the partial tiles
   // (a second barrier, the sum, ~700 cycles).  Wave w sits on SIMD w % 4: the layer lasts as long as its busiest SIMD,
   // or as one wave's chunks end to end (a chunk's loads are issued one chunk ahead: ~600 cycles from issue to use).
+  // (The constants are the 8-row form's; with the 4-row form's 16 MFMAs per chunk the model would also split the 8-tile
+  // 352 -> 451 layer into 16 units of 11 chunks -- measured: 14.6-15.0 k cycles against 13.9 k unsplit.  Eight waves
+  // already move that layer's weights at 50 B/clk; the meeting of the partial tiles is all the split adds.)
   const int kChunkCycles = 32 * 9, kChunkLatency = 600, kMeetCycles = 700;
   int max_parts = kC32sWaves / tiles;
   if (max_parts > nch) max_parts = nch;
