@@ -315,7 +315,12 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   // gain, 44.3 against 43.3 us at batch 256 (4 rows), 93.7 against 90.0 at 2,048 (8 rows).  The steady state is the same
   // sequence of requests, and what a unit saves at its start it pays where the exchange, and the bias values requested an
   // unknown number of loads earlier, make hipcc wait for everything in flight.  The big layers move their weights at
-  // 47-51 B/clk; the same two-buffer loop alone reaches 56 (scripts/diag/chain_loop_probe.hip), a pure stream 63.)
+  // 47-51 B/clk; the same two-buffer loop alone reaches 56 (scripts/diag/chain_loop_probe.hip), a pure stream 63.
+  // THREE buffers in the 4-row form -- two chunks in flight per wave, the job row naming the wave's next three chunks, the
+  // buffers rotated back by selects at the head of a unit (under control flow hipcc kept two of them in scratch memory:
+  // 335 k cycles): 126 VGPRs, nothing spilled, and slower: 74.5 k cycles against 66 k, the unsplit 8-tile layer
+  // (22 chunks per wave end to end) 14.2 k against 13.9 k.  What looked like one round trip per chunk is the CU's load
+  // path at ~50 B/clk, shared by the waves that stream.)
   auto contract = [&](const f32x4* wsrc, const float* act, int nch, f32x4 (&acc)[G], const Job nxt, int f0) __attribute__((always_inline)) -> bool {
     const float* ap = act + jr * PITCH + 4 * f0;
     load_bias(nxt, bnext);  // (the caller has consumed this unit's values)
