@@ -164,7 +164,9 @@ inline void c32s_build_jobs(const ChainModel& a, C32sJob* tab) {
 
 // ROWS = 8: two groups of four rows share every weight word (two MFMAs per word); ROWS = 4: one group -- twice the
 // workgroups, half the matrix work in each, the same weight stream through each CU (the LDS carve-up stays the 8-row one).
-template <int ROWS>
+// GAUSS = false: a promise of the host that the stack has no variational head -- its code folds away (with it compiled in,
+// a plain autoencoder's step took 44.5 instead of 42.9 us at batch 256: 67 k against 63 k cycles of the chain).
+template <int ROWS, bool GAUSS>
 __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const ChainStep& st, const int bidx) {
   static_assert(ROWS == 4 || ROWS == 8, "one or two groups of four rows");
   constexpr int NW = kC32sWaves, PITCH = kC32Pitch, G = ROWS / 4;
@@ -199,7 +201,8 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   typedef const C32sJob __attribute__((address_space(4)))* jobptr;
   const jobptr jobs = (jobptr)(unsigned long long)a.jobs + wave;
   int gl = -1;  // the variational head (V21_ACT_GAUSS: Dense outputs [z_mean | z_log_var]) or -1
-  for (int l = 0; l + 1 < a.L; ++l) gl = a.lt[l].gauss ? l : gl;
+  if constexpr (GAUSS)
+    for (int l = 0; l + 1 < a.L; ++l) gl = a.lt[l].gauss ? l : gl;
   // (a row is fetched one step before it is used: the scalar loads of a step's row miss the constant cache -- every
   // wave has its own 64 bytes per step -- and ~600 cycles at the head of each of nine steps were exactly that)
   auto row = [&](int r) __attribute__((always_inline)) -> C32sJob {
@@ -595,34 +598,34 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   flush_t(buf[cur], a.lt[0].N, a.lt[0].dzt16, 0);
 }
 
-template <int ROWS>
+template <int ROWS, bool GAUSS = false>
 __global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_kernel(const ChainArgs a) {
   if ((int)blockIdx.x >= a.ncons) { chain_prefetch(a, a); return; }
-  train_chain32s_body<ROWS>(a, a, (int)blockIdx.x - a.blk0);
+  train_chain32s_body<ROWS, GAUSS>(a, a, (int)blockIdx.x - a.blk0);
 }
 // joint step (train_chain.h: train_chain_joint_kernel; BASELINE configs[2]) in the reference's arithmetic: blocks
 // [0, ncons) carry the autoencoder's row blocks, blocks [ncons, 2 ncons) the emulator's -- first the ENCODER alone on the
 // block's rows (forward layers [0, zcap_layer]; its latents stay in LDS), then the emulator's chain with those latents as
 // targets.  tab[0] = autoencoder, tab[1] = emulator (device memory); no prefetchers.  The latent layer may be the
 // autoencoder's variational head (the emulator then learns z_mean); the emulator has none.
-template <int ROWS>
+template <int ROWS, bool GAUSS = false>  // GAUSS: the autoencoder is variational (the emulator never is)
 __global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_joint_kernel(const ChainModel* __restrict__ tab, const ChainStep sa, const ChainStep sb) {
   const int b = (int)blockIdx.x;
-  if (b < sa.ncons) { train_chain32s_body<ROWS>(tab[0], sa, b); return; }
+  if (b < sa.ncons) { train_chain32s_body<ROWS, GAUSS>(tab[0], sa, b); return; }
   ChainStep se = sa;
   se.fwd_only = 1; se.nfwd = tab[0].zcap_layer + 1;
-  train_chain32s_body<ROWS>(tab[0], se, b - sa.ncons);
+  train_chain32s_body<ROWS, GAUSS>(tab[0], se, b - sa.ncons);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the latents are written; the encoder's last LDS reads precede the emulator's gather
-  train_chain32s_body<ROWS>(tab[1], sb, b - sa.ncons);
+  train_chain32s_body<ROWS, false>(tab[1], sb, b - sa.ncons);
 }
 // a sweep: `models` per-model blocks in device memory (as train_chain_group_kernel); no prefetchers.  Workgroup b carries
 // row block b / models of model b % models: workgroups are dealt to the XCDs round-robin, so with 8 models (or a divisor
 // or multiple of 8) a model's row blocks share ONE XCD and its weights are fetched into one L2 -- with blockIdx.y = model
 // every XCD streamed every model's weights (8 x 2.5 MB through a 4-MB L2): 68.8 us per launch of 8 models.
-template <int ROWS>
+template <int ROWS, bool GAUSS = false>  // GAUSS: some member of the sweep has a variational head
 __global__ void __launch_bounds__(64 * kC32sWaves) train_chain32s_group_kernel(const ChainModel* __restrict__ tab, const ChainStep st, const int models) {
   const int b = (int)blockIdx.x;
-  train_chain32s_body<ROWS>(tab[b % models], st, b / models);
+  train_chain32s_body<ROWS, GAUSS>(tab[b % models], st, b / models);
 }
 
 }  // namespace v21

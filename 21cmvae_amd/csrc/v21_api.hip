@@ -1463,6 +1463,16 @@ static int chain_attr_of() {
   for (const void* f : fs) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLdsBytes));
   return V21_OK;
 }
+static void launch_joint32_kernel(int rpw, bool gauss, dim3 grid, dim3 block, hipStream_t st, const ChainModel* tab, const ChainStep& sa,
+                                  const ChainStep& sb) {
+  if (rpw == 4) {
+    if (gauss) hipLaunchKernelGGL((train_chain32s_joint_kernel<4, true>), grid, block, kC32sLdsBytes, st, tab, sa, sb);
+    else hipLaunchKernelGGL((train_chain32s_joint_kernel<4, false>), grid, block, kC32sLdsBytes, st, tab, sa, sb);
+  } else {
+    if (gauss) hipLaunchKernelGGL((train_chain32s_joint_kernel<8, true>), grid, block, kC32sLdsBytes, st, tab, sa, sb);
+    else hipLaunchKernelGGL((train_chain32s_joint_kernel<8, false>), grid, block, kC32sLdsBytes, st, tab, sa, sb);
+  }
+}
 static void launch_joint_kernel(int prec, bool gauss, dim3 grid, dim3 block, hipStream_t st, const ChainModel* tab, const ChainStep& sa,
                                 const ChainStep& sb) {
   if (prec == V21_PREC_F16) {
@@ -1491,9 +1501,12 @@ static int chain_attr(int prec) {
   if (prec == V21_PREC_F32) {
     for (const void* f : {(const void*)train_chain32_kernel<0>, (const void*)train_chain32_kernel<kChainFwd>, (const void*)train_chain32_kernel<kChainFwd | kChainOut>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kC32LdsBytes));
-    for (const void* f : {(const void*)train_chain32s_kernel<8>, (const void*)train_chain32s_kernel<4>,
-                          (const void*)train_chain32s_group_kernel<8>, (const void*)train_chain32s_group_kernel<4>,
-                          (const void*)train_chain32s_joint_kernel<8>, (const void*)train_chain32s_joint_kernel<4>})
+    for (const void* f : {(const void*)train_chain32s_kernel<8, false>, (const void*)train_chain32s_kernel<4, false>,
+                          (const void*)train_chain32s_kernel<8, true>, (const void*)train_chain32s_kernel<4, true>,
+                          (const void*)train_chain32s_group_kernel<8, false>, (const void*)train_chain32s_group_kernel<4, false>,
+                          (const void*)train_chain32s_group_kernel<8, true>, (const void*)train_chain32s_group_kernel<4, true>,
+                          (const void*)train_chain32s_joint_kernel<8, false>, (const void*)train_chain32s_joint_kernel<4, false>,
+                          (const void*)train_chain32s_joint_kernel<8, true>, (const void*)train_chain32s_joint_kernel<4, true>})
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kC32sLdsBytes));
   } else if (prec == V21_PREC_F16) {
     CHK(chain_attr_of<PrecF16>());
@@ -1580,8 +1593,16 @@ static int launch_chain32_args(ChainArgs& a, hipStream_t st, bool small = false)
     const int rpw = force_rows == 4 || force_rows == 8 ? force_rows : (a.rows <= kC32sRows4Max ? 4 : 8);
     a.ncons = (int)((((long long)a.rows + rpw - 1) / rpw + 7) / 8 * 8);
     a.npref = chain_prefetchers(a.ncons, 1);
-    if (rpw == 4) hipLaunchKernelGGL(train_chain32s_kernel<4>, dim3(a.ncons + 8 * a.npref), dim3(64 * kC32sWaves), kC32sLdsBytes, st, a);
-    else hipLaunchKernelGGL(train_chain32s_kernel<8>, dim3(a.ncons + 8 * a.npref), dim3(64 * kC32sWaves), kC32sLdsBytes, st, a);
+    bool gauss = false;  // (train_chain32s.h: GAUSS -- the variational head's code only where the stack has one)
+    for (int l = 0; l < a.L; ++l) gauss = gauss || a.lt[l].gauss;
+    const dim3 grid(a.ncons + 8 * a.npref), block(64 * kC32sWaves);
+    if (rpw == 4) {
+      if (gauss) hipLaunchKernelGGL((train_chain32s_kernel<4, true>), grid, block, kC32sLdsBytes, st, a);
+      else hipLaunchKernelGGL((train_chain32s_kernel<4, false>), grid, block, kC32sLdsBytes, st, a);
+    } else {
+      if (gauss) hipLaunchKernelGGL((train_chain32s_kernel<8, true>), grid, block, kC32sLdsBytes, st, a);
+      else hipLaunchKernelGGL((train_chain32s_kernel<8, false>), grid, block, kC32sLdsBytes, st, a);
+    }
     HIPCHK(hipGetLastError());
     return V21_OK;
   }
@@ -2683,8 +2704,16 @@ static int sweep_step_chain32(v21_sweep* s, const ChainStep& cs, long long step_
   csp.ncons = ((rows + rpw - 1) / rpw + 7) / 8 * 8;
   csp.npref = 0;
   const dim3 grid(csp.ncons * G), block(64 * kC32sWaves);
-  if (rpw == 4) hipLaunchKernelGGL(train_chain32s_group_kernel<4>, grid, block, kC32sLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
-  else hipLaunchKernelGGL(train_chain32s_group_kernel<8>, grid, block, kC32sLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
+  bool gauss = false;
+  for (v21_trainer* t : s->tr) gauss = gauss || t->gl >= 0;
+  const ChainModel* tab = (const ChainModel*)s->d_chain;
+  if (rpw == 4) {
+    if (gauss) hipLaunchKernelGGL((train_chain32s_group_kernel<4, true>), grid, block, kC32sLdsBytes, st, tab, csp, G);
+    else hipLaunchKernelGGL((train_chain32s_group_kernel<4, false>), grid, block, kC32sLdsBytes, st, tab, csp, G);
+  } else {
+    if (gauss) hipLaunchKernelGGL((train_chain32s_group_kernel<8, true>), grid, block, kC32sLdsBytes, st, tab, csp, G);
+    else hipLaunchKernelGGL((train_chain32s_group_kernel<8, false>), grid, block, kC32sLdsBytes, st, tab, csp, G);
+  }
   HIPCHK(hipGetLastError());
   return launch_dw32_group(s->tr, s->d_dw32, rows, step_index, max_blocks, st);
 }
@@ -2924,8 +2953,7 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
         const int rpw = force_rows == 4 || force_rows == 8 ? force_rows : (2 * ((rows + 3) / 4) <= 256 ? 4 : 8);
         sa.ncons = sb.ncons = ((rows + rpw - 1) / rpw + 7) / 8 * 8;
         const dim3 grid(2 * sa.ncons), block(64 * kC32sWaves);
-        if (rpw == 4) hipLaunchKernelGGL(train_chain32s_joint_kernel<4>, grid, block, kC32sLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
-        else hipLaunchKernelGGL(train_chain32s_joint_kernel<8>, grid, block, kC32sLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+        launch_joint32_kernel(rpw, ta->gl >= 0, grid, block, st, (const ChainModel*)j->d_tab, sa, sb);
         HIPCHK(hipGetLastError());
       }
       if (group32) {
@@ -3030,8 +3058,7 @@ extern "C" int v21_joint_eval(v21_joint* j, double* losses) {
     sa.gs = sb.gs = 1.0f;
     sa.ncons = sb.ncons = (int)(((n + rpw - 1) / rpw + 7) / 8 * 8);
     const dim3 grid(2 * sa.ncons), block(64 * kC32sWaves);
-    if (rpw == 4) hipLaunchKernelGGL(train_chain32s_joint_kernel<4>, grid, block, kC32sLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
-    else hipLaunchKernelGGL(train_chain32s_joint_kernel<8>, grid, block, kC32sLdsBytes, st, (const ChainModel*)j->d_tab, sa, sb);
+    launch_joint32_kernel(rpw, ta->gl >= 0, grid, block, st, (const ChainModel*)j->d_tab, sa, sb);
   } else {
     sa.ncons = sb.ncons = (int)(((n + 31) / 32 + 7) / 8 * 8);
     sb.blk0 = sa.ncons;
