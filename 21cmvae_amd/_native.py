@@ -97,6 +97,7 @@ SIGNATURES = {
     "v21_trainer_get_grad": (C.c_int, [_P, _F, C.c_size_t]),
     "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
     "v21_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
+    "v21_debug_check_chain_jobs": (C.c_int, [_P, C.c_longlong, C.c_longlong]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
     "v21_trainer_enable_stamps": (C.c_int, [_P, C.c_int]),
     "v21_trainer_chain_stamps": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "v21_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(CommHostOps)]),
     "v21_comm_destroy": (C.c_int, [_P]),
     "v21_comm_set_sharded": (C.c_int, [_P, C.c_int]),
+    "v21_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "v21_comm_allreduce_f32": (C.c_int, [_P, _P, C.c_size_t]),
     "v21_comm_reduce_scatter_f32": (C.c_int, [_P, _P, C.c_size_t]),
     "v21_comm_allgather_f32": (C.c_int, [_P, _P, C.c_size_t]),
@@ -308,6 +310,25 @@ class Context:
 
     def comm_set_sharded(self, on=True):
         check(self.lib.v21_comm_set_sharded(self.h, 1 if on else 0))
+
+    def comm_info(self):
+        """(nranks, rank, transport) as the attached communicator reports them; transport "none" / "rccl" / "host"."""
+        n, r, t = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self.lib.v21_comm_info(self.h, C.byref(n), C.byref(r), C.byref(t)))
+        return n.value, r.value, ("none", "rccl", "host")[t.value]
+
+    def ranks_seen(self):
+        """Sum of 1.0 over the communicator (one all-reduce through the library's transport): how many ranks really
+        take part in an exchange.  A collective call: every rank must make it."""
+        d = self.malloc(4)
+        try:
+            self.h2d(d, np.ones(1, np.float32))
+            self.allreduce(d, 1)
+            out = np.zeros(1, np.float32)
+            self.d2h(out, d)
+        finally:
+            self.free(d)
+        return int(round(float(out[0])))
 
     def comm_destroy(self):
         check(self.lib.v21_comm_destroy(self.h))
@@ -504,6 +525,11 @@ class Trainer:
         arithmetic, bit-identical results; the host enqueues one graph launch per step instead of 3-14 kernels
         (measured r2: the steps are GPU-bound, so this frees the host thread but does not shorten a step)."""
         check(self.lib.v21_trainer_use_graph(self.h, 1 if enable else 0))
+
+    def check_chain_jobs(self, fw_bytes=-1, bw_bytes=-1):
+        """Diagnostics: validate the small-batch f32 chain's job table against packed streams of the given sizes
+        (bytes; -1 = the allocated ones).  Raises EngineError where a row points outside."""
+        check(self.lib.v21_debug_check_chain_jobs(self.h, int(fw_bytes), int(bw_bytes)))
 
     def enable_stamps(self, on=True):
         """Cycle stamps of the chain kernel's phases (diagnostics; off by default: they cost 2-3 us per step)."""

@@ -614,7 +614,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
           const int row = 8 * i + (lane >> 3);
           f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + row * SP + c4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v4[e] = v4[e] * st.out_std + mean4[e];
+          for (int e = 0; e < 4; ++e) v4[e] = (ly.relu ? fmaxf(v4[e], 0.f) : v4[e]) * st.out_std + mean4[e];  // (a ReLU OUTPUT layer: v21_mlp_create allows one)
           if (row < vrows) {
             float* dst = st.out + (long long)(m0 + row) * st.ldo + n;
             if (n + 3 < ly.N) *reinterpret_cast<f32x4_u*>(dst) = v4;

@@ -297,7 +297,8 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
           const int n = n0 + 16 * s + 4 * kq;
           f32x4 v4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v4[r] = acc[s][r] * st.out_std + (st.out_mean ? st.out_mean[n + r < ly.N ? n + r : ly.N - 1] : 0.f);
+          for (int r = 0; r < 4; ++r)
+            v4[r] = (ly.relu ? fmaxf(acc[s][r], 0.f) : acc[s][r]) * st.out_std + (st.out_mean ? st.out_mean[n + r < ly.N ? n + r : ly.N - 1] : 0.f);
           if (m < vrows) {
             float* dst = st.out + (long long)(m0 + m) * st.ldo + n;
             if (n + 3 < ly.N) *reinterpret_cast<f32x4_u*>(dst) = v4;

@@ -162,6 +162,50 @@ inline void c32s_build_jobs(const ChainModel& a, C32sJob* tab) {
   }
 }
 
+// Host-side check of a job table against the buffers it points into -- the kernel follows the table blindly (scalar
+// loads of offsets, no range checks in the loop), so a bad row is a GPU memory fault, not an error code.  Every address
+// a wave may REQUEST must lie inside the allocation: the chunks of its unit, and the first chunk of its next unit (the
+// rolling prefetch requests it under this unit's last chunk whether or not it is ever used).  `fw_words` / `bw_words`:
+// sizes of the two packed streams in 16-byte words (one lane's share of a fragment; a fragment is 64 words, a chunk 256);
+// `arena_floats`: size of the parameter arena (biases).  Returns nullptr or a description of the first bad row (static
+// buffer).  Called by build_chain32s_jobs (v21_api.hip) when a trainer is created and by v21_debug_check_chain_jobs.
+inline const char* c32s_validate_jobs(const ChainModel& a, const C32sJob* tab, long long fw_words, long long bw_words,
+                                      long long arena_floats) {
+  static thread_local char msg[256];
+  const int L = a.L, steps = 2 * L - 1;
+  auto bad = [&](int i, int w, const char* what, long long v, long long lim) {
+    snprintf(msg, sizeof msg, "chain job table: step %d wave %d: %s = %lld outside [0, %lld]", i, w, what, v, lim);
+    return msg;
+  };
+  for (int i = -1; i < steps; ++i) {
+    const bool fwd = i < L;
+    const int l = i < 0 ? 0 : (fwd ? i : L - 1 - (i - L));
+    const ChainLayer& ly = a.lt[l];
+    const int frags = fwd ? ly.KS : ly.NS, tiles = fwd ? ly.NT : ly.KT;
+    const long long words = fwd ? fw_words : bw_words;
+    const long long lay0 = fwd ? ly.fw_off : ly.bw_off;
+    for (int w = 0; w < kC32sWaves; ++w) {
+      const C32sJob& j = tab[(1 + i) * kC32sWaves + w];
+      if (i >= 0 && j.nch > 0) {
+        if (j.t < 0 || j.t >= tiles) return bad(i, w, "tile", j.t, tiles - 1);
+        if (j.parts < 1 || j.s < 0 || j.s >= j.parts) return bad(i, w, "part", j.s, j.parts - 1);
+        if (j.f0 < 0 || j.f0 + 4 * j.nch > frags) return bad(i, w, "last fragment of the unit", j.f0 + 4 * j.nch, frags);
+        const long long end = (long long)j.w_off + 256ll * j.nch;
+        if (j.w_off < lay0 || end > lay0 + (long long)tiles * frags * 64) return bad(i, w, "unit end (words, within its layer)", end, lay0 + (long long)tiles * frags * 64);
+        if (j.w_off < 0 || end > words) return bad(i, w, "unit end (words, within the stream)", end, words);
+        if (j.mask_tile >= 0 && j.mask_tile + tiles > kC32sMaskTiles) return bad(i, w, "mask tile", j.mask_tile + tiles, kC32sMaskTiles);
+        if (j.flush_f > 0 && !j.flush_lo && !j.flush_hi) return bad(i, w, "flush pointer", 0, 0);
+      }
+      // the next unit's first chunk is requested in any case (offset 0 of the forward stream when nothing is left)
+      const long long nwords = j.nxt_bw ? bw_words : fw_words;
+      if (j.nxt_w_off < 0 || (long long)j.nxt_w_off + 256 > nwords) return bad(i, w, "next unit's first chunk end (words)", (long long)j.nxt_w_off + 256, nwords);
+      if (j.nxt_nb > 0 && (j.nxt_b_off < 0 || (long long)j.nxt_b_off + std::min(j.nxt_nb, 64) > arena_floats))
+        return bad(i, w, "next unit's bias end (floats)", (long long)j.nxt_b_off + std::min(j.nxt_nb, 64), arena_floats);
+    }
+  }
+  return nullptr;
+}
+
 // ROWS = 8: two groups of four rows share every weight word (two MFMAs per word); ROWS = 4: one group -- twice the
 // workgroups, half the matrix work in each, the same weight stream through each CU (the LDS carve-up stays the 8-row one).
 // GAUSS = false: a promise of the host that the stack has no variational head -- its code folds away (with it compiled in,
@@ -323,7 +367,22 @@ __device__ __forceinline__ void train_chain32s_body(const ChainModel& a, const C
   // buffers rotated back by selects at the head of a unit (under control flow hipcc kept two of them in scratch memory:
   // 335 k cycles): 126 VGPRs, nothing spilled, and slower: 74.5 k cycles against 66 k, the unsplit 8-tile layer
   // (22 chunks per wave end to end) 14.2 k against 13.9 k.  What looked like one round trip per chunk is the CU's load
-  // path at ~50 B/clk, shared by the waves that stream.)
+  // path at ~50 B/clk, shared by the waves that stream.
+  // That experiment also ABORTED the process once (r3, gpurun_out/r3ring2.log: SIGABRT inside v21_trainer_run_epoch of
+  // tests/test_train_gpu.py::test_vae_step_matches_oracle, the suite's smallest f32 stack 451-64-(9|9)-32-451, every
+  // larger stack before it had passed).  The diff was dropped uncommitted a minute later; what is in hand names the
+  // cause: with two chunks in flight a wave requests the chunk TWO ahead of the one it computes on, and for the wave
+  // that holds the last unit of a packed stream -- and for every unit shorter than the look-ahead, which is every unit of
+  // that stack's 1- and 2-chunk layers -- that address lies up to 8 KiB PAST THE END OF THE STREAM.  Streams are whole
+  // 4-KiB chunks (chain32s_frags pads to four fragments) and were allocated with 64 bytes of slack, so a stream ends
+  // on a page boundary and the request lands on the page after the allocation: harmless while hipMalloc happens to
+  // place another buffer there (all the stacks before), a memory access fault -- which the HSA runtime answers with
+  // abort() -- when it does not.  The two-buffer kernel never had the problem (its one look-ahead address is the next
+  // unit's first chunk, or offset 0 when nothing is left); the class of bug is "the kernel trusts offsets the host
+  // wrote".  Since r4: c32s_validate_jobs checks every address a row makes a wave request against the allocated sizes
+  // when the table is built (V21_ERR_STATE instead of a fault; tests/test_train_gpu.py truncates a stream on purpose), and
+  // the packed streams carry kChainStreamSlack = two chunks of zeroed slack, so a deeper prefetch tried later reads
+  // zeros inside the allocation instead of whatever lies behind it.)
   auto contract = [&](const f32x4* wsrc, const float* act, int nch, f32x4 (&acc)[G], const Job nxt, int f0) __attribute__((always_inline)) -> bool {
     const float* ap = act + jr * PITCH + 4 * f0;
     load_bias(nxt, bnext);  // (the caller has consumed this unit's values)

@@ -64,6 +64,10 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* v21_last_error(void) { return g_err.c_str(); }
 static inline long long p16(int d) { return (d + 15) & ~15; }  // row pitch: whole 16-float groups
+// Zeroed bytes behind every packed weight stream of the chain kernels: two 4-KiB chunks.  A stream is whole chunks, so
+// its end is a page boundary; the rolling prefetch requests addresses AHEAD of what it uses, and a request must never
+// leave the allocation (train_chain32s.h: the r3 abort).
+constexpr size_t kChainStreamSlack = 8192;
 // floats behind the P parameters of an arena: the loss slot, then room to round P + 1 up to whole shards of up to
 // 64 ranks (sharded data-parallel Adam works on nranks * ceil((P + 1) / nranks) elements in place)
 constexpr size_t kArenaPad = 4 + 64;
@@ -86,6 +90,7 @@ typedef int (*fn_ReduceScatter)(const void*, void*, size_t, int, int, nccl_comm,
 typedef int (*fn_AllGather)(const void*, void*, size_t, int, nccl_comm, hipStream_t);
 typedef int (*fn_CommDestroy)(nccl_comm);
 typedef const char* (*fn_GetErrorString)(int);
+typedef int (*fn_CommCount)(nccl_comm, int*);
 struct RcclApi {
   void* lib = nullptr;
   fn_GetUniqueId GetUniqueId = nullptr;
@@ -95,6 +100,7 @@ struct RcclApi {
   fn_AllGather AllGather = nullptr;
   fn_CommDestroy CommDestroy = nullptr;
   fn_GetErrorString GetErrorString = nullptr;
+  fn_CommCount CommCount = nullptr, CommUserRank = nullptr;
 };
 static RcclApi g_rccl;
 static int load_rccl() {
@@ -114,6 +120,8 @@ static int load_rccl() {
   g_rccl.AllGather = (fn_AllGather)dlsym(lib, "ncclAllGather");
   g_rccl.CommDestroy = (fn_CommDestroy)dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (fn_GetErrorString)dlsym(lib, "ncclGetErrorString");
+  g_rccl.CommCount = (fn_CommCount)dlsym(lib, "ncclCommCount");
+  g_rccl.CommUserRank = (fn_CommCount)dlsym(lib, "ncclCommUserRank");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy || !g_rccl.ReduceScatter ||
       !g_rccl.AllGather)
     return fail(V21_ERR_COMM, "librccl lacks a required symbol");
@@ -683,6 +691,19 @@ extern "C" int v21_comm_destroy(v21_ctx* c) {
   c->nranks = 1; c->rank = 0; c->sharded = 0;
   return V21_OK;
 }
+// what the attached communicator itself says (RCCL: ncclCommCount / ncclCommUserRank; host transport: what the host
+// passed): transport 0 = none, 1 = RCCL inside the library, 2 = host-staged callbacks
+extern "C" int v21_comm_info(v21_ctx* c, int* nranks, int* rank, int* transport) {
+  if (!c || !nranks || !rank || !transport) return fail(V21_ERR_ARG, "null argument");
+  *nranks = c->nranks; *rank = c->rank;
+  *transport = c->comm ? 1 : (c->host_comm ? 2 : 0);
+  if (c->comm && g_rccl.CommCount && g_rccl.CommUserRank) {
+    int r = g_rccl.CommCount(c->comm, nranks);
+    if (r == 0) r = g_rccl.CommUserRank(c->comm, rank);
+    if (r != 0) return fail(V21_ERR_COMM, "ncclCommCount / ncclCommUserRank: %s", rccl_err(r));
+  }
+  return V21_OK;
+}
 extern "C" int v21_comm_set_sharded(v21_ctx* c, int on) {
   if (!c) return fail(V21_ERR_ARG, "null context");
   c->sharded = on ? 1 : 0;
@@ -906,8 +927,8 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
         t->bw_off.push_back(ob); ob += (long long)((K + 31) / 32) * chain_steps(N) * 512;
       }
       t->fw_bytes = of * 2; t->bw_bytes = ob * 2;
-      HIPCHK(hipMalloc(&t->d_fw, (size_t)of * 2 + 64)); HIPCHK(hipMemsetAsync(t->d_fw, 0, (size_t)of * 2 + 64, st));
-      HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 2 + 64)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 2 + 64, st));
+      HIPCHK(hipMalloc(&t->d_fw, (size_t)of * 2 + kChainStreamSlack)); HIPCHK(hipMemsetAsync(t->d_fw, 0, (size_t)of * 2 + kChainStreamSlack, st));
+      HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 2 + kChainStreamSlack)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 2 + kChainStreamSlack, st));
       CHK(zalloc(&t->d_partial, (size_t)(max_batch + 31) / 32 + 4, st));
       HIPCHK(hipMalloc((void**)&t->d_ticket, 16)); HIPCHK(hipMemsetAsync(t->d_ticket, 0, 16, st));
       HIPCHK(hipMalloc((void**)&t->d_stamps, kStampSlots * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, kStampSlots * 8, st));
@@ -991,8 +1012,8 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
         t->bw_off.push_back(ob); ob += (long long)t->c32_tiles(K) * t->c32_frags(N) * 256;
       }
       t->fw_bytes = of * 4; t->bw_bytes = ob * 4;
-      HIPCHK(hipMalloc(&t->d_fw, (size_t)of * 4 + 64)); HIPCHK(hipMemsetAsync(t->d_fw, 0, (size_t)of * 4 + 64, st));
-      HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 4 + 64)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 4 + 64, st));
+      HIPCHK(hipMalloc(&t->d_fw, (size_t)of * 4 + kChainStreamSlack)); HIPCHK(hipMemsetAsync(t->d_fw, 0, (size_t)of * 4 + kChainStreamSlack, st));
+      HIPCHK(hipMalloc(&t->d_bw, (size_t)ob * 4 + kChainStreamSlack)); HIPCHK(hipMemsetAsync(t->d_bw, 0, (size_t)ob * 4 + kChainStreamSlack, st));
       HIPCHK(hipMalloc((void**)&t->d_ticket, 16)); HIPCHK(hipMemsetAsync(t->d_ticket, 0, 16, st));
       HIPCHK(hipMalloc((void**)&t->d_stamps, kStampSlots * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, kStampSlots * 8, st));
       t->chain32 = true;
@@ -1581,6 +1602,10 @@ static int build_chain32s_jobs(v21_trainer* t) {
   const ChainModel a = chain_model32(t);
   std::vector<C32sJob> tab((size_t)2 * a.L * kC32sWaves);
   c32s_build_jobs(a, tab.data());
+  // the kernel follows these rows without range checks: every chunk and bias a row names must lie inside the buffers
+  // allocated above, or the trainer is not created (the alternative is a GPU memory fault in the first step)
+  if (const char* why = c32s_validate_jobs(a, tab.data(), t->fw_bytes / 16, t->bw_bytes / 16, (long long)t->P))
+    return fail(V21_ERR_STATE, "%s", why);
   HIPCHK(hipMalloc((void**)&t->d_jobs, tab.size() * sizeof(C32sJob)));
   HIPCHK(hipMemcpyAsync(t->d_jobs, tab.data(), tab.size() * sizeof(C32sJob), hipMemcpyHostToDevice, t->ctx->stream));
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
@@ -1635,8 +1660,8 @@ static int ensure_chain_stream(v21_mlp* m, int prec) {
     m->cfw_bytes[pc] = of * esz; m->cbw_bytes[pc] = ob * esz;
   }
   if (!m->d_cfw[prec]) {
-    HIPCHK(hipMalloc(&m->d_cfw[prec], (size_t)m->cfw_bytes[pc] + 64)); HIPCHK(hipMemsetAsync(m->d_cfw[prec], 0, (size_t)m->cfw_bytes[pc] + 64, st));
-    HIPCHK(hipMalloc(&m->d_cbw[prec], (size_t)m->cbw_bytes[pc] + 64)); HIPCHK(hipMemsetAsync(m->d_cbw[prec], 0, (size_t)m->cbw_bytes[pc] + 64, st));
+    HIPCHK(hipMalloc(&m->d_cfw[prec], (size_t)m->cfw_bytes[pc] + kChainStreamSlack)); HIPCHK(hipMemsetAsync(m->d_cfw[prec], 0, (size_t)m->cfw_bytes[pc] + kChainStreamSlack, st));
+    HIPCHK(hipMalloc(&m->d_cbw[prec], (size_t)m->cbw_bytes[pc] + kChainStreamSlack)); HIPCHK(hipMemsetAsync(m->d_cbw[prec], 0, (size_t)m->cbw_bytes[pc] + kChainStreamSlack, st));
   }
   AdamArgs a{};  // the arena -> the packed streams (the trainer's repacking kernel without the Adam update)
   a.w = m->d_w; a.n = (long long)m->nparams; a.L = L; a.do_adam = 0; a.skip_nt = 1;
@@ -2086,7 +2111,7 @@ static int step_graph(v21_trainer* t, const float* x, long long ldx, const float
       // The lazy refresh of the packed weight copies is NOT part of the captured step (it was a no-op while the
       // step was recorded): an arena rewritten between two replays (v21_mlp_set_weights, a loaded file) must reach
       // the copies before the replayed kernels read them.
-      CHK(ensure_copies(t, !t->chain));
+      CHK(ensure_copies(t, !t->chain && !t->chain32));  // (the chain trainers never read the NT copies: after_replay's nt_ok)
       *out = g.exec;
       return V21_OK;
     }
@@ -2097,7 +2122,7 @@ static int step_graph(v21_trainer* t, const float* x, long long ldx, const float
   }
   hipStream_t st = t->ctx->stream;
   // everything that may not happen inside a capture: lazy refreshes, function attributes
-  CHK(ensure_copies(t, !t->chain));
+  CHK(ensure_copies(t, !t->chain && !t->chain32));
   if (t->chain) { CHK(chain_attr(t->prec)); CHK(dw16_attr(t->prec)); }
   if (t->chain32) CHK(chain_attr(V21_PREC_F32));
   hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -2948,6 +2973,7 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
         ChainStep sa = chain_step(ta->d_x[0], dsig, nullptr, dsig, ta->d_rw[0], d_idx, lo, rows, brows, dsig, nullptr, lo - first);
         ChainStep sb = chain_step(te->d_x[0], dpar, nullptr, dlat, te->d_rw[0], d_idx, lo, rows, brows, dlat, nullptr, lo - first);
         sa.gs = sb.gs = 1.0f;
+        sa.step_off = (unsigned long long)s;  // the table holds the autoencoder's step counter as of the epoch's start (noise key)
         sb.y_from_lds = 1;
         const char* er = getenv("V21_C32S_ROWS");
         const int force_rows = er ? atoi(er) : 0;
@@ -3143,6 +3169,19 @@ extern "C" int v21_debug_poison_lds(v21_ctx* c, uint32_t pattern) {
   return V21_OK;
 }
 
+// diagnostics: the check build_chain32s_jobs makes at creation, repeated against stream sizes the CALLER names (bytes;
+// < 0 = the real ones) -- a test hands in a truncated stream and expects V21_ERR_STATE, not a launch
+extern "C" int v21_debug_check_chain_jobs(v21_trainer* t, long long fw_bytes, long long bw_bytes) {
+  if (!t) return fail(V21_ERR_ARG, "null trainer");
+  if (!t->chain32s) return fail(V21_ERR_UNSUPPORTED, "the trainer does not run the small-batch f32 chain (no job table)");
+  const ChainModel a = chain_model32(t);
+  std::vector<C32sJob> tab((size_t)2 * a.L * kC32sWaves);
+  c32s_build_jobs(a, tab.data());
+  if (const char* why = c32s_validate_jobs(a, tab.data(), (fw_bytes < 0 ? t->fw_bytes : fw_bytes) / 16,
+                                           (bw_bytes < 0 ? t->bw_bytes : bw_bytes) / 16, (long long)t->P))
+    return fail(V21_ERR_STATE, "%s", why);
+  return V21_OK;
+}
 extern "C" int v21_trainer_use_graph(v21_trainer* t, int enable) {
   if (!t) return fail(V21_ERR_ARG, "null trainer");
   CHK(use(t->ctx));

@@ -364,43 +364,51 @@ class Model:
         def draw():
             return _rng.permutation(n).astype(np.int32)
 
+        def draw_ahead(state):
+            # a PRIVATE generator started from a snapshot of the shared one: the shared stream is not touched here
+            g = np.random.Generator(type(_rng.bit_generator)())
+            g.bit_generator.state = state
+            return g.permutation(n).astype(np.int32), g.bit_generator.state
+
         # The next epoch's permutation is drawn while this epoch runs on the GPU (run_epoch blocks inside the library with
         # the GIL released; drawing 24,562 indices takes ~0.25 ms, 4 % of an f32 epoch of the reference recipe during
-        # which the GPU sat idle).  Same generator, same order of draws; a draw that early stopping leaves unused is
-        # undone (the generator's state is put back), so the stream of random numbers is what it was without this.
+        # which the GPU sat idle) -- from a COPY of the shared generator.  The shared generator advances only when that
+        # permutation is consumed, and it is consumed only if nothing (a callback, a nested fit(), set_random_seed)
+        # has touched the shared generator in between; otherwise the look-ahead is dropped and the permutation is drawn
+        # the ordinary way.  Either way the stream of random numbers is what it would be without the look-ahead.
         pool = ThreadPoolExecutor(1) if shuffle else None
-        ahead = rng_before = None
-        for epoch in range(initial_epoch, epochs):
-            cbs.on_epoch_begin(epoch)
-            tr.set_lr(float(self.optimizer.lr))
-            if getattr(self, "_vae_seed", None) is not None:  # a callback may anneal kl_weight between epochs
-                tr.set_vae(self.kl_weight, self.sample_latent, self._vae_seed)
-            perm = None
-            if shuffle:
-                perm = ahead.result() if ahead is not None else draw()
-                ahead = None
-            if dp and perm is not None:
-                perm = bcast(perm)
-            if shuffle and epoch + 1 < epochs:
-                rng_before = _rng.bit_generator.state
-                ahead = pool.submit(draw)
-            try:
+        ahead = None  # (future -> (perm, generator state after the draw), the shared generator, its state at the snapshot)
+        try:
+            for epoch in range(initial_epoch, epochs):
+                cbs.on_epoch_begin(epoch)
+                tr.set_lr(float(self.optimizer.lr))
+                if getattr(self, "_vae_seed", None) is not None:  # a callback may anneal kl_weight between epochs
+                    tr.set_vae(self.kl_weight, self.sample_latent, self._vae_seed)
+                perm = None
+                if shuffle:
+                    if ahead is not None and ahead[1] is _rng and _rng.bit_generator.state == ahead[2]:
+                        perm, after = ahead[0].result()
+                        _rng.bit_generator.state = after
+                    else:
+                        perm = draw()
+                    ahead = None
+                if dp and perm is not None:
+                    perm = bcast(perm)
+                if shuffle and epoch + 1 < epochs:
+                    snap = _rng.bit_generator.state
+                    ahead = (pool.submit(draw_ahead, snap), _rng, snap)
                 logs = {"loss": tr.run_epoch(perm, batch_size)}
-            finally:
-                if ahead is not None:
-                    ahead.result()  # (nothing else touches the generator while the draw is running)
-            self._dirty_host = True
-            if validation_data is not None:
-                logs["val_loss"] = tr.evaluate(1, min(vb, tr.max_batch))
-            if verbose in (1, 2):
-                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4e" % kv for kv in logs.items()))
-            cbs.on_epoch_end(epoch, logs)
-            if self.stop_training:
-                break
-        if ahead is not None:  # drawn ahead, never used
-            _rng.bit_generator.state = rng_before
-        if pool is not None:
-            pool.shutdown()
+                self._dirty_host = True
+                if validation_data is not None:
+                    logs["val_loss"] = tr.evaluate(1, min(vb, tr.max_batch))
+                if verbose in (1, 2):
+                    print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4e" % kv for kv in logs.items()))
+                cbs.on_epoch_end(epoch, logs)
+                if self.stop_training:
+                    break
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)  # (an unused look-ahead never touched the shared generator: nothing to undo)
         cbs.on_train_end()
         self.optimizer.iterations = tr.get_state()[0]
         self._sync_host()

@@ -99,13 +99,22 @@ class ParamStats:
 
 
 def _to_log_space(p):
+    """log10 of the LOG_COLUMNS, taken IN THE DTYPE OF THE INPUT for floating arrays, as the reference
+    does (preprocess.py:74-78 / 89-93: `.copy()` of the columns, the floor written into that copy,
+    `np.log10` of it, and only then the cast into a float64 result, :81-85): float32 parameters get a
+    float32 floor (1e-6 rounded to float32) and a float32 logarithm.  Documented deviation: a
+    non-floating array is taken to float64 first (the reference would truncate the floor to 0 and
+    return -inf)."""
     out = np.empty(p.shape)  # float64 whatever the input dtype, like the reference
+    src = p if np.issubdtype(p.dtype, np.floating) else p.astype(np.float64)
     for j in range(p.shape[1]):
-        col = p[:, j]
-        if j in ZERO_FLOOR:
-            col = col.astype(np.float64)  # (an integer array would truncate the floor to 0: preprocess.py:75-76)
-            col[col == 0] = ZERO_FLOOR[j]
-        out[:, j] = np.log10(col) if j in LOG_COLUMNS else col
+        col = src[:, j]
+        if j in LOG_COLUMNS:
+            col = np.array(col, copy=True, order="C")  # contiguous, input dtype
+            if j in ZERO_FLOOR:
+                col[col == 0] = ZERO_FLOOR[j]
+            col = np.log10(col)
+        out[:, j] = col
     return out
 
 

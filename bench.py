@@ -11,8 +11,11 @@ own batch (rows are independent; no data-path collective).
 
   python bench.py --gpus N --steps K --warmup W
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+          (or plain `python bench.py --gpus N`: without WORLD_SIZE in the environment the script starts that
+          launcher itself as a CHILD process, before anything here touches the GPU, and relays rank 0's line)
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0 -- and nothing else on stdout: file descriptor 1 is pointed at stderr for the
+whole run (banners of gloo / c10d / the HIP runtime land there), the line goes out through a saved duplicate.
 """
 import argparse
 import importlib
@@ -472,6 +475,56 @@ def fit_leg(precision, epochs=30, n_train=None, joint=False):
             "test_error_percent_mean_after_%d_epochs" % (epochs + 1): float(np.mean(err))}
 
 
+def _self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run` (one rank per GPU) as a
+    child process -- this process has imported numpy only, no HIP call has been made -- relay rank 0's JSON line to
+    stdout and everything else to stderr, and leave with the child's exit status (non-zero if no line came)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env,
+                           timeout=float(os.environ.get("V21_BENCH_LAUNCH_TIMEOUT", "1500")))
+        rc, raw = p.returncode, p.stdout
+    except subprocess.TimeoutExpired as e:
+        rc, raw = 124, e.stdout or b""
+    line = None
+    for ln in raw.decode(errors="replace").splitlines():
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                if "metric" in json.loads(t):
+                    line = t
+                    continue
+            except ValueError:
+                pass
+        if t:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 4
+        print("bench.py: the %d-rank child run printed no JSON line" % n, file=sys.stderr)
+    sys.exit(rc)
+
+
+def _claim_stdout():
+    """Point file descriptor 1 at stderr (whatever C++ libraries print -- `[Gloo] Rank ...`, c10d warnings -- goes
+    there) and return a text stream on a duplicate of the ORIGINAL stdout for the one JSON line."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(os.dup(2), "w", buffering=1)  # Python-level prints of imported modules: stderr as well
+    return os.fdopen(keep, "w")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -495,9 +548,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with torch.distributed.run" % args.gpus)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            _self_launch(args.gpus, sys.argv[1:])  # does not return
         args.gpus = world
+    json_out = _claim_stdout()
 
     torch = None
     dist = None
@@ -747,6 +801,11 @@ def main():
                 tl = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
                                args.train_batch, args.precision, args.train_steps, 20)
                 tl["transport"] = transport
+                # what the in-library communicator itself reports, and how many ranks an all-reduce through it sums
+                seen = ctx.ranks_seen()
+                info = ctx.comm_info()
+                tl["n_ranks_seen"] = seen
+                tl["communicator"] = {"nranks": info[0], "rank": info[1], "transport": info[2]}
                 ae_params = sum(k * n + n for k, n in zip(AE_DIMS[:-1], AE_DIMS[1:]))
                 tl["roofline"] = train_roofline(tl, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
                                                 "kernel_stats_train_b%d_%s.csv" % (args.train_batch, args.precision),
@@ -758,6 +817,7 @@ def main():
                                    args.train_batch, args.precision, args.train_steps, 20)
                     ts["collective"] = "reduce-scatter + all-gather, Adam on 1/%d of the arena per rank" % world
                     ts["transport"] = transport
+                    ts["n_ranks_seen"] = ctx.ranks_seen()
                     out["train_sharded_adam"] = ts
                     ctx.comm_set_sharded(False)
                 if world == 1 and not args.no_extras:
@@ -790,7 +850,7 @@ def main():
             if th.is_alive():
                 out["train"] = {"error": "timeout: the data-parallel training leg did not finish"}
                 if rank == 0:
-                    print(json.dumps(out), flush=True)
+                    print(json.dumps(out), file=json_out, flush=True)
                 os._exit(3)  # a hung leg is a failed run: the JSON line is still printed, the exit status says so
         else:
             run_train()
@@ -817,7 +877,7 @@ def main():
 
     barrier()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     ctx.free(d_x)
     ctx.free(d_y)
     if dist is not None:

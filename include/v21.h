@@ -211,6 +211,11 @@ int v21_trainer_use_graph(v21_trainer* tr, int enable);
  * when that is done.  The poison tests launch it immediately before each kernel that keeps activations in LDS, so
  * that a column or mask tile read before it is written meets NaN instead of a fresh process's zeros. */
 int v21_debug_poison_lds(v21_ctx* ctx, uint32_t pattern);
+/* diagnostics: the small-batch f32 chain kernel (csrc/train_chain32s.h) follows a host-built job table into the packed
+ * weight streams without range checks; v21_trainer_create validates every address a row names against the allocated
+ * streams (V21_ERR_STATE instead of a GPU memory fault).  This repeats that check against stream sizes the caller names
+ * (bytes; negative = the real ones): the tests hand in a truncated stream.  V21_ERR_UNSUPPORTED for trainers on other paths. */
+int v21_debug_check_chain_jobs(v21_trainer* tr, long long fw_bytes, long long bw_bytes);
 /* diagnostics: s_memtime stamps of workgroup 0 of the last chain-kernel launch (train_chain.h):
  * [0] start, [1] batch gathered, [2..L+1] after forward layer l, [L+2] loss reduced,
  * [L+3..] after each backward layer (top down).  Off by default (a stamp holds its wave for ~600 cycles and the
@@ -269,6 +274,9 @@ int v21_comm_init(v21_ctx* ctx, int nranks, int rank, const void* id);
 int v21_comm_init_host(v21_ctx* ctx, int nranks, int rank, const v21_comm_host_ops* ops);
 int v21_comm_destroy(v21_ctx* ctx);
 int v21_comm_set_sharded(v21_ctx* ctx, int on);
+/* what the attached communicator reports about itself (RCCL: ncclCommCount / ncclCommUserRank); transport: 0 none,
+ * 1 RCCL inside the library, 2 host-staged callbacks.  bench.py prints it beside the data-parallel legs. */
+int v21_comm_info(v21_ctx* ctx, int* nranks, int* rank, int* transport);
 int v21_comm_allreduce_f32(v21_ctx* ctx, float* d_buf, size_t n);           /* sum, in place */
 int v21_comm_reduce_scatter_f32(v21_ctx* ctx, float* d_buf, size_t n_per);  /* in place over nranks * n_per floats */
 int v21_comm_allgather_f32(v21_ctx* ctx, float* d_buf, size_t n_per);       /* in place over nranks * n_per floats */

@@ -38,7 +38,18 @@ out = dict(
     unpre_out=ref.unpreproc(ref.preproc(sig_in, sig_train), sig_train),
     pre_out_f64=ref.preproc(sig_in.astype(np.float64), sig_train),
 )
-for k in ("par_out", "par_out_1d", "pre_out", "unpre_out", "pre_out_f64"):
+# float32 parameters: the reference floors and takes log10 IN THE INPUT DTYPE (preprocess.py:74-78, 89-93)
+# and only then casts into its float64 result (:81-85) -- every dtype combination a caller can hand over
+par_in32, par_train32 = par_in.astype(np.float32), par_train.astype(np.float32)
+out.update(
+    par_out_in32_tr32=ref.par_transform(par_in32, par_train32),      # float32 `parameters` and `params_train`
+    par_out_in32_tr64=ref.par_transform(par_in32, par_train),        # mixed: f32 parameters, f64 training set
+    par_out_in64_tr32=ref.par_transform(par_in, par_train32),        # mixed: f64 parameters, f32 training set
+    par_out_1d_in32_tr32=ref.par_transform(par_in32[3], par_train32),  # 1-D float32 (the fx == 0 row)
+    par_out_1d_in32_tr64=ref.par_transform(par_in32[5], par_train),
+    par_train32_out=ref.par_transform(par_train32, par_train32),
+)
+for k in ("par_out", "par_out_1d", "pre_out", "unpre_out", "pre_out_f64", "par_out_in32_tr32", "par_out_1d_in32_tr32"):
     print(k, out[k].shape, out[k].dtype)
 np.savez_compressed(os.path.join(HERE, "preprocess_golden.npz"), **out)
 print("wrote preprocess_golden.npz")

@@ -297,6 +297,7 @@ CUSTOM_STACKS = [
     ([451, 352, 9], [1, 0]),                             # an encoder on its own (encoder.predict, emulator.py:753-754)
     ([9, 500, 512, 33], [1, 1, 0]),                      # odd widths up to the 512 limit
     ([451, 96, 9, 32, 451], [1, 2, 1, 0]),               # a variational autoencoder: predict uses z = z_mean
+    ([7, 96, 40], [1, 1]),                               # a ReLU OUTPUT layer (v21_mlp_create and engine.Dense allow one): every route must apply it
 ]
 
 

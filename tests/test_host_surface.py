@@ -85,3 +85,89 @@ def test_strict_reference_switch():
         assert abs(emu.freq2redshift(emu.redshift2freq(30.0)) - 30.0) < 1e-9  # tests/test_emulator.py:36-39
     finally:
         emu.set_strict_reference(False)
+
+
+class _FakeTrainer:
+    """Stands in for _native.Trainer in the fit() loop (no GPU): records the permutation of every epoch."""
+    max_batch = 1 << 20
+
+    class ctx:
+        nranks, rank, device = 1, 0, 0
+
+    def __init__(self, fail_at=None):
+        self.perms, self.fail_at = [], fail_at
+
+    def set_data(self, *a): pass
+    def set_lr(self, lr): pass
+    def get_state(self): return len(self.perms), None, None
+
+    def run_epoch(self, perm, batch):
+        if self.fail_at is not None and len(self.perms) == self.fail_at:
+            raise RuntimeError("device lost")
+        self.perms.append(None if perm is None else perm.copy())
+        return 1.0 / (1 + len(self.perms))
+
+    def evaluate(self, which, batch): return 0.5
+
+
+def _fit_with_fake_trainer(eng, monkeypatch, epochs, callbacks=(), fail_at=None, seed=None):
+    m = eng.Sequential([eng.Input((3,)), eng.Dense(4, "relu"), eng.Dense(2)])  # (draws its Glorot kernels from the shared stream)
+    m.compile(optimizer="adam", loss="mse")
+    if seed is not None:
+        eng.set_random_seed(seed)
+    fake = _FakeTrainer(fail_at)
+    monkeypatch.setattr(m, "_ensure_trainer", lambda b: fake)
+    x = np.zeros((50, 3), np.float32); y = np.zeros((50, 2), np.float32)
+    m.fit(x, y, batch_size=16, epochs=epochs, callbacks=list(callbacks))
+    return fake
+
+
+def test_fit_shuffle_stream_is_the_sequential_one_despite_the_look_ahead(monkeypatch):
+    """engine.Model.fit draws the next epoch's permutation while the current one runs -- from a COPY of the shared
+    generator.  The permutations, and the shared generator's state afterwards, must be exactly those of
+    drawing one permutation at the start of every epoch: (a) plain run; (b) a callback that draws from the shared
+    generator between epochs; (c) early stopping (the unused look-ahead leaves no trace); (d) set_random_seed from a
+    callback; (e) run_epoch raising (the worker pool is shut down, the generator is not ahead)."""
+    eng = pkg("engine")
+
+    # (a)
+    ref = np.random.default_rng(5)
+    fake = _fit_with_fake_trainer(eng, monkeypatch, 4, seed=5)
+    for p in fake.perms:
+        np.testing.assert_array_equal(p, ref.permutation(50).astype(np.int32))
+    assert eng._rng.bit_generator.state == ref.bit_generator.state
+
+    # (b) + (c): a callback uses the shared stream after every epoch and stops the fit after the third
+    class Draws:
+        def __init__(self): self.vals = []
+        def set_model(self, m): self.model = m
+        def on_epoch_end(self, epoch, logs=None):
+            self.vals.append(eng._rng.integers(0, 1 << 30))
+            if epoch == 2:
+                self.model.stop_training = True
+    ref = np.random.default_rng(6)
+    cb = Draws()
+    fake = _fit_with_fake_trainer(eng, monkeypatch, 10, [cb], seed=6)
+    assert len(fake.perms) == 3
+    for p, v in zip(fake.perms, cb.vals):
+        np.testing.assert_array_equal(p, ref.permutation(50).astype(np.int32))
+        assert v == ref.integers(0, 1 << 30)
+    assert eng._rng.bit_generator.state == ref.bit_generator.state
+
+    # (d) a callback re-seeds: the look-ahead drawn from the old generator must not be used
+    class Reseed:
+        def set_model(self, m): pass
+        def on_epoch_end(self, epoch, logs=None):
+            if epoch == 0:
+                eng.set_random_seed(99)
+    fake = _fit_with_fake_trainer(eng, monkeypatch, 3, [Reseed()], seed=7)
+    ref = np.random.default_rng(99)
+    for p in fake.perms[1:]:
+        np.testing.assert_array_equal(p, ref.permutation(50).astype(np.int32))
+
+    # (e) run_epoch raises in the second epoch
+    ref = np.random.default_rng(8)
+    with pytest.raises(RuntimeError, match="device lost"):
+        _fit_with_fake_trainer(eng, monkeypatch, 5, fail_at=1, seed=8)
+    ref.permutation(50); ref.permutation(50)  # two epochs began, two permutations were consumed
+    assert eng._rng.bit_generator.state == ref.bit_generator.state

@@ -25,6 +25,38 @@ def test_par_transform_matches_reference_golden(pg):
         ora.par_transform([0.0003, 4.2, 0.0, 0.055, 1.0, 0.1, 10.0], pg["par_train"]), pg["par_out_list"])
 
 
+F32_CASES = [  # (golden key, parameters, params_train): every dtype combination the reference's branch sees
+    ("par_out_in32_tr32", lambda g: g["par_in"].astype(np.float32), lambda g: g["par_train"].astype(np.float32)),
+    ("par_out_in32_tr64", lambda g: g["par_in"].astype(np.float32), lambda g: g["par_train"]),
+    ("par_out_in64_tr32", lambda g: g["par_in"], lambda g: g["par_train"].astype(np.float32)),
+    ("par_out_1d_in32_tr32", lambda g: g["par_in"].astype(np.float32)[3], lambda g: g["par_train"].astype(np.float32)),
+    ("par_out_1d_in32_tr64", lambda g: g["par_in"].astype(np.float32)[5], lambda g: g["par_train"]),
+    ("par_train32_out", lambda g: g["par_train"].astype(np.float32), lambda g: g["par_train"].astype(np.float32)),
+]
+
+
+@pytest.mark.parametrize("key,par,train", F32_CASES, ids=[c[0] for c in F32_CASES])
+def test_par_transform_float32_inputs_match_reference_golden(pg, key, par, train):
+    """preprocess.py:74-78 / 89-93: floor and log10 in the dtype of the array handed over, float64 result.
+    Oracle AND product, bit for bit against outputs of the reference run in the build container."""
+    pp = pkg("preprocess")
+    for fn in (ora.par_transform, pp.par_transform):
+        out = fn(par(pg), train(pg))
+        assert out.dtype == np.float64
+        np.testing.assert_array_equal(out, pg[key])
+    assert not np.array_equal(pg["par_out_in32_tr32"], pg["par_out"])  # the float32 branch IS a different result
+
+
+def test_par_transform_integer_array_is_the_documented_deviation(pg):
+    """an integer `parameters` array truncates the 1e-6 floor to 0 in the reference (-inf); the
+    product takes non-floating arrays to float64 first.  Lists of floats behave like the reference."""
+    pp = pkg("preprocess")
+    ints = np.array([[1, 5, 0, 1, 1, 1, 20]])
+    out = pp.par_transform(ints, pg["par_train"])
+    assert np.all(np.isfinite(out))
+    np.testing.assert_array_equal(out, pp.par_transform(ints.astype(np.float64), pg["par_train"]))
+
+
 def test_par_transform_train_box_is_unit_box(pg):
     # reference tests/test_preprocess.py:21-26
     t = ora.par_transform(pg["par_train"], pg["par_train"])

@@ -299,6 +299,33 @@ def test_vae_step_matches_oracle(ctx):
     np.testing.assert_allclose(st.forward(y[:20], "f32"), acts[-1], atol=2e-4, rtol=1e-4)
 
 
+def test_chain_job_table_is_validated_against_the_packed_streams(ctx):
+    """The small-batch f32 chain kernel follows a host-built job table into the packed weight streams without range
+    checks (csrc/train_chain32s.h; the r3 abort: a request past the end of a stream).  The host validates every address
+    a row names when the trainer is created; here the same check is handed a deliberately TRUNCATED stream and must
+    answer with an error instead of a launch -- for the stack of the aborted test and for the reference's autoencoder."""
+    native = pkg("_native")
+    for dims, act in (([451, 64, 9, 32, 451], [1, native.ACT_GAUSS, 1, 0]), ([451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0])):
+        st = native.Stack(ctx, dims, act)
+        tr = native.Trainer(st, "f32", 256)
+        tr.check_chain_jobs()                                     # the real streams: every row inside
+        with pytest.raises(native.EngineError, match="chain job table"):
+            tr.check_chain_jobs(bw_bytes=4096)                    # a backward stream cut to one chunk
+        with pytest.raises(native.EngineError, match="chain job table"):
+            tr.check_chain_jobs(fw_bytes=8192)
+    # the last 4-KiB chunk of the forward stream missing: only the rows of the last forward layer's last tile notice
+    st = native.Stack(ctx, [451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0])
+    tr = native.Trainer(st, "f32", 256)
+    frags = lambda d: ((d + 3) // 4 + 3) // 4 * 4                 # chain32s_frags
+    fw_bytes = sum(-(-n // 64) * frags(k) * 1024 for k, n in zip([451, 352, 9, 32, 352], [352, 9, 32, 352, 451]))
+    tr.check_chain_jobs(fw_bytes=fw_bytes)
+    with pytest.raises(native.EngineError, match="within the stream"):
+        tr.check_chain_jobs(fw_bytes=fw_bytes - 4096)
+    tr16 = native.Trainer(st, "f16", 256)
+    with pytest.raises(native.EngineError, match="no job table"):
+        tr16.check_chain_jobs()
+
+
 def test_vae_without_noise_and_kl_equals_plain_autoencoder(ctx):
     """kl_weight = 0 and eps = 0 must give the deterministic autoencoder of emulator.py:517:
     same loss and same gradients as the plain stack holding the z_mean columns."""
@@ -1108,6 +1135,46 @@ def test_joint_step_with_a_variational_autoencoder(ctx, prec):
     np.testing.assert_array_equal(sta.get_weights(), flat)
     d1, d2 = ste.get_weights() - ora.flatten_params(We, be), stx.get_weights() - ora.flatten_params(We, be)
     assert float(d1 @ d2 / (np.linalg.norm(d1) * np.linalg.norm(d2))) > (0.995 if prec == "f16" else 0.99999)
+
+
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_joint_step_trains_a_sampling_variational_autoencoder_like_the_autoencoder_alone(ctx, prec):
+    """Joint step, variational autoencoder at lr > 0 WITH sampling, several steps per epoch and two epochs: the
+    autoencoder's half must be, bit for bit, the autoencoder trained alone on the same permutations -- which holds only
+    if every optimizer step of the joint epoch keys its noise on its own step number (ChainStep::step_off; ADVICE r3:
+    the f32 branch of v21_joint_run_epoch drew the same eps in every step of an epoch)."""
+    native, synth = pkg("_native"), pkg("synth")
+    n, batch = 300, 128                                   # 3 steps per epoch, the last one partial
+    sig = synth.make_signals(n, seed=16)
+    y = ora.preproc(sig, sig)
+    par = np.random.default_rng(19).uniform(-1, 1, size=(n, 7)).astype(np.float32)
+    wa = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    ae_dims, ae_act = [451, 64, 9, 32, 451], [1, native.ACT_GAUSS, 1, 0]
+    em_dims, em_act = [7, 48, 9], [1, 0]
+    flat = (np.random.default_rng(13).normal(size=native.Stack(ctx, ae_dims, ae_act).num_params) * 0.05).astype(np.float32)
+    We, be = ora.init_mlp(em_dims, seed=12)
+
+    def ae_trainer():
+        st = native.Stack(ctx, ae_dims, ae_act); st.set_weights(flat)
+        tr = native.Trainer(st, prec, batch); tr.set_adam(lr=1e-3); tr.set_vae(1e-2, sample=True, seed=77)
+        tr.set_data(0, y, None, wa)
+        return st, tr
+    sta, tra = ae_trainer()
+    sts, trs = ae_trainer()                               # the autoencoder alone
+    ste = native.Stack(ctx, em_dims, em_act); ste.set_weights(ora.flatten_params(We, be))
+    tre = native.Trainer(ste, prec, batch); tre.set_adam(lr=2e-3)
+    tre.set_data(0, par, np.zeros((n, 9), np.float32), np.full(n, 1 / 9, np.float32))
+    joint = native.Joint(tra, tre, latent_layer=1)
+    for ep in range(2):
+        perm = ora.epoch_permutation(n, 21, ep)
+        la, le = joint.run_epoch(perm, batch)
+        ls = trs.run_epoch(perm, batch)
+        assert la == ls, (ep, la, ls)
+        np.testing.assert_array_equal(sta.get_weights(), sts.get_weights())
+        assert np.isfinite(le) and le > 0
+    # and the noise really differs from step to step: with the same draw in every step the epoch would equal one
+    # trained with the key frozen at the epoch's first step, which the stand-alone trainer above is not
+    assert tra.get_state()[0] == trs.get_state()[0] == 6
 
 
 @pytest.mark.parametrize("prec", ["f16", "f32"])
