@@ -31,8 +31,8 @@ class EngineError(RuntimeError):
 
 
 class AffineIn(C.Structure):
-    _fields_ = [("n", C.c_int32), ("log_mask", C.c_int32 * 8), ("zero_floor", C.c_float * 8),
-                ("lo", C.c_float * 8), ("scale", C.c_float * 8)]
+    _fields_ = [("n", C.c_int32), ("log_mask", C.c_int32 * 8), ("zero_floor", C.c_double * 8),
+                ("lo", C.c_double * 8), ("span", C.c_double * 8)]
 
 
 class AffineOut(C.Structure):
@@ -388,7 +388,7 @@ class Stack:
             t.log_mask[j] = int(bool(log_mask[j]))
             t.zero_floor[j] = float(zero_floor[j])
             t.lo[j] = float(lo[j])
-            t.scale[j] = float(2.0 / (float(hi[j]) - float(lo[j])))
+            t.span[j] = float(hi[j] - lo[j])  # float64, formed as the reference forms `maximum - minimum` (preprocess.py:106)
         check(self.lib.v21_mlp_set_input_transform(self.h, C.byref(t)))
 
     def set_output_transform(self, std, mean):

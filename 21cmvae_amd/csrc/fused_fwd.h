@@ -28,6 +28,7 @@
 #include <utility>
 
 #include "../../include/v21.h"
+#include "par_transform.h"
 
 namespace v21 {
 
@@ -406,13 +407,11 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
               if (a.in_transform) {
                 constexpr int g1 = f1 < 8 ? f1 : 7;
                 constexpr int g0 = f0 < 8 ? f0 : 7;
-                const float zf = h ? a.tin.zero_floor[g1] : a.tin.zero_floor[g0];
+                const double zf = h ? a.tin.zero_floor[g1] : a.tin.zero_floor[g0];
                 const int lm = h ? a.tin.log_mask[g1] : a.tin.log_mask[g0];
-                const float lo = h ? a.tin.lo[g1] : a.tin.lo[g0];
-                const float sc = h ? a.tin.scale[g1] : a.tin.scale[g0];
-                if (zf > 0.f && t == 0.f) t = zf;
-                if (lm) t = __log10f(t);
-                t = (t - lo) * sc - 1.0f;
+                const double lo = h ? a.tin.lo[g1] : a.tin.lo[g0];
+                const double sp = h ? a.tin.span[g1] : a.tin.span[g0];
+                t = par_transform_f32(t, lm, zf, lo, sp);  // (train_kernels.h: float64 log10 and map)
               }
             }
           }

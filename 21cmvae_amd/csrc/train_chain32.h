@@ -138,10 +138,7 @@ __device__ __forceinline__ void train_chain32_body(const ChainModel& a, const Ch
       float t = xs[k < K0 ? k : K0 - 1];
       if (i == 0 && GO(st.tin)) {  // par_transform on the (<= 8) input columns, as affine_in_kernel does it
         const int jc = lane < K0 ? lane : 0;
-        const float zf = st.tin->zero_floor[jc];
-        if (zf > 0.f && t == 0.f) t = zf;
-        if (st.tin->log_mask[jc]) t = __log10f(t);
-        t = (t - st.tin->lo[jc]) * st.tin->scale[jc] - 1.0f;
+        t = par_transform_f32(t, st.tin->log_mask[jc], st.tin->zero_floor[jc], st.tin->lo[jc], st.tin->span[jc]);
       }
       v[i] = k < kmax ? t : 0.f;
     }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/v21.h"
+#include "par_transform.h"
 
 namespace v21 {
 
@@ -419,17 +420,18 @@ __global__ void copy_pad_kernel(float* __restrict__ dst, long long ldd, const fl
   dst[i] = j < d ? src[row * lds_ + j] : 0.f;
 }
 
-// generic-path prologue / epilogue (the fused kernel does these in registers)
-__global__ void affine_in_kernel(float* __restrict__ dst, long long ldd, const float* __restrict__ src,
+// per-layer-path prologue (the fused and the chain kernels do this while they gather their rows); SRC = float: rows in
+// device memory / float32 host rows; SRC = double: float64 host rows staged as they are (v21_mlp_forward)
+template <class SRC>
+__global__ void affine_in_kernel(float* __restrict__ dst, long long ldd, const SRC* __restrict__ src,
                                  long long lds_, long long n, const v21_affine_in t) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * t.n) return;
   const long long row = i / t.n;
   const int j = (int)(i % t.n);
-  float x = src[row * lds_ + j];
-  if (t.zero_floor[j] > 0.f && x == 0.f) x = t.zero_floor[j];
-  if (t.log_mask[j]) x = __log10f(x);
-  dst[row * ldd + j] = (x - t.lo[j]) * t.scale[j] - 1.0f;
+  const SRC x = src[row * lds_ + j];
+  if constexpr (sizeof(SRC) == 8) dst[row * ldd + j] = par_transform_f64(x, t.log_mask[j], t.zero_floor[j], t.lo[j], t.span[j]);
+  else dst[row * ldd + j] = par_transform_f32(x, t.log_mask[j], t.zero_floor[j], t.lo[j], t.span[j]);
 }
 __global__ void affine_out_kernel(float* __restrict__ y, long long ldy, long long n, int d,
                                   float stdv, const float* __restrict__ mean) {

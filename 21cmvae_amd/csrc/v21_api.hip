@@ -144,6 +144,10 @@ struct v21_ctx {
   float* h_stage = nullptr;
   size_t h_stage_n = 0;
   int sharded = 0;  // 1: reduce-scatter -> Adam on this rank's shard -> all-gather (v21_comm_set_sharded)
+  // v21_mlp_forward on many rows: results leave over PCIe on a second stream, slice by slice, while the next slice
+  // is being computed (created on first use)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t slice_done[2] = {nullptr, nullptr};
 };
 // ncclDataType_t / ncclRedOp_t values of rccl.h (the library is dlopen'ed, its header is not included)
 constexpr int kNcclFloat32 = 7, kNcclSum = 0;
@@ -173,6 +177,8 @@ extern "C" int v21_ctx_destroy(v21_ctx* c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->own) { hipStreamSynchronize(c->own); hipStreamDestroy(c->own); }
+  if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+  for (hipEvent_t e : c->slice_done) if (e) hipEventDestroy(e);
   delete c;
   return V21_OK;
 }
@@ -271,6 +277,7 @@ struct v21_mlp {
   long long act_rows = 0;
   // host-API staging
   float *d_xs = nullptr, *d_ys = nullptr;
+  double* d_xs64 = nullptr;  // float64 rows of v21_mlp_forward awaiting the float64 par_transform
   long long stage_rows = 0;
   int maxdim = 0;
   bool wpad_ok = false;  // false after the arena was rewritten from outside a trainer (set_weights)
@@ -353,6 +360,7 @@ extern "C" int v21_mlp_destroy(v21_mlp* m) {
   for (int i = 0; i < 3; ++i) { if (m->d_cfw[i]) hipFree(m->d_cfw[i]); if (m->d_cbw[i]) hipFree(m->d_cbw[i]); }
   if (m->d_tin) hipFree(m->d_tin);
   if (m->d_xs) hipFree(m->d_xs);
+  if (m->d_xs64) hipFree(m->d_xs64);
   if (m->d_ys) hipFree(m->d_ys);
   delete m;
   return V21_OK;
@@ -390,6 +398,9 @@ extern "C" int v21_mlp_set_input_transform(v21_mlp* m, const v21_affine_in* t) {
   if (!m) return fail(V21_ERR_ARG, "null mlp");
   if (!t) { m->has_tin = false; return V21_OK; }
   if (t->n != m->dims[0] || t->n > 8) return fail(V21_ERR_ARG, "input transform: n = %d, stack input = %d (max 8)", t->n, m->dims[0]);
+  for (int j = 0; j < t->n; ++j)
+    if (!(t->span[j] == t->span[j]) || !(t->lo[j] == t->lo[j]))
+      return fail(V21_ERR_ARG, "input transform: column %d has a NaN minimum or span", j);
   m->tin = *t;
   m->has_tin = true;
   CHK(use(m->ctx));
@@ -504,7 +515,7 @@ static int forward_generic(v21_mlp* m, const float* d_x, long long ldx, long lon
     int cur = 0;
     if ((flags & V21_FWD_IN_TRANSFORM) && m->has_tin) {
       const long long tot = (long long)rows * m->dims[0];
-      hipLaunchKernelGGL(affine_in_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->d_act[0],
+      hipLaunchKernelGGL(affine_in_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->d_act[0],
                          (long long)m->dims[0], in, ldx, (long long)rows, m->tin);
       HIPCHK(hipGetLastError());
       in = m->d_act[0]; ldin = m->dims[0]; cur = 1;
@@ -600,7 +611,9 @@ extern "C" int v21_mlp_forward(v21_mlp* m, const void* x, int x_dtype, int64_t n
   if (m->stage_rows < need) {
     if (m->d_xs) HIPCHK(hipFree(m->d_xs));
     if (m->d_ys) HIPCHK(hipFree(m->d_ys));
+    if (m->d_xs64) HIPCHK(hipFree(m->d_xs64));
     HIPCHK(hipMalloc((void**)&m->d_xs, (size_t)need * din * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&m->d_xs64, (size_t)need * din * sizeof(double)));
     HIPCHK(hipMalloc((void**)&m->d_ys, (size_t)need * dout * sizeof(float)));
     m->stage_rows = need;
   }
@@ -609,8 +622,30 @@ extern "C" int v21_mlp_forward(v21_mlp* m, const void* x, int x_dtype, int64_t n
   if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
   if ((flags & V21_FWD_IN_TRANSFORM) && !m->has_tin) return fail(V21_ERR_STATE, "input transform requested but not set");
   if ((flags & V21_FWD_OUT_TRANSFORM) && !m->has_tout) return fail(V21_ERR_STATE, "output transform requested but not set");
-  if (takes_small_path(m, n, precision, flags) && !(flags & V21_FWD_IN_TRANSFORM)) {
-    // few rows: pad the rows on the host, so the first layer reads the staging buffer in place (one launch fewer)
+  const bool tin = (flags & V21_FWD_IN_TRANSFORM) != 0;
+  // par_transform of one value ON THE HOST, for the few-row route below: the same two branches as the device's
+  // (par_transform.h) with libm's log10 / log10f -- what numpy calls for float64 / float32 arrays
+  auto host_value = [&](long long r, int j) -> float {
+    if (x_dtype == V21_DTYPE_F64) {
+      double t = ((const double*)x)[r * din + j];
+      if (!tin) return (float)t;  // Keras casts float64 inputs to float32 [K]
+      const v21_affine_in& a = m->tin;
+      if (a.zero_floor[j] > 0.0 && t == 0.0) t = a.zero_floor[j];
+      if (a.log_mask[j]) t = std::log10(t);
+      t -= a.lo[j]; t /= a.span[j]; t *= 2.0; t -= 1.0;  // preprocess.py:105-108, in this order
+      return (float)t;
+    }
+    float f = ((const float*)x)[r * din + j];
+    if (!tin) return f;
+    const v21_affine_in& a = m->tin;
+    if (a.zero_floor[j] > 0.0 && f == 0.f) f = (float)a.zero_floor[j];
+    double t = a.log_mask[j] ? (double)std::log10(f) : (double)f;  // (log10f: np.log10 of a float32 array)
+    t -= a.lo[j]; t /= a.span[j]; t *= 2.0; t -= 1.0;
+    return (float)t;
+  };
+  if (takes_small_path(m, n, precision, flags & ~V21_FWD_IN_TRANSFORM) && (!tin || din <= 8)) {
+    // few rows: transform (if asked) and pad the rows on the host, so the first layer reads the staging buffer in
+    // place (two launches fewer than transforming on the device)
     const long long ldp = p16(din);
     if (m->stage_pad_rows < n) {
       if (m->d_xpad) HIPCHK(hipFree(m->d_xpad));
@@ -619,28 +654,65 @@ extern "C" int v21_mlp_forward(v21_mlp* m, const void* x, int x_dtype, int64_t n
     }
     tmp.assign((size_t)n * ldp, 0.f);
     for (long long r = 0; r < n; ++r)
-      for (int j = 0; j < din; ++j)
-        tmp[(size_t)r * ldp + j] = x_dtype == V21_DTYPE_F64 ? (float)((const double*)x)[r * din + j] : ((const float*)x)[r * din + j];
+      for (int j = 0; j < din; ++j) tmp[(size_t)r * ldp + j] = host_value(r, j);
     HIPCHK(hipMemcpyAsync(m->d_xpad, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    CHK(forward_small(m, m->d_xpad, ldp, n, m->d_ys, dout, precision, flags | V21_FWD_X_PADDED));
+    CHK(forward_small(m, m->d_xpad, ldp, n, m->d_ys, dout, precision, (flags & ~V21_FWD_IN_TRANSFORM) | V21_FWD_X_PADDED));
     HIPCHK(hipMemcpyAsync(y, m->d_ys, (size_t)n * dout * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return V21_OK;
   }
   for (long long r0 = 0; r0 < n; r0 += chunk) {
     const long long rows = std::min(chunk, n - r0);
-    const float* src;
-    if (x_dtype == V21_DTYPE_F64) {  // Keras casts float64 inputs to float32 [K]
-      tmp.resize((size_t)rows * din);
+    int fl = flags;
+    if (x_dtype == V21_DTYPE_F64 && tin) {
+      // float64 parameters: staged as they are and transformed in float64 on the device (the reference's float64
+      // branch, preprocess.py:74-108), the float32 cast after the map as Keras does it [K]
       const double* xd = (const double*)x + r0 * din;
-      for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (float)xd[i];
-      src = tmp.data();
+      HIPCHK(hipMemcpyAsync(m->d_xs64, xd, (size_t)rows * din * sizeof(double), hipMemcpyHostToDevice, st));
+      const long long tot = rows * din;
+      hipLaunchKernelGGL(affine_in_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->d_xs, (long long)din,
+                         (const double*)m->d_xs64, (long long)din, rows, m->tin);
+      HIPCHK(hipGetLastError());
+      fl &= ~V21_FWD_IN_TRANSFORM;
     } else {
-      src = (const float*)x + r0 * din;
+      const float* src;
+      if (x_dtype == V21_DTYPE_F64) {  // Keras casts float64 inputs to float32 [K]
+        tmp.resize((size_t)rows * din);
+        const double* xd = (const double*)x + r0 * din;
+        for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (float)xd[i];
+        src = tmp.data();
+      } else {
+        src = (const float*)x + r0 * din;
+      }
+      HIPCHK(hipMemcpyAsync(m->d_xs, src, (size_t)rows * din * sizeof(float), hipMemcpyHostToDevice, st));
     }
-    HIPCHK(hipMemcpyAsync(m->d_xs, src, (size_t)rows * din * sizeof(float), hipMemcpyHostToDevice, st));
-    CHK(v21_mlp_forward_dev(m, m->d_xs, din, rows, m->d_ys, dout, precision, flags));
-    HIPCHK(hipMemcpyAsync(y + r0 * dout, m->d_ys, (size_t)rows * dout * sizeof(float), hipMemcpyDeviceToHost, st));
+    // The results are 1,804 B per row against 28-56 B of input: the call is bound by their way back over PCIe
+    // (65,536 rows: 118 MB, ~2.1 ms).  Slices of kSliceRows rows are computed on the context's stream and copied
+    // out on a second one, so that only the FIRST slice's kernel is not hidden under a copy (f32, 65,536 rows:
+    // 0.46 ms of kernel + 2.2 ms of copy one after the other -> 0.12 + 2.2 ms).
+    constexpr long long kSliceRows = 16384;
+    if (rows <= kSliceRows) {
+      CHK(v21_mlp_forward_dev(m, m->d_xs, din, rows, m->d_ys, dout, precision, fl));
+      HIPCHK(hipMemcpyAsync(y + r0 * dout, m->d_ys, (size_t)rows * dout * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      continue;
+    }
+    v21_ctx* c = m->ctx;
+    if (!c->copy_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+      for (hipEvent_t& e : c->slice_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    int k = 0;
+    for (long long s0 = 0; s0 < rows; s0 += kSliceRows, ++k) {
+      const long long srows = std::min(kSliceRows, rows - s0);
+      CHK(v21_mlp_forward_dev(m, m->d_xs + s0 * din, din, srows, m->d_ys + s0 * dout, dout, precision, fl));
+      // (an event is reused every other slice: the copy that waited on its previous record was enqueued before this one)
+      HIPCHK(hipEventRecord(c->slice_done[k & 1], st));
+      HIPCHK(hipStreamWaitEvent(c->copy_stream, c->slice_done[k & 1], 0));
+      HIPCHK(hipMemcpyAsync(y + (r0 + s0) * dout, m->d_ys + s0 * dout, (size_t)srows * dout * sizeof(float), hipMemcpyDeviceToHost,
+                            c->copy_stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
     HIPCHK(hipStreamSynchronize(st));
   }
   return V21_OK;
@@ -1178,7 +1250,7 @@ static int forward_small(v21_mlp* m, const float* d_x, long long ldx, long long 
     a0 = d_x; lda0 = ldx;
   } else if ((flags & V21_FWD_IN_TRANSFORM) && m->has_tin) {
     const long long tot = (long long)rows * m->dims[0];
-    hipLaunchKernelGGL(affine_in_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->d_small[0], ld0, d_x,
+    hipLaunchKernelGGL(affine_in_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->d_small[0], ld0, d_x,
                        ldx, (long long)rows, m->tin);
   } else {
     const long long tot = (long long)rows * ld0;

@@ -150,30 +150,53 @@ def _grid(redshifts_, frequencies):
 class _EmulatorBase:
     par_labels = ["fstar", "Vc", "fx", "tau", "alpha", "nu_min", "Rmfp"]
 
-    def _set_data(self, par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data=False):
+    def _set_data(self, par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data=True):
+        """``freeze_data`` (default True; not in the reference): ``self.par_train`` and ``self.signal_train`` -- the two
+        arrays whose statistics every ``predict`` needs -- are PRIVATE READ-ONLY COPIES of what the caller passed.  The
+        reference keeps the caller's arrays and recomputes mean / std / min / max of the ~44 MB training set on every
+        call (preprocess.py:22-23, 44-45, 89-101); caching those numbers is exact only while the buffer cannot change,
+        and a read-only copy nobody else holds cannot: a call costs no checksum (r3's default re-hashed the 44 MB per
+        call to stay exact: 1.24 ms for one parameter vector), and an attempt to edit ``em.signal_train`` in place
+        raises numpy's "assignment destination is read-only" instead of being silently ignored.  To change the
+        training set, ASSIGN a new array (``em.signal_train = new``: a new identity, new statistics) or build a new
+        emulator.  ``freeze_data=False`` keeps the reference's by-reference semantics -- the caller's own writable
+        arrays, edits in place honoured -- at the price of a whole-buffer hash per call (``preprocess._cached``)."""
         d = _resolve_data(dict(par_train=par_train, par_val=par_val, par_test=par_test,
                                signal_train=signal_train, signal_val=signal_val, signal_test=signal_test))
         for k, v in d.items():
-            # freeze_data: private read-only copies of the two arrays whose statistics every call needs, so the
-            # statistics cache is exact without hashing ~44 MB per predict() (preprocess.freeze)
-            if freeze_data and k in ("par_train", "signal_train"):
+            if freeze_data and k in ("par_train", "signal_train") and not pp._is_frozen(v):
                 v = pp.freeze(v)
             setattr(self, k, v)
         self.par_labels = list(_EmulatorBase.par_labels)
 
     def _predict_stack(self, model, params, devices=None):
-        """par_transform -> device stack -> unpreproc, squeezing a single row
-        (emulator.py:401-407 / :788-795).  The parameter transform is done on the host in
-        float64 exactly as the reference does; the un-preprocessing is fused into the
-        last layer's epilogue on the device."""
-        x = pp.par_transform(params, self.par_train)
+        """par_transform -> device stack -> unpreproc, squeezing a single row (emulator.py:401-407 / :788-795).
+        Both transforms run inside the library: float32 and float64 parameter arrays are handed over RAW and take the
+        reference's branch for their dtype there (include/v21.h: v21_affine_in; few rows: on the host while they are
+        padded, many: in float64 on the device, so a 65,536-row call is bound by the 118 MB of results over PCIe and not
+        by a 4-ms numpy transform); the un-preprocessing rides in the last layer's epilogue.  Any other dtype is
+        transformed by ``preprocess.par_transform`` first."""
+        from . import _native as nat
+        x = np.asarray(params)
+        if x.ndim == 1:
+            x = x[None, :]
         st = model._ensure_stack()
         ss = pp.SignalStats.of(self.signal_train)
         if getattr(st, "_out_stats", None) is not ss:  # a new record whenever the training set changed (even in place)
             st.set_output_transform(ss.std, ss.mean)
             st._out_stats = ss
-        from . import _native as nat
-        pred = model.predict(x, devices=devices, flags=nat.FWD_OUT_TRANSFORM)
+        flags = nat.FWD_OUT_TRANSFORM
+        if not np.issubdtype(x.dtype, np.floating):
+            x = x.astype(np.float64)  # (documented deviation: the reference truncates the fx floor in integer arrays)
+        if x.dtype in (np.float32, np.float64) and x.shape[-1] <= 8:
+            ps = pp.ParamStats.of(self.par_train)
+            if getattr(st, "_in_stats", None) is not ps:
+                st.set_input_transform(ps.log_mask, ps.zero_floor, ps.lo, ps.hi)
+                st._in_stats = ps
+            flags |= nat.FWD_IN_TRANSFORM
+        else:
+            x = pp.par_transform(x, self.par_train)
+        pred = model.predict(x, devices=devices, flags=flags)
         return pred[0, :] if pred.shape[0] == 1 else pred
 
     def save(self):
@@ -185,7 +208,7 @@ class DirectEmulator(_EmulatorBase):
 
     def __init__(self, par_train=None, par_val=None, par_test=None, signal_train=None, signal_val=None,
                  signal_test=None, hidden_dims=hidden_dims, activation_func="relu", redshifts=redshifts,
-                 frequencies=None, precision="f32", freeze_data=False):
+                 frequencies=None, precision="f32", freeze_data=True):
         self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data)
         self.emulator = _gen_model(self.par_train.shape[-1], hidden_dims, self.signal_train.shape[-1],
                                    activation_func, name="emulator")
@@ -268,7 +291,7 @@ class AutoEncoderEmulator(_EmulatorBase):
                  signal_test=None, latent_dim=latent_dim, enc_hidden_dims=enc_hidden_dims,
                  dec_hidden_dims=dec_hidden_dims, em_hidden_dims=em_hidden_dims, activation_func="relu",
                  redshifts=redshifts, frequencies=None, precision="f32", variational=False, kl_weight=0.0,
-                 freeze_data=False):
+                 freeze_data=True):
         self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data)
         self.redshifts, self.frequencies = _grid(redshifts, frequencies)
         autoencoder = AutoEncoder(self.signal_train, enc_hidden_dims, dec_hidden_dims, latent_dim, activation_func,

@@ -255,7 +255,7 @@ class Model:
         # trained weights newer than the host copies: pulled back ONCE (that bumps the layer versions, hence the
         # signature below), so the replicas are refreshed once per change and not on every call after a fit()
         self._sync_host()
-        sig = (id(st), self._stack_sig, id(getattr(st, "_out_stats", None)))
+        sig = (id(st), self._stack_sig, id(getattr(st, "_out_stats", None)), id(getattr(st, "_in_stats", None)))
         flat = None
         stacks = []
         for slot, d in enumerate(devices):  # one replica per LIST ENTRY (an ordinal may appear twice)
@@ -269,6 +269,9 @@ class Model:
                 rs.set_weights(flat)
                 if getattr(st, "_out_stats", None) is not None:
                     rs.set_output_transform(st._out_stats.std, st._out_stats.mean)
+                if getattr(st, "_in_stats", None) is not None:
+                    ps = st._in_stats
+                    rs.set_input_transform(ps.log_mask, ps.zero_floor, ps.lo, ps.hi)
                 reps[key] = ent = (sig, rs)
             stacks.append(ent[1])
         n = x.shape[0]

@@ -399,21 +399,51 @@ def accuracy_leg(native, ctx):
     return out
 
 
-def latency_leg():
-    """Auxiliary metric: what a sampler sees -- DirectEmulator.predict() on ONE parameter vector through
-    the class surface (numpy in, numpy out; host transform, PCIe both ways, synchronisation included), with a
-    training set of the reference's size (24,562 rows).  The reference quotes 40 ms per call (README.rst:11) and
-    recomputes the training-set statistics on every call; for arrays the CALLER passed in this package re-hashes them
-    on every call instead (exactness against in-place edits of a buffer the caller still holds), and
-    `freeze_data=True` (private read-only copies) removes that cost.  An emulator built without explicit data -- the
-    reference's default use -- takes read-only arrays from the data set file and needs no checksum
-    (`f32_no_argument_constructor`: a synthetic dataset_21cmVAE.h5 of the reference's size, written to a temporary directory)."""
+def class_surface_leg():
+    """What a user of the reference's API gets: ``DirectEmulator.predict(params)`` -- numpy in, numpy
+    out, both transforms, PCIe both ways, the Python layer -- at configs[1]'s 65,536 rows and at configs[0]'s 1,000 rows,
+    for float64 parameters (numpy's default; transformed in float64 on the device) and float32 ones (the reference's
+    float32 branch inside the kernel prologue).  Training set of the reference's size.  The PCIe bound for 65,536 rows
+    is ~34 M signals/s (118 MB of float32 results at ~63 GB/s)."""
     synth = importlib.import_module("21cmvae_amd.synth")
     emu = importlib.import_module("21cmvae_amd.emulator")
     data = synth.make_dataset(synth.N_TRAIN, 400, 400)
     res = {}
-    for key, prec, freeze, reps in (("f32_freeze_data", "f32", True, 200), ("f16_freeze_data", "f16", True, 200),
-                                    ("f32_default_rehash", "f32", False, 10)):
+    for prec in ("f16", "f32"):
+        em = emu.DirectEmulator(hidden_dims=DIMS[1:-1], precision=prec, **data)
+        for rows, reps in ((BATCH, 10), (1000, 200)):
+            for dt in (np.float64, np.float32):
+                par = synth.make_params(rows, seed=77).astype(dt)
+                for _ in range(3):
+                    y = em.predict(par)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    y = em.predict(par)
+                dtm = (time.perf_counter() - t0) / reps
+                assert y.shape == (rows, DIMS[-1])
+                res["%s_rows%d_params_%s" % (prec, rows, np.dtype(dt).name)] = {"signals_per_s": rows / dtm, "ms_per_call": dtm * 1e3}
+                del y
+    res["note"] = ("DirectEmulator.predict on host arrays, 7->[352,352,352,224]->451; results of 65,536 rows land in pooled "
+                   "page-locked memory; r3 transformed the parameters with numpy on the host (4.3 ms per 65,536 rows)")
+    return res
+
+
+def latency_leg():
+    """Auxiliary metric: what a sampler sees -- DirectEmulator.predict() on ONE parameter vector through
+    the class surface (numpy in, numpy out; transforms, PCIe both ways, synchronisation included), with a
+    training set of the reference's size (24,562 rows).  The reference quotes 40 ms per call (README.rst:11) and
+    recomputes the training-set statistics on every call.  `f32_default` / `f16_default`: the constructor's default since
+    r4 (`freeze_data=True`: private read-only copies of the training arrays, statistics cached on identity, no checksum);
+    `f32_freeze_data_false_rehash`: the reference's by-reference arrays, re-hashed on every call (r3's default, then
+    called `f32_default_rehash`).  An emulator built without explicit data -- the reference's default use -- takes
+    read-only arrays from the data set file (`f32_no_argument_constructor`: a synthetic dataset_21cmVAE.h5 of the
+    reference's size, written to a temporary directory)."""
+    synth = importlib.import_module("21cmvae_amd.synth")
+    emu = importlib.import_module("21cmvae_amd.emulator")
+    data = synth.make_dataset(synth.N_TRAIN, 400, 400)
+    res = {}
+    for key, prec, freeze, reps in (("f32_default", "f32", True, 200), ("f16_default", "f16", True, 200),
+                                    ("f32_freeze_data_false_rehash", "f32", False, 10)):
         em = emu.DirectEmulator(hidden_dims=DIMS[1:-1], precision=prec, freeze_data=freeze, **data)
         p1 = data["par_test"][0]
         for _ in range(5):
@@ -866,6 +896,10 @@ def main():
             out["accuracy_on_trained_stack"] = accuracy_leg(native, ctx)
         except Exception as e:
             out["accuracy_on_trained_stack"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            out["class_surface_predict"] = class_surface_leg()
+        except Exception as e:
+            out["class_surface_predict"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             out["single_call_latency"] = latency_leg()
         except Exception as e:

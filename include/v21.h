@@ -54,16 +54,24 @@ enum { V21_PREC_F32 = 0, V21_PREC_F16 = 1, V21_PREC_BF16 = 2 };
 enum { V21_ACT_LINEAR = 0, V21_ACT_RELU = 1, V21_ACT_GAUSS = 2 };
 enum { V21_DTYPE_F32 = 0, V21_DTYPE_F64 = 1 };
 
-/* Fused prologue = preprocess.par_transform (preprocess.py:49-110) with the
- * training-set statistics cached: y_j = ((log_mask_j ? log10(x_j) : x_j) - lo_j)
- * * scale_j - 1, scale_j = 2/(hi_j-lo_j); x_j == 0 -> zero_floor_j first when
- * zero_floor_j > 0 (the fx == 0 -> 1e-6 rule, preprocess.py:76).  n <= 8. */
+/* Fused prologue = preprocess.par_transform (preprocess.py:49-110) with the training-set statistics cached:
+ *   t = x_j;  if (zero_floor_j > 0 && t == 0) t = zero_floor_j      (fx == 0 -> 1e-6, preprocess.py:76)
+ *   if (log_mask_j) t = log10(t)                                     (preprocess.py:77-78)
+ *   y_j = (t - lo_j) / span_j * 2 - 1,  span_j = hi_j - lo_j         (preprocess.py:105-108, float64)
+ * and the float32 cast Keras applies to the float64 result [K].  lo / hi are the column minima / maxima of the
+ * log-transformed TRAINING parameters (float64, computed by the host as the reference computes them, :89-101).
+ * The reference floors and takes log10 IN THE DTYPE OF THE ARRAY IT IS HANDED (:74-78) and does the affine map in
+ * float64 (:81-85, :105-108); the library keeps both branches:
+ *   float64 rows (v21_mlp_forward with V21_DTYPE_F64): floor, log10 and map in float64 on the device;
+ *   float32 rows (V21_DTYPE_F32, and every device-resident input): floor = (float)zero_floor_j, log10 rounded to
+ *     float32 (the correctly rounded log10f), then the float64 map -- numpy's float32 branch up to log10f's last bit.
+ * n <= 8. */
 typedef struct {
   int32_t n;
   int32_t log_mask[8];
-  float zero_floor[8];
-  float lo[8];
-  float scale[8];
+  double zero_floor[8];
+  double lo[8];
+  double span[8];
 } v21_affine_in;
 
 /* Fused epilogue = preprocess.unpreproc (preprocess.py:27-46): y*std + mean_j. */

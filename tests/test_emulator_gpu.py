@@ -160,6 +160,37 @@ def test_autoencoder_emulator_load_predict_shipped_weights(data, shipped):
     assert d.mean() < 0.05
 
 
+@pytest.mark.parametrize("n", [1, 10, 300, 6000])
+def test_predict_with_float32_and_float64_parameters_on_the_shipped_weights(shipped, n):
+    """The reference floors and takes log10 in the dtype of the parameter array it is handed (preprocess.py:74-78); float32
+    `parameters` and float32 `par_train` therefore give other transformed inputs than float64 ones.  Through the class
+    surface (AutoEncoderEmulator.predict on the reference's trained weights; 1 / 10 / 300 rows: the few-row route, 6,000:
+    the one-launch kernel with the device prologue) every dtype combination must meet oracle.ae_predict -- which follows
+    the reference's dtype branch and is pinned to it by reference-generated goldens (tests/test_oracle.py) -- at the
+    stated f32 tolerance: atol 2e-5 in pre-processed units."""
+    emulator, synth = pkg("emulator"), pkg("synth")
+    data = synth.make_dataset(n_train=3000, n_val=50, n_test=max(n, 2), seed=11)
+    std = float(np.std(data["signal_train"]))
+    for tr_dt in (np.float64, np.float32):
+        d = dict(data)
+        d["par_train"] = data["par_train"].astype(tr_dt)
+        ae_em = emulator.AutoEncoderEmulator(**d)
+        ae_em.load_model()
+        for in_dt in (np.float64, np.float32):
+            pars = data["par_test"][:n].astype(in_dt)
+            ref = ora.ae_predict(shipped["ae_emulator"], shipped["decoder"], pars, d["par_train"], d["signal_train"], dtype=np.float64)
+            got = ae_em.predict(pars)
+            assert got.shape == ref.shape and got.dtype == np.float32
+            np.testing.assert_allclose(got, ref, atol=2e-5 * std, rtol=1e-5, err_msg="par_train %s, parameters %s" % (tr_dt.__name__, in_dt.__name__))
+    # integer parameters: the documented deviation (taken to float64; the reference would return -inf for fx == 0)
+    ints = np.array([[1, 20, 0, 1, 1, 1, 30]] * 3)
+    np.testing.assert_array_equal(ae_em.predict(ints), ae_em.predict(ints.astype(np.float64)))
+    # float16 parameters: transformed by preprocess.par_transform on the host (the reference's branch for that dtype)
+    p16 = data["par_test"][:4].astype(np.float16)
+    ref = ora.ae_predict(shipped["ae_emulator"], shipped["decoder"], p16, d["par_train"], d["signal_train"], dtype=np.float64)
+    np.testing.assert_allclose(ae_em.predict(p16), ref, atol=2e-5 * std, rtol=1e-5)
+
+
 def test_autoencoder_emulator_two_phase_training(data):
     emulator, optm, eng = pkg("emulator"), pkg("optimizers"), pkg("engine")
     eng.set_random_seed(1)

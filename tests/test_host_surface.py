@@ -57,6 +57,39 @@ def test_frozen_copies_are_cached_on_identity_and_cannot_change():
     assert pp.SignalStats.of(v) is not a
 
 
+def test_emulators_snapshot_their_training_set_by_default(monkeypatch):
+    """r4 contract of the class surface: an emulator keeps private read-only copies of
+    par_train / signal_train (freeze_data=True), so its statistics cache is exact WITHOUT a per-call checksum -- an
+    in-place edit of the emulator's array raises, an edit of the caller's array no longer reaches the emulator, and
+    assigning a new array is seen; freeze_data=False keeps the reference's by-reference arrays and the whole-buffer
+    hash of every call (r3's default)."""
+    emu, pp, synth = pkg("emulator"), pkg("preprocess"), pkg("synth")
+    data = synth.make_dataset(n_train=400, n_val=20, n_test=20, seed=2)
+    em = emu.DirectEmulator(hidden_dims=[8], **data)
+    for k in ("par_train", "signal_train"):
+        a = getattr(em, k)
+        assert a is not data[k] and not a.flags.writeable and np.array_equal(a, data[k])
+    assert em.par_val is data["par_val"]                      # (only the two arrays with cached statistics are copied)
+    s0, p0 = pp.SignalStats.of(em.signal_train), pp.ParamStats.of(em.par_train)
+    calls = []
+    monkeypatch.setattr(pp, "_digest", lambda buf: calls.append(1) or b"x")
+    assert pp.SignalStats.of(em.signal_train) is s0 and pp.ParamStats.of(em.par_train) is p0 and not calls   # no hash
+    with pytest.raises(ValueError, match="read-only"):
+        em.signal_train[0, 0] = 1.0
+    data["signal_train"][0, 0] += 50.0                        # the caller's buffer is not the emulator's any more
+    assert pp.SignalStats.of(em.signal_train) is s0
+    monkeypatch.undo()
+    em.signal_train = data["signal_train"]                    # assignment: a new identity, new statistics
+    s1 = pp.SignalStats.of(em.signal_train)
+    assert s1 is not s0 and s1.mean[0] == np.mean(data["signal_train"], axis=0)[0]
+    # the reference's by-reference semantics on request
+    em2 = emu.AutoEncoderEmulator(freeze_data=False, enc_hidden_dims=[8], dec_hidden_dims=[8], em_hidden_dims=[8], **data)
+    assert em2.signal_train is data["signal_train"] and em2.par_train is data["par_train"]
+    a = pp.SignalStats.of(em2.signal_train)
+    data["signal_train"][3, 3] += 1.0
+    assert pp.SignalStats.of(em2.signal_train) is not a       # the in-place edit is seen (whole-buffer hash)
+
+
 def test_strict_reference_switch():
     emu = pkg("emulator")
     nu = np.linspace(50.0, 200.0, 451)
