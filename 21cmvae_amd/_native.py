@@ -18,7 +18,7 @@ PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32,
               "f16": PREC_F16, "fp16": PREC_F16, "float16": PREC_F16,
               "bf16": PREC_BF16, "bfloat16": PREC_BF16}
 ACT_LINEAR, ACT_RELU, ACT_GAUSS = 0, 1, 2
-FWD_IN_TRANSFORM, FWD_OUT_TRANSFORM, FWD_FORCE_GENERIC, FWD_NO_SMALL, FWD_FORCE_CHAIN = 1, 2, 4, 8, 16
+FWD_IN_TRANSFORM, FWD_OUT_TRANSFORM, FWD_FORCE_GENERIC, FWD_NO_SMALL, FWD_FORCE_CHAIN, FWD_FORCE_JIT = 1, 2, 4, 8, 16, 32
 COMM_ID_BYTES = 128
 
 
@@ -80,6 +80,8 @@ SIGNATURES = {
     "v21_mlp_set_input_transform": (C.c_int, [_P, C.POINTER(AffineIn)]),
     "v21_mlp_set_output_transform": (C.c_int, [_P, C.POINTER(AffineOut)]),
     "v21_mlp_has_fused": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    "v21_mlp_jit": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "v21_jit_prebuild": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_char_p]),
     "v21_mlp_forward": (C.c_int, [_P, _P, C.c_int, C.c_int64, _F, C.c_int, C.c_int]),
     "v21_mlp_forward_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int, C.c_int]),
     "v21_trainer_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
@@ -404,6 +406,13 @@ class Stack:
         check(self.lib.v21_mlp_has_fused(self.h, precision_id(precision), C.byref(y)))
         return bool(y.value)
 
+    def jit(self, precision="f32", wait_ms=-1):
+        """Ask for the fused kernel of THIS stack (run-time instantiation, include/v21.h: v21_mlp_jit) and wait up to
+        `wait_ms` (< 0: until compiled).  -> "ready" / "compiling"; raises EngineError when the stack cannot have one."""
+        s = C.c_int(0)
+        check(self.lib.v21_mlp_jit(self.h, precision_id(precision), int(wait_ms), C.byref(s)))
+        return "ready" if s.value == 1 else "compiling"
+
     def forward(self, x, precision="f32", flags=0):
         """host (n, in) float32/float64 -> host (n, out) float32"""
         x = np.asarray(x)
@@ -425,6 +434,15 @@ class Stack:
 
     def forward_dev(self, d_x, ldx, n, d_y, ldy, precision="f32", flags=0):
         check(self.lib.v21_mlp_forward_dev(self.h, _P(d_x), ldx, n, _P(d_y), ldy, precision_id(precision), flags))
+
+
+def jit_prebuild(dims, act, precision, directory=None):
+    """Compile the fused kernel of (dims, act, precision) into `directory` (None: kernel_cache/ next to libv21.so).
+    Needs hiprtc but no GPU."""
+    lib = load_library()
+    L = len(act)
+    check(lib.v21_jit_prebuild(L, (C.c_int * (L + 1))(*[int(d) for d in dims]), (C.c_int * L)(*[int(a) for a in act]),
+                               precision_id(precision), directory.encode() if directory else None))
 
 
 class Trainer:

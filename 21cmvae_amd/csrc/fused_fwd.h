@@ -22,12 +22,14 @@
 // Everything (layer, tile, k-step, fragment and ring-slot indices, wait counts) is a
 // compile-time constant: the kernel is straight-line code per architecture.
 #pragma once
+#ifndef __HIPCC_RTC__  // (hiprtc brings its own runtime header: csrc/jit.hip compiles this file at run time)
 #include <hip/hip_runtime.h>
+#endif
 
 #include <type_traits>
 #include <utility>
 
-#include "../../include/v21.h"
+#include "../../include/v21_types.h"
 #include "par_transform.h"
 
 namespace v21 {
@@ -227,6 +229,12 @@ template <class Arch, class P> struct Geo {
   static constexpr int spread_limit(int G) {
     const Item t = tile_at(G), n = tile_at(G + 1);
     if (n.l < 0) return 0;
+    // Output layer: a tile's epilogue reads its bias / mean from auxb[tile parity], and the aux fragment of tile G + 2
+    // (same parity) lands there when the LOAD side reaches it, DEPTH items ahead of the compute side, i.e. during
+    // k-step ks - DEPTH of tile G + 1: the chunks must be done by then.  (Found by the run-time instantiations of r4:
+    // the compiled-in stacks have 14-28 k-steps per output tile and finish their 8 chunks long before; an output layer
+    // fed by 128 features has 8 k-steps in f16, and its rows 24-31 -- chunks 6 and 7 -- left with the NEXT tile's bias.)
+    if (n.l == t.l && t.l == L - 1) return ks_of(n.l) > P::DEPTH ? ks_of(n.l) - P::DEPTH : 0;
     if (n.l == t.l) return ks_of(n.l);
     const int first_use = IPT * (nt_of(t.l) - 1);
     return first_use < ks_of(n.l) ? first_use : ks_of(n.l);
@@ -373,6 +381,8 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
   constexpr int NOUT = G::dim(L);
   constexpr int NCH = CT * 8;  // epilogue chunks per tile
   static_assert(G::act(L - 1) == 0, "output layer must be linear");
+  // (see Geo::spread_limit: with fewer k-steps than this the next-but-one tile's aux fragment overtakes the epilogue)
+  static_assert(G::nt_of(L - 1) == 1 || G::ks_of(L - 1) > P::DEPTH, "output layer: too few k-steps per tile for the aux double buffer");
   static_assert(D <= kBlkFrags, "read-ahead must stay within one block");
 
   const int lane = threadIdx.x & 63;

@@ -1,9 +1,11 @@
 // par_transform.h -- the reference's preprocess.par_transform for one value, as the prologue of every forward kernel
 // computes it (fused_fwd.h, train_chain.h, train_chain32.h, train_kernels.h:affine_in_kernel).
 #pragma once
+#ifndef __HIPCC_RTC__  // (hiprtc brings its own runtime header: csrc/jit.hip compiles this file at run time)
 #include <hip/hip_runtime.h>
+#endif
 
-#include "../../include/v21.h"
+#include "../../include/v21_types.h"
 
 namespace v21 {
 // preprocess.par_transform of ONE value (include/v21.h: v21_affine_in).  The map is float64 as in the reference

@@ -20,6 +20,7 @@
 #include "../../include/v21.h"
 #include "archs.h"
 #include "fused_fwd.h"
+#include "jit.h"
 #include "gemm.h"
 #include "gemm_nt.h"
 #include "train_kernels.h"
@@ -296,6 +297,10 @@ struct v21_mlp {
   std::vector<long long> cfw_off[2], cbw_off[2];  // element offsets per layer; [0]: 16-bit streams, [1]: fp32 (train_chain32.h)
   long long cfw_bytes[2] = {0, 0}, cbw_bytes[2] = {0, 0};
   v21_affine_in* d_tin = nullptr;           // device copy of the input transform
+  // fused_fwd<this stack, precision> instantiated at run time (jit.h) for stacks outside archs.h; requested on the
+  // first large forward call, used once its code object is there
+  v21::JitKernel* jit[3] = {nullptr, nullptr, nullptr};
+  bool jit_asked[3] = {false, false, false};
   // width of layer l's Dense output: dims[l+1], or 2*dims[l+1] = [z_mean | z_log_var] for V21_ACT_GAUSS
   int nw(int l) const { return act[l] == V21_ACT_GAUSS ? 2 * dims[l + 1] : dims[l + 1]; }
 };
@@ -560,7 +565,7 @@ static int forward_chain(v21_mlp* m, const float* d_x, long long ldx, long long 
 static bool takes_small_path(const v21_mlp* m, long long n, int precision, int flags) {
   const bool fused = m->fused_id >= 0 && !(flags & V21_FWD_FORCE_GENERIC) &&
                      (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8);
-  return n <= V21_SMALL_BATCH_ROWS && !(flags & (V21_FWD_NO_SMALL | V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN)) &&
+  return n <= V21_SMALL_BATCH_ROWS && !(flags & (V21_FWD_NO_SMALL | V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN | V21_FWD_FORCE_JIT)) &&
          (precision == V21_PREC_F32 || !fused) && (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) &&
          m->maxdim <= kNtMaxKPerWg;
 }
@@ -574,14 +579,32 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
   CHK(use(m->ctx));
   if ((flags & V21_FWD_IN_TRANSFORM) && !m->has_tin) return fail(V21_ERR_STATE, "input transform requested but not set");
   if ((flags & V21_FWD_OUT_TRANSFORM) && !m->has_tout) return fail(V21_ERR_STATE, "output transform requested but not set");
-  const bool fused = m->fused_id >= 0 && !(flags & (V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN)) &&
+  const bool fused = m->fused_id >= 0 && !(flags & (V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN | V21_FWD_FORCE_JIT)) &&
                      (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) && ldy < (1ll << 21);
   // few rows: one latency-oriented launch per layer beats one wave walking the whole stack in f32
   // (and the K-loop GEMM of the generic path in any precision)
   if (takes_small_path(m, n, precision, flags) && ldy < (1ll << 21))
     return forward_small(m, d_x, ldx, n, d_y, ldy, precision, flags);
-  if (!fused && chain_fwd_eligible(m, precision, flags) && n < (1ll << 30)) return forward_chain(m, d_x, ldx, n, d_y, ldy, precision, flags);
-  if (!fused) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
+  // a stack outside archs.h: the same fused kernel, instantiated for it at run time (jit.h).  The first call asks for
+  // it; the calls that arrive before its code object does take the table-driven routes below.
+  v21::JitKernel* jk = nullptr;
+  const bool force_jit = (flags & V21_FWD_FORCE_JIT) != 0;
+  if ((m->fused_id < 0 || force_jit) && !(flags & (V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN)) && ldy < (1ll << 21) &&
+      (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8)) {
+    if (!m->jit_asked[precision]) {
+      m->jit[precision] = v21::jit_request(m->L, m->dims.data(), m->act.data(), precision);
+      m->jit_asked[precision] = true;
+    }
+    if (force_jit && m->jit[precision]) v21::jit_wait(m->jit[precision], -1);  // (diagnostics: this route or an error)
+    if (m->jit[precision] && v21::jit_state(m->jit[precision]) == v21::JIT_READY) jk = m->jit[precision];
+    if (force_jit && !jk) {
+      std::string why = "not eligible, or V21_JIT=0";
+      if (m->jit[precision]) v21::jit_state(m->jit[precision], &why);
+      return fail(V21_ERR_UNSUPPORTED, "V21_FWD_FORCE_JIT: no run-time kernel for this stack: %s", why.c_str());
+    }
+  }
+  if (!fused && !jk && chain_fwd_eligible(m, precision, flags) && n < (1ll << 30)) return forward_chain(m, d_x, ldx, n, d_y, ldy, precision, flags);
+  if (!fused && !jk) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
   CHK(ensure_stream(m, precision));
   FusedArgs a{};
   a.x = d_x; a.ldx = ldx; a.y = d_y; a.ldy = ldy; a.n_rows = n;
@@ -594,7 +617,51 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
 #ifdef V21_FUSED_STAMP  // diagnostic build only: where the cycle stamps go
   a.dbg = (unsigned long long*)(getenv("V21_FUSED_DBG_PTR") ? strtoull(getenv("V21_FUSED_DBG_PTR"), nullptr, 0) : 0ull);
 #endif
+  if (jk) {
+    const hipError_t e = v21::jit_launch(jk, m->ctx->device, a, m->ctx->stream);
+    if (e == hipSuccess) return V21_OK;
+    (void)hipGetLastError();
+    if (force_jit) {
+      std::string why;
+      v21::jit_state(jk, &why);
+      return fail(V21_ERR_UNSUPPORTED, "V21_FWD_FORCE_JIT: %s (%s)", why.c_str(), hipGetErrorString(e));
+    }
+    // the code object could not be loaded or needs scratch memory (jit_launch marked it failed): this call and every
+    // later one take the table-driven route
+    if (chain_fwd_eligible(m, precision, flags) && n < (1ll << 30)) return forward_chain(m, d_x, ldx, n, d_y, ldy, precision, flags);
+    return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
+  }
   HIPCHK(g_fused[m->fused_id].fn[precision](a, m->ctx->stream));
+  return V21_OK;
+}
+
+// ---- run-time instantiation of the fused kernel (csrc/jit.h) through the C ABI
+extern "C" int v21_mlp_jit(v21_mlp* m, int precision, int wait_ms, int* status) {
+  if (!m || !status) return fail(V21_ERR_ARG, "null argument");
+  if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
+  *status = -1;
+  if (m->fused_id >= 0) { *status = 1; return V21_OK; }  // compiled into the library (archs.h)
+  std::string why;
+  if (!v21::jit_eligible(m->L, m->dims.data(), m->act.data(), &why)) return fail(V21_ERR_UNSUPPORTED, "no fused kernel for this stack: %s", why.c_str());
+  if (!m->jit_asked[precision]) {
+    m->jit[precision] = v21::jit_request(m->L, m->dims.data(), m->act.data(), precision);
+    m->jit_asked[precision] = true;
+  }
+  v21::JitKernel* k = m->jit[precision];
+  if (!k) return fail(V21_ERR_UNSUPPORTED, "run-time compilation is switched off (V21_JIT=0) and no cached kernel exists");
+  int s = v21::jit_state(k);
+  if (s == v21::JIT_COMPILING && wait_ms != 0) s = v21::jit_wait(k, wait_ms);
+  *status = s;
+  if (s == v21::JIT_FAILED) {
+    v21::jit_state(k, &why);
+    return fail(V21_ERR_UNSUPPORTED, "fused kernel of this stack: %s", why.c_str());
+  }
+  return V21_OK;
+}
+extern "C" int v21_jit_prebuild(int n_layers, const int* dims, const int* act, int precision, const char* dir) {
+  if (!dims || !act) return fail(V21_ERR_ARG, "null argument");
+  std::string why;
+  if (v21::jit_prebuild(n_layers, dims, act, precision, dir, &why) != 0) return fail(V21_ERR_UNSUPPORTED, "%s", why.c_str());
   return V21_OK;
 }
 
@@ -702,10 +769,14 @@ extern "C" int v21_mlp_forward(v21_mlp* m, const void* x, int x_dtype, int64_t n
       HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
       for (hipEvent_t& e : c->slice_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    // equal slices of whole 256-row workgroup rounds; every slice takes the route the whole call would take (a short
+    // last slice must not fall onto the few-row path: another summation order within one result)
+    const long long nsl = (rows + kSliceRows - 1) / kSliceRows;
+    const long long per = ((rows + nsl - 1) / nsl + 255) / 256 * 256;
     int k = 0;
-    for (long long s0 = 0; s0 < rows; s0 += kSliceRows, ++k) {
-      const long long srows = std::min(kSliceRows, rows - s0);
-      CHK(v21_mlp_forward_dev(m, m->d_xs + s0 * din, din, srows, m->d_ys + s0 * dout, dout, precision, fl));
+    for (long long s0 = 0; s0 < rows; s0 += per, ++k) {
+      const long long srows = std::min(per, rows - s0);
+      CHK(v21_mlp_forward_dev(m, m->d_xs + s0 * din, din, srows, m->d_ys + s0 * dout, dout, precision, fl | V21_FWD_NO_SMALL));
       // (an event is reused every other slice: the copy that waited on its previous record was enqueued before this one)
       HIPCHK(hipEventRecord(c->slice_done[k & 1], st));
       HIPCHK(hipStreamWaitEvent(c->copy_stream, c->slice_done[k & 1], 0));

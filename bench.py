@@ -771,12 +771,34 @@ def main():
             td["f32"]["slowdown_vs_fused"] = modes.get("f32", {}).get("signals_per_s", 0.0) / td["f32"]["signals_per_s"]
             td["f16"]["slowdown_vs_fused"] = (out["value"] if args.precision == "f16" else modes.get("f16", {}).get("signals_per_s", 0.0)) / td["f16"]["signals_per_s"]
             out["predict_table_driven_S1"] = td
+            # r4: the fused kernel instantiated for a stack at RUN TIME (csrc/jit.h, hiprtc) -- what every stack outside
+            # csrc/archs.h gets once its code object is there.  `predict_jit_S1`: the headline stack forced down that
+            # route (V21_FWD_FORCE_JIT) against its compiled-in kernel: the same template, so ~1.0x by construction.
+            pj = {}
+            for prec in ("f16", "f32"):
+                try:
+                    pj[prec] = fwd_rate(stack, DIMS, prec, flags | native.FWD_FORCE_JIT)
+                    pj[prec]["slowdown_vs_fused"] = (out["value"] if prec == args.precision else modes.get(prec, {}).get("signals_per_s", 0.0)) / pj[prec]["signals_per_s"]
+                except Exception as e:
+                    pj[prec] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["predict_jit_S1"] = pj
             cdims = [7, 64, 128, 451]
             cst = native.Stack(ctx, cdims, [1, 1, 0])
             cst.set_weights(glorot(cdims, seed=5))
             cst.set_input_transform(ps.log_mask, ps.zero_floor, ps.lo, ps.hi)
             cst.set_output_transform(ss.std, ss.mean)
-            out["predict_custom"] = {prec: fwd_rate(cst, cdims, prec, flags) for prec in ("f16", "f32")}
+            pc = {}
+            for prec in ("f16", "f32"):
+                t0 = time.perf_counter()
+                try:
+                    state = cst.jit(prec)  # waits for the compilation (a cached code object: milliseconds)
+                except Exception as e:
+                    state = "unavailable (%s)" % e
+                wait_s = time.perf_counter() - t0
+                pc[prec] = fwd_rate(cst, cdims, prec, flags)
+                pc[prec]["route"] = "fused kernel instantiated at run time: %s after %.2f s" % (state, wait_s)
+                pc[prec + "_table_driven"] = fwd_rate(cst, cdims, prec, flags | native.FWD_FORCE_CHAIN)
+            out["predict_custom"] = pc
             out["predict_custom"]["model"] = "7->[64,128]->451 (notebooks/sample_notebook.ipynb), %d rows, device-resident" % B
         except Exception as e:
             out["predict_generic_S1"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -66,13 +66,7 @@ enum { V21_DTYPE_F32 = 0, V21_DTYPE_F64 = 1 };
  *   float32 rows (V21_DTYPE_F32, and every device-resident input): floor = (float)zero_floor_j, log10 rounded to
  *     float32 (the correctly rounded log10f), then the float64 map -- numpy's float32 branch up to log10f's last bit.
  * n <= 8. */
-typedef struct {
-  int32_t n;
-  int32_t log_mask[8];
-  double zero_floor[8];
-  double lo[8];
-  double span[8];
-} v21_affine_in;
+#include "v21_types.h" /* v21_affine_in */
 
 /* Fused epilogue = preprocess.unpreproc (preprocess.py:27-46): y*std + mean_j. */
 typedef struct {
@@ -142,6 +136,21 @@ int v21_mlp_forward(v21_mlp* mlp, const void* x, int x_dtype, int64_t n, float* 
  * in floats (>= in_dim / out_dim). */
 int v21_mlp_forward_dev(v21_mlp* mlp, const float* d_x, int64_t ldx, int64_t n,
                         float* d_y, int64_t ldy, int precision, int flags);
+/* The fully fused register-resident kernel (csrc/fused_fwd.h) is straight-line code per (stack, precision): the stacks of
+ * csrc/archs.h are compiled into the library, every other `_gen_model` output (emulator.py:12-48: any `hidden_dims`)
+ * gets it instantiated AT RUN TIME by hiprtc (csrc/jit.h), in a background thread started by the first
+ * v21_mlp_forward[_dev] call above V21_SMALL_BATCH_ROWS rows; calls that arrive earlier take the table-driven one-launch
+ * kernel (same results to operand rounding).  Code objects are cached under $V21_KERNEL_CACHE (default
+ * ~/.cache/21cmvae_amd/kernels) and looked up in `kernel_cache/` next to libv21.so first; V21_JIT=0 switches the
+ * compilation off (cached kernels are still used).
+ * v21_mlp_jit: ask for the kernel now and wait up to wait_ms milliseconds (< 0: until the compilation has ended, 0: do
+ *   not wait); *status = 1 ready (also for the compiled-in stacks), 0 compiling; V21_ERR_UNSUPPORTED (status -1) when
+ *   the stack cannot have one (non-linear output layer, variational head, too wide for the register budget, no
+ *   libhiprtc) -- v21_last_error says which.
+ * v21_jit_prebuild: compile (stack, precision) into `dir` (NULL: kernel_cache/ next to the library) without touching a
+ *   GPU -- a build step for deployments that know their stacks. */
+int v21_mlp_jit(v21_mlp* mlp, int precision, int wait_ms, int* status);
+int v21_jit_prebuild(int n_layers, const int* dims, const int* act, int precision, const char* dir);
 #define V21_FWD_IN_TRANSFORM 1
 #define V21_FWD_OUT_TRANSFORM 2
 #define V21_FWD_FORCE_GENERIC 4
@@ -149,6 +158,9 @@ int v21_mlp_forward_dev(v21_mlp* mlp, const float* d_x, int64_t ldx, int64_t n,
 /* diagnostics / benchmarks: the table-driven one-launch forward (csrc/train_chain.h, FORWARD mode: any stack up to 512
  * wide, f16 / bf16) even where a compiled fused kernel exists -- what every other stack gets by default */
 #define V21_FWD_FORCE_CHAIN 16
+/* diagnostics / benchmarks: the run-time-instantiated fused kernel (v21_mlp_jit) even for a stack that has a
+ * compiled-in one; waits for the compilation, V21_ERR_UNSUPPORTED if the stack cannot have one */
+#define V21_FWD_FORCE_JIT 32
 #define V21_SMALL_BATCH_ROWS 4096
 
 /* ---- trainer: replaces Model.compile + Model.fit (emulator.py:369-378, :739-747,
