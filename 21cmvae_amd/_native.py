@@ -100,6 +100,8 @@ SIGNATURES = {
     "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
     "v21_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
     "v21_debug_check_chain_jobs": (C.c_int, [_P, C.c_longlong, C.c_longlong]),
+    "v21_debug_clock_probe_start": (C.c_int, [_P, C.c_double, C.c_double]),
+    "v21_debug_clock_probe_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
     "v21_trainer_enable_stamps": (C.c_int, [_P, C.c_int]),
     "v21_trainer_chain_stamps": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
@@ -200,6 +202,16 @@ class Context:
     def poison_lds(self, pattern=0xFFFFFFFF):
         """Diagnostics: fill every CU's LDS with ``pattern`` (NaN by default) before the next launch."""
         check(self.lib.v21_debug_poison_lds(self.h, pattern))
+
+    def clock_probe_start(self, duration_ms, period_us=50.0):
+        """Diagnostics: sample the shader clock for `duration_ms` beside the kernels launched meanwhile (include/v21.h)."""
+        check(self.lib.v21_debug_clock_probe_start(self.h, float(duration_ms), float(period_us)))
+
+    def clock_probe_read(self):
+        """-> {"ghz_mean", "ghz_min", "ghz_max", "samples"} of the probe started last (waits for it)."""
+        a, b, c_, n = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
+        check(self.lib.v21_debug_clock_probe_read(self.h, C.byref(a), C.byref(b), C.byref(c_), C.byref(n)))
+        return {"ghz_mean": a.value, "ghz_min": b.value, "ghz_max": c_.value, "samples": n.value}
 
     def memset(self, dptr, byte, nbytes):
         check(self.lib.v21_memset(self.h, _P(dptr), int(byte), int(nbytes)))

@@ -81,11 +81,21 @@ bool load_rtc(std::string* why) {
   return true;
 }
 
-const char* prec_type(int prec) { return prec == 0 ? "PrecF32" : (prec == 1 ? "PrecF16x2sp" : "PrecBF16x2sp"); }
+// V21_JIT_WIDE=1 (diagnostics; read when a kernel is first requested): the 16-bit kernels in their ONE-workgroup-per-CU
+// form -- one wave per SIMD with TWO column tiles (64 signals), every weight fragment read from LDS feeds two MFMAs,
+// up to 512 registers -- instead of "x2sp" (two workgroups per CU, one column tile per wave, 256 registers).  Half the
+// LDS bytes per MFMA; r1 measured it slower (62-65 against 52 us on the headline stack) and r4 measured it again
+// through this switch.
+bool jit_wide() { const char* e = getenv("V21_JIT_WIDE"); return e && e[0] == '1'; }
+const char* prec_type(int prec, bool wide) {
+  return prec == 0 ? "PrecF32" : (prec == 1 ? (wide ? "PrecF16" : "PrecF16x2sp") : (wide ? "PrecBF16" : "PrecBF16x2sp"));
+}
 struct Launch { int rows_per_wg, threads, lds; };
 template <class P> constexpr Launch launch_of() { return Launch{P::WAVES * P::CT * 32, 64 * P::WAVES, fused_lds_alloc<P>()}; }
-Launch launch_geometry(int prec) {
-  return prec == 0 ? launch_of<PrecF32>() : (prec == 1 ? launch_of<PrecF16x2sp>() : launch_of<PrecBF16x2sp>());
+Launch launch_geometry(int prec, bool wide) {
+  if (prec == 0) return launch_of<PrecF32>();
+  if (prec == 1) return wide ? launch_of<PrecF16>() : launch_of<PrecF16x2sp>();
+  return wide ? launch_of<PrecBF16>() : launch_of<PrecBF16x2sp>();
 }
 
 unsigned long long fnv1a(const void* p, size_t n, unsigned long long h = 1469598103934665603ull) {
@@ -159,6 +169,7 @@ bool write_cache(const std::string& dir, const std::string& path, const std::str
 
 struct JitKernel {
   int L = 0, prec = 0;
+  bool wide = false;  // V21_JIT_WIDE at request time
   int dims[17] = {}, act[16] = {};
   std::string spec, file;  // "7x64x128x451_a110_PrecF16x2sp", "<spec>_<hash>.v21k"
   std::atomic<int> state{JIT_COMPILING};
@@ -188,13 +199,13 @@ struct Registry {
 };
 Registry g_reg;
 
-std::string make_spec(int L, const int* dims, const int* act, int prec) {
+std::string make_spec(int L, const int* dims, const int* act, int prec, bool wide) {
   std::string s;
   for (int l = 0; l <= L; ++l) s += (l ? "x" : "") + std::to_string(dims[l]);
   s += "_a";
   for (int l = 0; l < L; ++l) s += act[l] ? "1" : "0";
   s += "_";
-  s += prec_type(prec);
+  s += prec_type(prec, wide);
   return s;
 }
 std::string make_source(const JitKernel& k) {
@@ -219,7 +230,7 @@ std::string file_name(const JitKernel& k) {
 int compile(const JitKernel& k, std::string& sym, std::vector<char>& code, std::string& why) {
   if (!load_rtc(&why)) return -1;
   const std::string src = make_source(k);
-  const std::string expr = std::string("v21::fused_fwd<v21::ArchRT, v21::") + prec_type(k.prec) + ">";
+  const std::string expr = std::string("v21::fused_fwd<v21::ArchRT, v21::") + prec_type(k.prec, k.wide) + ">";
   rtc_prog prog = nullptr;
   int r = g_rtc.CreateProgram(&prog, src.c_str(), "v21_fused_rt.hip", 0, nullptr, nullptr);
   if (r != 0) { why = "hiprtcCreateProgram failed"; return -1; }
@@ -259,10 +270,10 @@ void finish(JitKernel* k, int state, const std::string& why) {
   k->cv.notify_all();
 }
 void fill(JitKernel* k, int L, const int* dims, const int* act, int prec) {
-  k->L = L; k->prec = prec;
+  k->L = L; k->prec = prec; k->wide = jit_wide();
   for (int l = 0; l <= L; ++l) k->dims[l] = dims[l];
   for (int l = 0; l < L; ++l) k->act[l] = act[l];
-  k->spec = make_spec(L, dims, act, prec);
+  k->spec = make_spec(L, dims, act, prec, k->wide);
   k->file = file_name(*k);
 }
 }  // namespace
@@ -283,7 +294,7 @@ bool jit_eligible(int L, const int* dims, const int* act, std::string* why) {
 
 JitKernel* jit_request(int L, const int* dims, const int* act, int prec) {
   if (prec < 0 || prec > 2 || !jit_eligible(L, dims, act, nullptr)) return nullptr;
-  const std::string spec = make_spec(L, dims, act, prec);
+  const std::string spec = make_spec(L, dims, act, prec, jit_wide());
   std::lock_guard<std::mutex> lk(g_reg.mu);
   auto it = g_reg.all.find(spec);
   if (it != g_reg.all.end()) return it->second;
@@ -363,7 +374,7 @@ hipError_t jit_launch(JitKernel* k, int device, const FusedArgs& a, hipStream_t 
   const int s = k->state.load(std::memory_order_acquire);
   if (s == JIT_COMPILING) return hipErrorNotReady;
   if (s != JIT_READY) return hipErrorInvalidValue;
-  const Launch g = launch_geometry(k->prec);
+  const Launch g = launch_geometry(k->prec, k->wide);
   JitKernel::Loaded ld;
   {
     std::lock_guard<std::mutex> lk(k->mu);

@@ -420,6 +420,33 @@ __global__ void copy_pad_kernel(float* __restrict__ dst, long long ldd, const fl
   dst[i] = j < d ? src[row * lds_ + j] : 0.f;
 }
 
+// diagnostics: the shader clock UNDER LOAD.  One wave samples (s_memtime, s_memrealtime) pairs -- the shader-clock cycle
+// counter and the constant 100 MHz reference counter -- every `period` reference ticks for `duration` reference ticks
+// (or until `max_samples` pairs are written: both bounds are reached whatever else happens), while the kernels under
+// test run beside it (it needs one wave slot and a handful of registers).  d(memtime) / d(memrealtime) x 100 MHz is the
+// clock those kernels ran at (bench.py: roofline.clock_ghz).
+__global__ void clock_probe_kernel(unsigned long long* out, int max_samples, unsigned long long period, unsigned long long duration) {
+  if (threadIdx.x != 0) return;
+  unsigned long long t0, r0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+  out[0] = t0; out[1] = r0;
+  int n = 1;
+  unsigned long long next = r0 + period;
+  while (n < max_samples) {
+    unsigned long long t, r;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r)::"memory");
+    if (r >= next) {
+      out[2 * n] = t; out[2 * n + 1] = r;
+      ++n;
+      next += period;
+      if (r - r0 >= duration) break;
+    } else {
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  out[2 * max_samples] = (unsigned long long)n;
+}
+
 // per-layer-path prologue (the fused and the chain kernels do this while they gather their rows); SRC = float: rows in
 // device memory / float32 host rows; SRC = double: float64 host rows staged as they are (v21_mlp_forward)
 template <class SRC>

@@ -149,6 +149,10 @@ struct v21_ctx {
   // is being computed (created on first use)
   hipStream_t copy_stream = nullptr;
   hipEvent_t slice_done[2] = {nullptr, nullptr};
+  // v21_debug_clock_probe_*: the sampling wave runs on its own stream beside the kernels under test
+  hipStream_t probe_stream = nullptr;
+  unsigned long long* d_probe = nullptr;
+  int probe_cap = 0;
 };
 // ncclDataType_t / ncclRedOp_t values of rccl.h (the library is dlopen'ed, its header is not included)
 constexpr int kNcclFloat32 = 7, kNcclSum = 0;
@@ -180,6 +184,8 @@ extern "C" int v21_ctx_destroy(v21_ctx* c) {
   if (c->own) { hipStreamSynchronize(c->own); hipStreamDestroy(c->own); }
   if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
   for (hipEvent_t e : c->slice_done) if (e) hipEventDestroy(e);
+  if (c->probe_stream) { hipStreamSynchronize(c->probe_stream); hipStreamDestroy(c->probe_stream); }
+  if (c->d_probe) hipFree(c->d_probe);
   delete c;
   return V21_OK;
 }
@@ -3309,6 +3315,46 @@ extern "C" int v21_debug_poison_lds(v21_ctx* c, uint32_t pattern) {
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipFree(sink));
   if (bad) return fail(V21_ERR_HIP, "LDS read-back mismatch in %u threads", bad);
+  return V21_OK;
+}
+
+// diagnostics: the shader clock while other kernels run (train_kernels.h: clock_probe_kernel).  start: one sampling wave
+// on a private stream for `duration_ms`, a sample every `period_us`; read: waits for it and reduces the samples.
+extern "C" int v21_debug_clock_probe_start(v21_ctx* c, double duration_ms, double period_us) {
+  CHK(use(c));
+  if (!(duration_ms > 0.0) || duration_ms > 2000.0 || !(period_us >= 1.0)) return fail(V21_ERR_ARG, "clock probe: duration in (0, 2000] ms, period >= 1 us");
+  if (!c->probe_stream) HIPCHK(hipStreamCreateWithFlags(&c->probe_stream, hipStreamNonBlocking));
+  const int nmax = (int)std::min(65536.0, duration_ms * 1000.0 / period_us + 2.0);
+  if (c->probe_cap < nmax) {
+    if (c->d_probe) HIPCHK(hipFree(c->d_probe));
+    HIPCHK(hipMalloc((void**)&c->d_probe, ((size_t)2 * nmax + 1) * sizeof(unsigned long long)));
+    c->probe_cap = nmax;
+  }
+  HIPCHK(hipMemsetAsync(c->d_probe, 0, ((size_t)2 * c->probe_cap + 1) * sizeof(unsigned long long), c->probe_stream));
+  // (s_memrealtime: 100 MHz -> 100 ticks per microsecond)
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->probe_stream, c->d_probe, c->probe_cap,
+                     (unsigned long long)(period_us * 100.0), (unsigned long long)(duration_ms * 100000.0));
+  HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+extern "C" int v21_debug_clock_probe_read(v21_ctx* c, double* ghz_mean, double* ghz_min, double* ghz_max, int* samples) {
+  CHK(use(c));
+  if (!ghz_mean || !ghz_min || !ghz_max || !samples) return fail(V21_ERR_ARG, "null argument");
+  if (!c->probe_stream || !c->d_probe) return fail(V21_ERR_STATE, "no clock probe was started");
+  std::vector<unsigned long long> h((size_t)2 * c->probe_cap + 1);
+  HIPCHK(hipMemcpyAsync(h.data(), c->d_probe, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->probe_stream));
+  HIPCHK(hipStreamSynchronize(c->probe_stream));
+  const int n = (int)h[(size_t)2 * c->probe_cap];
+  *samples = n;
+  *ghz_mean = *ghz_min = *ghz_max = 0.0;
+  if (n < 2) return fail(V21_ERR_STATE, "the clock probe took %d samples", n);
+  double lo = 1e30, hi = 0.0;
+  for (int i = 1; i < n; ++i) {
+    const double g = (double)(h[2 * i] - h[2 * i - 2]) / (double)(h[2 * i + 1] - h[2 * i - 1]) * 0.1;  // cycles per 10 ns
+    lo = std::min(lo, g); hi = std::max(hi, g);
+  }
+  *ghz_mean = (double)(h[2 * (n - 1)] - h[0]) / (double)(h[2 * (n - 1) + 1] - h[1]) * 0.1;
+  *ghz_min = lo; *ghz_max = hi;
   return V21_OK;
 }
 

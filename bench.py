@@ -660,6 +660,19 @@ def main():
             ctx.record(evs[i + 1])
         ctx.sync()
         timed.per_launch_ms = [ctx.elapsed_ms(evs[i], evs[i + 1]) for i in range(steps)]
+        # the shader clock these launches run at: a THIRD untimed run of the same K launches with one
+        # sampling wave beside them (v21_debug_clock_probe_*: s_memtime against the 100 MHz s_memrealtime), started once
+        # the launches are enqueued and sampling for the middle 60 % of the run
+        timed.clock = None
+        try:
+            run_ms = max(0.4, steps * ev_ms / max(steps, 1))
+            for _ in range(steps):
+                stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
+            ctx.clock_probe_start(0.6 * run_ms, period_us=max(20.0, 0.6 * run_ms * 1000.0 / 200.0))
+            ctx.sync()
+            timed.clock = ctx.clock_probe_read()
+        except Exception as e:  # pragma: no cover
+            timed.clock = {"error": "%s: %s" % (type(e).__name__, e)}
         if dist is not None:
             t = torch.tensor([wall], dtype=torch.float64, device=_pg_device(dist))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -695,6 +708,11 @@ def main():
                      "time_base": "HIP events on the launch stream around the K timed launches (mean); min / median from "
                                   "per-launch event pairs of a second run; profiles/%s/kernel_stats_bench_f16.csv " % PROFILE_TAG +
                                   "(rocprofv3 --kernel-trace --stats of this command) must agree with the mean",
+                     "clock_ghz": (timed.clock or {}).get("ghz_mean"), "clock_probe": timed.clock, "clock_nominal_ghz": 2.4,
+                     "frac_of_clocked_peak": (achieved_tf / (PEAK_TFLOPS[args.precision] * timed.clock["ghz_mean"] / 2.4)
+                                              if timed.clock and timed.clock.get("ghz_mean") else None),
+                     "clock_note": "shader clock during an untimed repeat of the K launches (one sampling wave beside them); "
+                                   "peak figures assume 2.4 GHz, frac_of_clocked_peak rescales the peak to the measured clock",
                      "algorithmic_flop_per_launch": FLOP_PER_SIGNAL * B,
                      "hbm_GBps_algorithmic": BYTES_PER_SIGNAL * B / kern_s / 1e9,
                      "hbm_frac_of_8TBps": BYTES_PER_SIGNAL * B / kern_s / 1e9 / PEAK_HBM_GBS},

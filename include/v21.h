@@ -231,6 +231,12 @@ int v21_trainer_use_graph(v21_trainer* tr, int enable);
  * when that is done.  The poison tests launch it immediately before each kernel that keeps activations in LDS, so
  * that a column or mask tile read before it is written meets NaN instead of a fresh process's zeros. */
 int v21_debug_poison_lds(v21_ctx* ctx, uint32_t pattern);
+/* diagnostics: the shader clock UNDER LOAD.  start: one wave on a private stream samples the shader-clock cycle counter
+ * against the constant 100 MHz reference counter every period_us for duration_ms, beside whatever runs on the context's
+ * stream meanwhile; read: waits for it; mean / min / max of cycles per nanosecond over the sampling intervals.
+ * bench.py reports it as roofline.clock_ghz (DVFS holds ~1.6-1.9 GHz under the fused kernel, 2.4 GHz is nominal). */
+int v21_debug_clock_probe_start(v21_ctx* ctx, double duration_ms, double period_us);
+int v21_debug_clock_probe_read(v21_ctx* ctx, double* ghz_mean, double* ghz_min, double* ghz_max, int* samples);
 /* diagnostics: the small-batch f32 chain kernel (csrc/train_chain32s.h) follows a host-built job table into the packed
  * weight streams without range checks; v21_trainer_create validates every address a row names against the allocated
  * streams (V21_ERR_STATE instead of a GPU memory fault).  This repeats that check against stream sizes the caller names
