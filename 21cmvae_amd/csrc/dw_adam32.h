@@ -210,12 +210,12 @@ __device__ __forceinline__ void dwadam32_body(const NtGroupBig& grp, const NtAda
 #endif
   D32FINE(5);
 }
-__global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, const NtAdamInfo ad) { dwadam32_body(grp, ad, (int)blockIdx.x, -1, 0.f, -1); }
+static __global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, const NtAdamInfo ad) { dwadam32_body(grp, ad, (int)blockIdx.x, -1, 0.f, -1); }
 // a sweep of f32 models: blockIdx.y = model (its problem and Adam blocks in device memory), blockIdx.x = tile of the model.
 // (One model per XCD -- workgroup b = tile b / models of model b % models, as train_chain32s_group_kernel deals its row
 // blocks -- was slower: 59.8 against 53.3 us for 8 autoencoders of 128 .. 512 hidden units; the XCD with the largest
 // model's tiles ends last.)
-__global__ void __launch_bounds__(256) dwadam32_group_kernel(const Dw32Model* __restrict__ tab, const Dw32Step st) {
+static __global__ void __launch_bounds__(256) dwadam32_group_kernel(const Dw32Model* __restrict__ tab, const Dw32Step st) {
   const Dw32Model& md = tab[blockIdx.y];
   if ((int)blockIdx.x >= md.grp.first[md.grp.count]) return;
   dwadam32_body(md.grp, md.ad, (int)blockIdx.x, st.rows, st.alpha[blockIdx.y], st.slot);

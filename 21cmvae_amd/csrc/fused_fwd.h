@@ -12,7 +12,7 @@
 //     consecutive output bins and rows are stored as 128-byte segments.
 //   * activations never touch LDS or HBM; the only streamed operand is the weight
 //     set, pre-packed on the host into 1-KiB MFMA fragments in consumption order
-//     ("the stream", pack_stream() in v21_api.hip).  The 4 waves of a workgroup share
+//     ("the stream", ensure_stream() in api_forward.hip).  The 4 waves of a workgroup share
 //     it through a 4-slot LDS ring filled by LDS-DMA (global_load_lds_dwordx4) two
 //     blocks ahead, with one counted vmcnt + s_barrier per 24-fragment block.
 //   * bias enters as the accumulator's initial value (hidden layers) or in the

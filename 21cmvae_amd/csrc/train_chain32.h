@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(64 * kC32Waves) train_chain32_kernel(const Cha
 }
 // once per step on a data-parallel rank (the loss numerator must ride in the gradient arena BEFORE the exchange);
 // a single rank lets the Adam kernel do it
-__global__ void chain32_loss_kernel(unsigned long long* acc, float* out) {
+static __global__ void chain32_loss_kernel(unsigned long long* acc, float* out) {
   *out = (float)((double)(long long)*acc * (1.0 / 4294967296.0));
   *acc = 0ull;
 }

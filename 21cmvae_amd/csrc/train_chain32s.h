@@ -168,7 +168,7 @@ inline void c32s_build_jobs(const ChainModel& a, C32sJob* tab) {
 // rolling prefetch requests it under this unit's last chunk whether or not it is ever used).  `fw_words` / `bw_words`:
 // sizes of the two packed streams in 16-byte words (one lane's share of a fragment; a fragment is 64 words, a chunk 256);
 // `arena_floats`: size of the parameter arena (biases).  Returns nullptr or a description of the first bad row (static
-// buffer).  Called by build_chain32s_jobs (v21_api.hip) when a trainer is created and by v21_debug_check_chain_jobs.
+// buffer).  Called by build_chain32s_jobs (api_trainer.hip) when a trainer is created and by v21_debug_check_chain_jobs.
 inline const char* c32s_validate_jobs(const ChainModel& a, const C32sJob* tab, long long fw_words, long long bw_words,
                                       long long arena_floats) {
   static thread_local char msg[256];

@@ -15,7 +15,7 @@ namespace v21 {
 // node of the captured step increments *cur.  desc == nullptr: the values in the kernel arguments.
 struct StepDesc { long long first; float alpha; int slot; };
 struct StepCtx { const StepDesc* desc; const int* cur; };
-__global__ void step_tick_kernel(int* cur) { *cur += 1; }
+static __global__ void step_tick_kernel(int* cur) { *cur += 1; }
 
 // K2: loss_i = w_i sum_j (p - y)^2 (relative_mse_loss, emulator.py:68-81, with
 // w_i = 1/(D amp_i^2); plain MSE w_i = 1/D) and dL/dp = scale * w_i * (p - y),
@@ -46,7 +46,7 @@ __global__ void loss_grad_kernel(const float* __restrict__ p, long long ldp,
 }
 
 // deterministic sum of n floats by ONE workgroup -> out[0] (n <= a few 10^5)
-__global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out, int accumulate,
+static __global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out, int accumulate,
                            float* __restrict__ slots = nullptr, StepCtx sc = StepCtx{nullptr, nullptr}, int slot = -1) {
   __shared__ double part[16];
   double s = 0.0;
@@ -65,7 +65,7 @@ __global__ void sum_kernel(const float* __restrict__ v, int n, float* __restrict
 }
 
 // deterministic split-K reduction: g[i] = slab_0[i] + slab_1[i] + ... (fixed order)
-__global__ void reduce_slabs_kernel(float* __restrict__ g, const float* __restrict__ slabs, int nslab,
+static __global__ void reduce_slabs_kernel(float* __restrict__ g, const float* __restrict__ slabs, int nslab,
                                     long long stride, long long n) {
   const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 + 3 < n) {
@@ -86,7 +86,7 @@ __global__ void reduce_slabs_kernel(float* __restrict__ g, const float* __restri
 
 // ---- kernels of the NT training path (gemm_nt.h) ------------------------------------
 // K5: the Keras data adapter's shuffled batch (emulator.py:369-378 [K]); one wave per batch row: x[idx] -> H0 row and H0^T column, y[idx] -> Y row, w[idx]
-__global__ void gather_batch_kernel(const float* __restrict__ x, int din, float* __restrict__ h0, long long ldh,
+static __global__ void gather_batch_kernel(const float* __restrict__ x, int din, float* __restrict__ h0, long long ldh,
                                     float* __restrict__ h0t, long long ldt, const float* __restrict__ y, int dout,
                                     float* __restrict__ yb, long long ldy, const float* __restrict__ w,
                                     float* __restrict__ wb, const int* __restrict__ idx, long long first, int n,
@@ -110,7 +110,7 @@ __global__ void gather_batch_kernel(const float* __restrict__ x, int din, float*
 }
 
 // K2 (training form): like loss_grad_kernel, also writes the transposed gradient dZ^T (dout x batch)
-__global__ void loss_grad_t_kernel(const float* __restrict__ p, long long ldp, const float* __restrict__ y,
+static __global__ void loss_grad_t_kernel(const float* __restrict__ p, long long ldp, const float* __restrict__ y,
                                    long long ldy, const float* __restrict__ w, float* __restrict__ dz,
                                    long long lddz, float* __restrict__ dzt, long long ldt,
                                    float* __restrict__ rowloss, int n, int d, float scale,
@@ -162,7 +162,7 @@ struct GaussArgs {
   unsigned long long seed, step, row0;
 };
 // one wave per row: z = mu + exp(lv/2) eps;  KL_i = -1/2 sum_d (1 + lv - mu^2 - exp lv)
-__global__ void gauss_sample_kernel(const GaussArgs a) {
+static __global__ void gauss_sample_kernel(const GaussArgs a) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= a.n) return;
@@ -182,7 +182,7 @@ __global__ void gauss_sample_kernel(const GaussArgs a) {
   if (lane == 0) a.klrow[row] = a.beta * kl;
 }
 // d mu = dz + beta mu;  d lv = dz eps exp(lv/2)/2 + beta (exp lv - 1)/2     (beta = kl_weight / B)
-__global__ void gauss_sample_bwd_kernel(const GaussArgs a) {
+static __global__ void gauss_sample_bwd_kernel(const GaussArgs a) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= a.n) return;
@@ -218,7 +218,7 @@ struct LossGroup {
   int n, d;
   float scale;
 };
-__global__ void loss_grad_t_group_kernel(const LossGroup a) {
+static __global__ void loss_grad_t_group_kernel(const LossGroup a) {
   const int k = blockIdx.y;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -242,7 +242,7 @@ __global__ void loss_grad_t_group_kernel(const LossGroup a) {
   if (lane == 0) a.rowloss[k][row] = wi * s;
 }
 struct SumGroup { const float* v[kSweepMax]; float* out[kSweepMax]; float* out2[kSweepMax]; int n; };
-__global__ void sum_group_kernel(const SumGroup a) {  // one workgroup per model, same order as sum_kernel
+static __global__ void sum_group_kernel(const SumGroup a) {  // one workgroup per model, same order as sum_kernel
   __shared__ double part[16];
   const float* v = a.v[blockIdx.x];
   double s = 0.0;
@@ -380,7 +380,7 @@ __device__ __forceinline__ void adam_repack_block(const AdamArgs& a, long long b
   if (l0 == l1) adam_repack_element(a, i, alpha, a.lt[l0]);
   else adam_repack_element(a, i, alpha, a.lt[adam_layer_of(a, i)]);
 }
-__global__ void adam_repack_kernel(const AdamArgs a) {
+static __global__ void adam_repack_kernel(const AdamArgs a) {
   if (a.loss_acc && blockIdx.x == 0 && threadIdx.x == 0) {
     const float f = (float)((double)(long long)*a.loss_acc * (1.0 / 4294967296.0));
     *a.loss_out = f;
@@ -391,14 +391,14 @@ __global__ void adam_repack_kernel(const AdamArgs a) {
 }
 // sweep form: blockIdx.y = model, argument blocks in device memory (one per model)
 struct AlphaGroup { float a[kSweepMax]; };
-__global__ void adam_repack_group_kernel(const AdamArgs* __restrict__ tab, const AlphaGroup alpha) {
+static __global__ void adam_repack_group_kernel(const AdamArgs* __restrict__ tab, const AlphaGroup alpha) {
   const AdamArgs& a = tab[blockIdx.y];
   if ((long long)blockIdx.x * blockDim.x >= a.n) return;
   adam_repack_block(a, (long long)blockIdx.x * blockDim.x, a.n, alpha.a[blockIdx.y]);
 }
 
 // fp32 W^T copies (rows = outputs, pitch p16(K)) of the small-batch forward path: one thread per arena element
-__global__ void wt_pack_kernel(const AdamArgs a) {
+static __global__ void wt_pack_kernel(const AdamArgs a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   int l = 0;
@@ -411,7 +411,7 @@ __global__ void wt_pack_kernel(const AdamArgs a) {
   }
 }
 // rows of x -> zero-padded rows of pitch ldd (the latency GEMM reads whole 16-float groups)
-__global__ void copy_pad_kernel(float* __restrict__ dst, long long ldd, const float* __restrict__ src, long long lds_,
+static __global__ void copy_pad_kernel(float* __restrict__ dst, long long ldd, const float* __restrict__ src, long long lds_,
                                 long long n, int d) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * ldd) return;
@@ -425,7 +425,7 @@ __global__ void copy_pad_kernel(float* __restrict__ dst, long long ldd, const fl
 // (or until `max_samples` pairs are written: both bounds are reached whatever else happens), while the kernels under
 // test run beside it (it needs one wave slot and a handful of registers).  d(memtime) / d(memrealtime) x 100 MHz is the
 // clock those kernels ran at (bench.py: roofline.clock_ghz).
-__global__ void clock_probe_kernel(unsigned long long* out, int max_samples, unsigned long long period, unsigned long long duration) {
+static __global__ void clock_probe_kernel(unsigned long long* out, int max_samples, unsigned long long period, unsigned long long duration) {
   if (threadIdx.x != 0) return;
   unsigned long long t0, r0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
@@ -460,7 +460,7 @@ __global__ void affine_in_kernel(float* __restrict__ dst, long long ldd, const S
   if constexpr (sizeof(SRC) == 8) dst[row * ldd + j] = par_transform_f64(x, t.log_mask[j], t.zero_floor[j], t.lo[j], t.span[j]);
   else dst[row * ldd + j] = par_transform_f32(x, t.log_mask[j], t.zero_floor[j], t.lo[j], t.span[j]);
 }
-__global__ void affine_out_kernel(float* __restrict__ y, long long ldy, long long n, int d,
+static __global__ void affine_out_kernel(float* __restrict__ y, long long ldy, long long n, int d,
                                   float stdv, const float* __restrict__ mean) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * d) return;
@@ -480,7 +480,7 @@ struct PackArgs {
   int is_bf16;
   PackLayer lt[16];
 };
-__global__ void pack_stream_kernel(const PackArgs a) {
+static __global__ void pack_stream_kernel(const PackArgs a) {
   const int F = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (F >= a.padded) return;

@@ -169,7 +169,7 @@ def _sharded_worker(rank, world, port, q):
 
 
 def test_sharded_adam_equals_one_process():
-    """reduce-scatter -> Adam on each rank's slice -> all-gather (v21_api.hip: reduce_and_update, sharded form),
+    """reduce-scatter -> Adam on each rank's slice -> all-gather (api_trainer.hip: reduce_and_update, sharded form),
     restated with the oracle over gloo: the gathered weights and the epoch loss are the single-process result."""
     from oracle import ref_numpy as ora
     world, port = 2, _free_port()
