@@ -186,6 +186,11 @@ struct v21_trainer {
   float* d_partial = nullptr;
   unsigned* d_ticket = nullptr;
   std::vector<void*> d_ht16, d_dzt16;  // fragment-ordered weight-gradient operands (train_chain.h)
+  // large steps of f16 / bf16 trainers whose stack has a compiled fused training kernel (fused_train.h; archs.h: T1 ..):
+  // index into the registry of api_trainer.hip or -1, and that kernel's packed stream (rebuilt before every launch)
+  int train_arch = -1;
+  unsigned char* d_tstream = nullptr;
+  int tstream_total = 0, tstream_padded = 0;
   int* d_dworder = nullptr;            // dw_adam.h: tile order per XCD (two-dimensional blocks per layer)
   int dw_xper = 0;
   long long BS = 0;                    // batch steps of 16 per feature tile

@@ -2,6 +2,20 @@
 // fp32 chains), the exchange of data-parallel ranks, captured steps (hipGraph), the Keras-fit()-shaped epoch driver.
 #include "api_internal.h"
 
+// ---- compiled fused training kernels (fused_train.h, one translation unit each: fused_train_inst.hip)
+namespace v21 {
+#define V21_TDECL(a)                                                          \
+  hipError_t launch_fused_train_##a##_F16t(const ChainArgs&, hipStream_t);   \
+  hipError_t launch_fused_train_##a##_BF16t(const ChainArgs&, hipStream_t);
+V21_TRAIN_ARCH_LIST(V21_TDECL)
+#undef V21_TDECL
+}  // namespace v21
+typedef hipError_t (*train_launcher)(const ChainArgs&, hipStream_t);
+struct TrainEntry { int L; const int* dims; const int* act; train_launcher fn[2]; /* f16, bf16 */ };
+#define V21_TENTRY(a) {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_train_##a##_F16t, launch_fused_train_##a##_BF16t}},
+static const TrainEntry g_train[] = {V21_TRAIN_ARCH_LIST(V21_TENTRY)};
+#undef V21_TENTRY
+
 // ---------------------------------------------------------------------------------
 // trainer (NT path: gemm_nt.h).  Every contraction of a step reads operands whose
 // contraction index is contiguous; the producers write the transposed copies.
@@ -112,6 +126,26 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
         HIPCHK(hipStreamSynchronize(st));
       }
       t->chain = true;
+      // a compiled fused training kernel for this stack (large steps; no variational head)?
+      if (t->gl < 0 && !(getenv("V21_FUSED_TRAIN") && getenv("V21_FUSED_TRAIN")[0] == '0'))
+        for (size_t e = 0; e < sizeof(g_train) / sizeof(g_train[0]); ++e) {
+          bool same = g_train[e].L == L;
+          for (int l = 0; same && l <= L; ++l) same = g_train[e].dims[l] == m->dims[l];
+          for (int l = 0; same && l < L; ++l) same = g_train[e].act[l] == m->act[l];
+          if (same) t->train_arch = (int)e;
+        }
+      if (t->train_arch >= 0) {
+        int total = 0;
+        for (int v = 0; v < 2 * L - 1; ++v) {
+          const int l = v < L ? v : 2 * L - 1 - v;
+          const int K = v < L ? m->dims[l] : m->dims[l + 1], N = v < L ? m->dims[l + 1] : m->dims[l];
+          total += ((N + 31) / 32) * ((K + 15) / 16 + 1);
+        }
+        t->tstream_total = total;
+        t->tstream_padded = (total + 7) / 8 * 8;
+        HIPCHK(hipMalloc((void**)&t->d_tstream, (size_t)t->tstream_padded * 1024 + kChainStreamSlack));
+        HIPCHK(hipMemsetAsync(t->d_tstream, 0, (size_t)t->tstream_padded * 1024 + kChainStreamSlack, st));
+      }
       if (!(getenv("V21_DW_BLOCKS") && getenv("V21_DW_BLOCKS")[0] == '0')) {
         // tile order of dw16_adam_kernel: per layer the R x C tile grid in 8 blocks (rb x cb = 8, the shape with the least
         // operand rows per block), the blocks handed to the XCDs largest first onto the least loaded XCD
@@ -211,6 +245,7 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   if (t->d_slab) hipFree(t->d_slab);
   if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
   if (t->d_dworder) hipFree(t->d_dworder);
+  if (t->d_tstream) hipFree(t->d_tstream);
   if (t->chain32) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_ticket); hipFree(t->d_stamps); if (t->d_jobs) hipFree(t->d_jobs); }
   if (t->chain) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_partial); hipFree(t->d_ticket); hipFree(t->d_stamps);
     for (void* p : t->d_ht16) if (p) hipFree(p);
@@ -605,6 +640,38 @@ int chain_prefetchers(int ncons, int models) {
   if (env) return std::max(0, std::min(atoi(env), idle / 8));
   // (per XCD: none 45.6 us per f16 step at 4,096 rows, 2-4 43.4-43.6, 8 43.8-43.9, 16 44.2; f32 at batch 256: 46.4 / 42.6-42.8 / 42.9 / 43.4)
   return idle >= 8 ? std::min(4, idle / 8) : 0;
+}
+// Large steps (fused_train.h): the packed stream of the virtual stack -- forward layers, then the activation-gradient
+// layers with the transposed weights -- is rebuilt from the arena (the previous step's Adam moved it), then one launch
+// carries 128 rows per workgroup through forward pass, loss and activation gradients.
+static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
+                              const int* d_idx, long long first, int rows, int brows, long long row0) {
+  v21_mlp* m = t->mlp;
+  const int L = m->L;
+  hipStream_t st = t->ctx->stream;
+  PackArgs pa{};
+  pa.w = m->d_w; pa.mean = nullptr; pa.stream = t->d_tstream;
+  pa.L = 2 * L - 1; pa.total = t->tstream_total; pa.padded = t->tstream_padded;
+  pa.fpi = 16; pa.epi = 8; pa.esize = 2; pa.is_bf16 = t->prec == V21_PREC_BF16; pa.all_hidden = 1;
+  int f = 0;
+  for (int v = 0; v < 2 * L - 1; ++v) {
+    const int l = v < L ? v : 2 * L - 1 - v;
+    PackLayer& pl = pa.lt[v];
+    pl.K = v < L ? m->dims[l] : m->dims[l + 1]; pl.N = v < L ? m->dims[l + 1] : m->dims[l];
+    pl.ks = (pl.K + 15) / 16; pl.nt = (pl.N + 31) / 32;
+    pl.w_off = m->w_off[l]; pl.b_off = m->b_off[l];
+    pl.flags = v < L ? 0 : 3;  // activation-gradient layer: transposed weights, no bias
+    pl.first = f;
+    f += pl.nt * (pl.ks + 1);
+  }
+  hipLaunchKernelGGL(pack_stream_kernel, dim3((pa.padded + 3) / 4), dim3(256), 0, st, pa);
+  HIPCHK(hipGetLastError());
+  ChainArgs a{};
+  static_cast<ChainModel&>(a) = chain_model(t);
+  static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, m->dims[L], nullptr, row0);
+  a.fw = t->d_tstream; a.fw_bytes = (long long)t->tstream_padded * 1024;
+  HIPCHK(g_train[t->train_arch].fn[t->prec == V21_PREC_F16 ? 0 : 1](a, st));
+  return V21_OK;
 }
 static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
                         const int* d_idx, long long first, int rows, int brows, long long row0) {
@@ -1008,13 +1075,21 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   if (rows > 0) {
     CHK(ensure_copies(t, false));
-    CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
+    // steps of >= V21_FUSED_TRAIN_ROWS rows (default 24,576) of a stack with a compiled fused training kernel: 128 rows per
+    // workgroup, weights through an LDS ring, activations in registers (fused_train.h); below, the 32-row chain
+    // (measured r4, autoencoder stack, f16, whole step: 16,384 rows 98 us either way -- 128 workgroups fill half the chip --
+    //  24,576 rows 116 against 137 us, 32,768 rows 141 against 179, 65,536 rows 303 against 360; read per step: tests force it)
+    const char* efr = getenv("V21_FUSED_TRAIN_ROWS");
+    const int fused_rows = efr ? atoi(efr) : 24576;
+    const bool fused = t->train_arch >= 0 && rows >= fused_rows && !t->capturing;
+    if (fused) CHK(launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
+    else CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
     // Single rank, nothing to exchange: gradients, Adam and the packed copies in one launch (dw_adam.h) -- up to the
     // batch where its 32 x 32 tiles, each pulling its operands over the WHOLE batch through one CU, lose to the
     // 128 x 128 LDS-staged split-K kernel + an Adam launch that sums the slabs (V21_DW_SPLIT_ROWS overrides the
     // threshold; measured r3, autoencoder stack, f16: see DESIGN.md section 3)
     static const int split_rows = getenv("V21_DW_SPLIT_ROWS") ? atoi(getenv("V21_DW_SPLIT_ROWS")) : 8192;
-    if (t->ctx->nranks == 1 && (rows < split_rows || t->capturing)) {
+    if (t->ctx->nranks == 1 && (rows < split_rows || t->capturing) && !fused) {
       if (!t->capturing) t->iter += 1;
       // an epoch's per-step loss slot is written by the kernel itself (a device-to-device copy per step is a launch)
       const bool in_table = loss_out && t->d_steploss && loss_out >= t->d_steploss && loss_out < t->d_steploss + t->steploss_cap;

@@ -471,14 +471,17 @@ static __global__ void affine_out_kernel(float* __restrict__ y, long long ldy, l
 
 // Weight stream of the fused forward kernel (fused_fwd.h): one thread per (fragment,
 // lane).  Layer table in `lt`: per layer {K, N, ks, nt, w_off, b_off, first_frag}.
-struct PackLayer { int K, N, ks, nt; long long w_off, b_off; int first; int pad; };
+// flags: 1 = the layer's weights are read TRANSPOSED (element (f, n) = w[w_off + n * K + f]: an activation-gradient layer
+// of fused_train.h, whose K is the real layer's N), 2 = no bias (zero aux fragment)
+struct PackLayer { int K, N, ks, nt; long long w_off, b_off; int first; int flags; };
 struct PackArgs {
   const float* w;        // flat arena
   const float* mean;     // out_dim floats or nullptr
   unsigned char* stream;
   int L, total, padded, fpi, epi, esize;  // esize: 2 (f16/bf16) or 4 (f32)
   int is_bf16;
-  PackLayer lt[16];
+  int all_hidden;        // fused_train.h: every layer's aux fragment is the accumulator's initial value (no output-orientation layer)
+  PackLayer lt[32];
 };
 static __global__ void pack_stream_kernel(const PackArgs a) {
   const int F = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -500,8 +503,8 @@ static __global__ void pack_stream_kernel(const PackArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int idx = lane * 4 + q;
       float v = 0.f;
-      if (l < a.L - 1) {
-        if (idx < 32) {  // [h][reg]: bias[32nt + rho(reg) + 4h]
+      if (l < a.L - 1 || a.all_hidden) {
+        if (idx < 32 && !(L.flags & 2)) {  // [h][reg]: bias[32nt + rho(reg) + 4h]
           const int hh = idx >> 4, reg = idx & 15;
           const int n = 32 * nt + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
           if (n < L.N) v = a.w[L.b_off + n];
@@ -519,7 +522,7 @@ static __global__ void pack_stream_kernel(const PackArgs a) {
   for (int e = 0; e < a.epi; ++e) {
     const int f = a.fpi * ks + 8 * (e >> 2) + 4 * h + (e & 3);
     float v = 0.f;
-    if (f < L.K && n < L.N) v = a.w[L.w_off + (long long)f * L.N + n];
+    if (f < L.K && n < L.N) v = (L.flags & 1) ? a.w[L.w_off + (long long)n * L.K + f] : a.w[L.w_off + (long long)f * L.N + n];
     if (a.esize == 4) ((float*)dst)[lane * 4 + e] = v;
     else if (a.is_bf16) ((__bf16*)dst)[lane * 8 + e] = (__bf16)v;
     else ((_Float16*)dst)[lane * 8 + e] = (_Float16)v;

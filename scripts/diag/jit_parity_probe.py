@@ -1,7 +1,8 @@
 """Diagnostics (r4): the run-time-instantiated fused kernel against the float64 oracle, per stack / precision / row count."""
+import os
 import importlib, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 native = importlib.import_module("21cmvae_amd._native")
 from oracle import ref_numpy as ora
 ctx = native.Context.default()

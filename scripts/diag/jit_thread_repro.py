@@ -1,7 +1,8 @@
 """Diagnostics (r4): a run-time compilation (hiprtc thread, csrc/jit.hip) running beside kernel launches of the main thread."""
+import os
 import importlib, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 native = importlib.import_module("21cmvae_amd._native")
 from oracle import ref_numpy as ora
 ctx = native.Context.default()

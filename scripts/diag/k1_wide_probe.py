@@ -3,7 +3,7 @@ wave per SIMD with two column tiles (fused_fwd<S1, PrecF16>, instantiated throug
 against the shipped form (two workgroups per CU, one column tile per wave), with the shader clock sampled beside each."""
 import importlib, os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["V21_JIT_WIDE"] = "1"
 native = importlib.import_module("21cmvae_amd._native")
 dims, act, B = [7, 352, 352, 352, 224, 451], [1, 1, 1, 1, 0], 65536

@@ -243,6 +243,83 @@ def test_large_batch_step_uses_big_tiles_and_split_k(ctx):
     _close(g, ref, 5e-4, "gradient at batch 4096")
 
 
+FUSED_TRAIN_STACKS = [   # csrc/archs.h: the stacks with a compiled fused training kernel (csrc/fused_train.h)
+    ("T1 autoencoder", [451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0], True),
+    ("T2 latent emulator", [7, 352, 352, 352, 224, 9], [1, 1, 1, 1, 0], False),
+    ("T3 direct emulator (reference default)", [7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0], False),
+    ("T4 direct emulator (configs[1])", [7, 352, 352, 352, 224, 451], [1, 1, 1, 1, 0], False),
+]
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("case", range(len(FUSED_TRAIN_STACKS)), ids=[c[0].split()[0] for c in FUSED_TRAIN_STACKS])
+def test_fused_training_kernel_matches_chain_route_and_oracle(ctx, case, prec, monkeypatch):
+    """Large steps of f16 / bf16 trainers (>= 24,576 rows by default) take csrc/fused_train.h: 128 rows per workgroup,
+    weights through an LDS ring shared by four waves, activations, ReLU masks and the activation gradients in registers,
+    forward pass + loss + activation-gradient chain as ONE unrolled virtual stack.  Forced here onto a ragged step of
+    1,000 rows (7 workgroups of 128 + one of 104; 1,000 = 62.5 groups of 16) of every stack it is compiled for: loss and
+    FULL gradient against the 32-row chain route (the same 16-bit arithmetic in another order) and the float64 oracle, a
+    second step (the packed stream is rebuilt from the arena Adam moved), targets = inputs and separate targets."""
+    native, synth = pkg("_native"), pkg("synth")
+    name, dims, act, ae = FUSED_TRAIN_STACKS[case]
+    n = 1000
+    rng = np.random.default_rng(40 + case)
+    Ws, bs = ora.init_mlp(dims, seed=30 + case)
+    bs = [rng.normal(scale=0.05, size=b.shape).astype(np.float32) for b in bs]
+    flat = ora.flatten_params(Ws, bs)
+    if ae:
+        sig = synth.make_signals(n, seed=9)
+        x = ora.preproc(sig, sig); y = None
+        w = ora.relative_mse_row_weight(x, sig).astype(np.float32)
+    else:
+        x = rng.uniform(-1, 1, size=(n, dims[0])).astype(np.float32)
+        if dims[-1] == 451:
+            sig = synth.make_signals(n, seed=10)
+            y = ora.preproc(sig, sig)
+            w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+        else:
+            y = rng.normal(size=(n, dims[-1])).astype(np.float32)
+            w = ora.mse_row_weight(y).astype(np.float32)
+    res = {}
+    for route, rows_env in (("chain", "1000000"), ("fused", "1")):
+        monkeypatch.setenv("V21_FUSED_TRAIN_ROWS", rows_env)
+        st = native.Stack(ctx, dims, act); st.set_weights(flat)
+        tr = native.Trainer(st, prec, n); tr.set_adam(lr=1e-3)
+        tr.set_data(0, x, y, w)
+        l1 = tr.run_epoch(None, n)
+        g1 = tr.get_grad()
+        l2 = tr.run_epoch(ora.epoch_permutation(n, 3, 0), n)     # gathered through an index table, weights moved by Adam
+        res[route] = (l1, g1, l2, st.get_weights())
+    # float64 oracle: loss and gradient of the first step
+    W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
+    acts = [x.astype(np.float64)]
+    for W_, b_, a_ in zip(W, b, act):
+        z = acts[-1] @ W_ + b_
+        acts.append(np.maximum(z, 0) if a_ else z)
+    tgt = (x if y is None else y).astype(np.float64)
+    lo, dz = ora.batch_loss_and_grad(acts[-1], tgt, w.astype(np.float64))
+    L = len(act)
+    dWs, dbs = [None] * L, [None] * L
+    for li in range(L - 1, -1, -1):
+        dWs[li] = acts[li].T @ dz; dbs[li] = dz.sum(0)
+        dh = dz @ W[li].T
+        dz = dh * (acts[li] > 0) if li > 0 and act[li - 1] else dh
+    go = ora.flatten_params(dWs, dbs)
+    tol_l, tol_c = (3e-3, 0.9995) if prec == "f16" else (3e-2, 0.995)
+    for route in ("chain", "fused"):
+        l1, g1, l2, _ = res[route]
+        assert abs(l1 - lo) / lo < tol_l, (name, route, l1, lo)
+        cos = float(g1 @ go / (np.linalg.norm(g1) * np.linalg.norm(go)))
+        assert cos > tol_c and abs(np.linalg.norm(g1) / np.linalg.norm(go) - 1) < 10 * tol_l, (name, route, cos)
+    (lc, gc, lc2, wc), (lf, gf, lf2, wf) = res["chain"], res["fused"]
+    # the two routes round the same operands to 16 bits and sum in fp32: they agree far better than either meets float64
+    assert abs(lf - lc) / lc < 1e-5 and abs(lf2 - lc2) / lc2 < 1e-3, (name, lf, lc, lf2, lc2)
+    cos = float(gc @ gf / (np.linalg.norm(gc) * np.linalg.norm(gf)))
+    assert cos > 0.99999 and np.abs(gc - gf).max() <= 2e-3 * np.abs(gc).max(), (name, cos, np.abs(gc - gf).max(), np.abs(gc).max())
+    dc, df = wc - flat, wf - flat
+    assert float(dc @ df / (np.linalg.norm(dc) * np.linalg.norm(df))) > 0.999
+
+
 # ---- A13: variational latent layer (V21_ACT_GAUSS) -- build-side extension ----------------
 def _make_vae(ctx, dims, gl, seed=0, max_batch=256, prec="f32"):
     """dims = widths the NEXT layer sees; layer `gl` is the (z_mean | z_log_var) head, so its
