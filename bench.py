@@ -205,7 +205,19 @@ def cpu_baseline(weights_flat, x_f32, budget_s=6.0):
     return out
 
 
-PROFILE_TAG = "r3"  # profiles/<tag>/: the rocprofv3 summaries of this round (scripts/collect_profiles.sh)
+PROFILE_TAG = "r4"  # profiles/<tag>/: the rocprofv3 summaries of this round (scripts/collect_profiles_r4.sh)
+
+
+def _profile_is_current():
+    """True when profiles/<tag>/BUILD_ID names the sources the running library was built from (scripts/build_id.py): the
+    per-kernel durations and PMC bytes quoted from profiles/ beside a live timing are only shown as current then
+    (stale profile numbers beside fresh timings)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from build_id import build_id
+        return open(os.path.join(ROOT, "profiles", PROFILE_TAG, "BUILD_ID")).read().strip() == build_id()
+    except Exception:
+        return False
 
 
 def _profile_kernels(name):
@@ -238,6 +250,7 @@ def train_roofline(leg, flop_per_sample, params, din, dout, stats_csv, pmc_json)
           "frac": flop / step_s / 1e12 / PEAK_TFLOPS[prec], "algorithmic_flop_per_step": flop,
           "algorithmic_bytes_per_step": alg_bytes, "traffic": None,
           "time_base": "wall clock over the timed steps of this leg (whole step: every launch and the gaps between them)"}
+    rf["profile_matches_build"] = _profile_is_current()
     rows = _profile_kernels(stats_csv)
     if rows:
         ks = [r for r in rows if "v21::" in r[0] and r[1] >= 10]
@@ -246,7 +259,8 @@ def train_roofline(leg, flop_per_sample, params, din, dout, stats_csv, pmc_json)
         if ks:
             rf["kernel"] = ks[0][0][:90]
             rf["kernel_ms"] = ks[0][2] / 1e6
-        rf["kernel_source"] = "profiles/%s/%s (rocprofv3 --kernel-trace --stats of scripts/train_probe.py at this batch)" % (PROFILE_TAG, stats_csv)
+        rf["kernel_source"] = "profiles/%s/%s (rocprofv3 --kernel-trace --stats of scripts/train_probe.py at this batch)%s" % (
+            PROFILE_TAG, stats_csv, "" if rf["profile_matches_build"] else "; STALE: the library sources changed since that profile was collected")
     path = os.path.join(ROOT, "profiles", PROFILE_TAG, pmc_json)
     if os.path.exists(path):
         try:
@@ -725,13 +739,14 @@ def main():
     # this same command and are kept under profiles/ (hbm_bytes = 2*FETCH*1024 + WRITE*1024 on gfx950).
     pmc = os.path.join(ROOT, "profiles", PROFILE_TAG, "pmc_fused_%s.json" % args.precision)
     if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r2", "pmc_fused_%s.json" % args.precision)  # (the kernel is unchanged since r2)
+        pmc = os.path.join(ROOT, "profiles", "r3", "pmc_fused_%s.json" % args.precision)
     if os.path.exists(pmc) and B == BATCH:
         try:
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = "%s (rocprofv3 --pmc, kernel %s)" % (
                 os.path.relpath(pmc, ROOT), json.load(open(pmc)).get("_kernel", "?"))
             out["roofline"]["algorithmic_bytes"] = BYTES_PER_SIGNAL * B
+            out["roofline"]["profile_matches_build"] = _profile_is_current()
         except Exception:
             pass
 
@@ -902,6 +917,15 @@ def main():
                                                       "kernel_stats_train_b16384_%s.csv" % args.precision,
                                                       "pmc_train_b16384_%s.json" % args.precision)
                     out["train_b16384"] = t16k
+                    # r4: steps of >= 24,576 rows take the fused training kernel (csrc/fused_train.h: 128 rows per workgroup,
+                    # weights through an LDS ring, activations in registers); V21_FUSED_TRAIN_ROWS sets the threshold
+                    t32k = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier, sync_all, 32768,
+                                     args.precision, max(10, args.train_steps // 4), 5)
+                    t32k["roofline"] = train_roofline(t32k, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
+                                                      "kernel_stats_train_b32768_%s.csv" % args.precision,
+                                                      "pmc_train_b32768_%s.json" % args.precision)
+                    t32k["route"] = "fused training kernel (fused_train<ArchT1, Prec%st>) + split-K weight gradients + Adam" % args.precision.upper()
+                    out["train_b32768"] = t32k
                     out["train_variational"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
                                                          sync_all, args.train_batch, args.precision, args.train_steps, 20,
                                                          variational=True)
