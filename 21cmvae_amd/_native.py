@@ -450,7 +450,9 @@ class Stack:
 
 def jit_prebuild(dims, act, precision, directory=None):
     """Compile the fused kernel of (dims, act, precision) into `directory` (None: kernel_cache/ next to libv21.so).
-    Needs hiprtc but no GPU."""
+    Needs hiprtc but no GPU.  Call it from a process that has not loaded ANOTHER LLVM (importing torch does: hiprtc then
+    finds that copy's option table, which lacks the AMDGPU flags, and LLVM ends the process) -- a build step, as
+    __graft_entry__.build() uses it; at run time the library compiles in a child process of its own (csrc/jitc_main.cpp)."""
     lib = load_library()
     L = len(act)
     check(lib.v21_jit_prebuild(L, (C.c_int * (L + 1))(*[int(d) for d in dims]), (C.c_int * L)(*[int(a) for a in act]),

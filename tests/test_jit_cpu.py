@@ -14,19 +14,28 @@ HAVE_HIPRTC = os.path.exists("/opt/rocm/lib/libhiprtc.so") or ctypes.util.find_l
 needs_hiprtc = pytest.mark.skipif(not HAVE_HIPRTC, reason="libhiprtc is not installed here")
 
 
+def _prebuild_in_a_fresh_process(dims, act, prec, d):
+    """hiprtc's LLVM must be the only one in its process (pytest has torch's loaded by now: its option table lacks the AMDGPU
+    flags and LLVM exits): a fresh interpreter, as __graft_entry__.build() uses -- the library itself compiles in `v21_jitc`."""
+    import sys
+    code = ("import importlib, sys; sys.path.insert(0, %r); n = importlib.import_module('21cmvae_amd._native'); "
+            "n.jit_prebuild(%r, %r, %r, %r)" % (ROOT, dims, act, prec, d))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
+
+
 @needs_hiprtc
 def test_prebuild_writes_a_code_object_and_finds_it_again(tmp_path):
-    native = pkg("_native")
     d = str(tmp_path / "kc")
-    native.jit_prebuild([7, 48, 451], [1, 0], "f16", d)
+    _prebuild_in_a_fresh_process([7, 48, 451], [1, 0], "f16", d)
     files = os.listdir(d)
     assert len(files) == 1 and files[0].startswith("fused_7x48x451_a10_PrecF16x2sp_") and files[0].endswith(".v21k")
     blob = open(os.path.join(d, files[0]), "rb").read()
     assert blob[:8] == b"V21KOBJ1" and b"fused_fwd" in blob[:200] and b"\x7fELF" in blob   # header, mangled kernel name, code object
     mtime = os.path.getmtime(os.path.join(d, files[0]))
-    native.jit_prebuild([7, 48, 451], [1, 0], "f16", d)                                     # same sources, same options: found, not rebuilt
+    _prebuild_in_a_fresh_process([7, 48, 451], [1, 0], "f16", d)                            # same sources, same options: found, not rebuilt
     assert os.path.getmtime(os.path.join(d, files[0])) == mtime
-    native.jit_prebuild([7, 48, 451], [1, 0], "f32", d)                                     # another precision: another kernel
+    _prebuild_in_a_fresh_process([7, 48, 451], [1, 0], "f32", d)                            # another precision: another kernel
     assert len(os.listdir(d)) == 2
 
 
