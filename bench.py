@@ -676,13 +676,21 @@ def main():
         timed.per_launch_ms = [ctx.elapsed_ms(evs[i], evs[i + 1]) for i in range(steps)]
         # the shader clock these launches run at: a THIRD untimed run of the same K launches with one
         # sampling wave beside them (v21_debug_clock_probe_*: s_memtime against the 100 MHz s_memrealtime), started once
-        # the launches are enqueued and sampling for the middle 60 % of the run
+        # the launches are enqueued and sampling for about half of the run
         timed.clock = None
         try:
             run_ms = max(0.4, steps * ev_ms / max(steps, 1))
-            for _ in range(steps):
+            # (under the same conditions as the timed launches: the reading of the per-launch events above left the GPU
+            #  idle for milliseconds, and an idle chip boosts -- the same untimed settle phase first)
+            t_s = time.perf_counter()
+            while time.perf_counter() - t_s < args.settle:
+                for _ in range(100):
+                    stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
+                ctx.sync()
+            for _ in range(warmup + steps):
                 stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
-            ctx.clock_probe_start(0.6 * run_ms, period_us=max(20.0, 0.6 * run_ms * 1000.0 / 200.0))
+            run_ms = run_ms * (warmup + steps) / max(steps, 1)
+            ctx.clock_probe_start(0.5 * run_ms, period_us=max(20.0, 0.5 * run_ms * 1000.0 / 200.0))
             ctx.sync()
             timed.clock = ctx.clock_probe_read()
         except Exception as e:  # pragma: no cover
@@ -747,6 +755,21 @@ def main():
                 os.path.relpath(pmc, ROOT), json.load(open(pmc)).get("_kernel", "?"))
             out["roofline"]["algorithmic_bytes"] = BYTES_PER_SIGNAL * B
             out["roofline"]["profile_matches_build"] = _profile_is_current()
+        except Exception:
+            pass
+    # MFMA-pipe occupancy (north_star: ">= 50 % MFMA utilisation", by rocprof): SQ_VALU_MFMA_BUSY_CYCLES of the timed
+    # launches (profiles/<tag>/pmc_fused_*_timed_launches_mfma_busy.json: summed over the 1,024 SIMDs; it is 32 cycles per
+    # 32x32x16 MFMA, so it does not depend on the clock the profiled run had) over the cycles a SIMD had during one launch
+    # of THIS run: kernel time x the clock measured beside the launches
+    busy = os.path.join(ROOT, "profiles", PROFILE_TAG, "pmc_fused_%s_timed_launches_mfma_busy.json" % args.precision)
+    if os.path.exists(busy) and B == BATCH and out["roofline"].get("clock_ghz"):
+        try:
+            per_simd = json.load(open(busy))["mfma_busy_cycles_per_simd"]
+            cyc = kern_s * out["roofline"]["clock_ghz"] * 1e9
+            out["roofline"]["mfma_busy_cycles_per_simd"] = per_simd
+            out["roofline"]["mfma_pipe_busy_frac"] = per_simd / cyc
+            out["roofline"]["mfma_pipe_busy_source"] = ("%s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, the timed launches only) / "
+                                                        "(kernel_ms x clock_ghz of this run)" % os.path.relpath(busy, ROOT))
         except Exception:
             pass
 
