@@ -19,6 +19,8 @@ torch = pytest.importorskip("torch")
 import torch.multiprocessing as mp  # noqa: E402
 
 DIMS, ACT = [451, 48, 9, 24, 451], ["relu", None, "relu", None]
+# the reference's autoencoder at full width: the stack csrc/fused_train.h is compiled for (archs.h: T1)
+DIMS_T1, ACT_T1 = [451, 352, 9, 32, 352, 451], ["relu", None, "relu", "relu", None]
 
 
 def _free_port():
@@ -33,8 +35,13 @@ def _data():
     return pp.preproc(sig, sig).astype(np.float32), pp.preproc(sv, sig).astype(np.float32), sig
 
 
-def _fit(prec, seed, world=1, rank=0, sharded=False, port=0):
+def _fit(prec, seed, world=1, rank=0, sharded=False, port=0, fused=False):
     import importlib
+    if fused:  # every step through the fused training kernel (large steps take it by default: >= 24,576 rows)
+        os.environ["V21_FUSED_TRAIN_ROWS"] = "1"
+    else:
+        os.environ.pop("V21_FUSED_TRAIN_ROWS", None)
+    dims, acts = (DIMS_T1, ACT_T1) if fused else (DIMS, ACT)
     sys.path.insert(0, ROOT)
     eng = importlib.import_module("21cmvae_amd.engine")
     native = importlib.import_module("21cmvae_amd._native")
@@ -47,7 +54,7 @@ def _fit(prec, seed, world=1, rank=0, sharded=False, port=0):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         importlib.import_module("21cmvae_amd.parallel").init_engine_comm(native.Context.default(), backend="host", sharded=sharded)
     eng.set_random_seed(seed)  # different on every rank: rank 0's weights and shuffles must win
-    m = eng.Sequential([eng.Input((451,))] + [eng.Dense(u, a) for u, a in zip(DIMS[1:], ACT)])
+    m = eng.Sequential([eng.Input((451,))] + [eng.Dense(u, a) for u, a in zip(dims[1:], acts)])
     m.precision = prec
     m.compile(optimizer=optm.Adam(2e-3), loss=losses.relative_mse_loss(sig))
     h = m.fit(y, y, batch_size=128, epochs=3, validation_data=(yv, yv), verbose=0)   # 128 + 128 + 44 rows per epoch
@@ -57,23 +64,27 @@ def _fit(prec, seed, world=1, rank=0, sharded=False, port=0):
         import torch.distributed as dist
         native.Context.default().comm_destroy()
         dist.destroy_process_group()
+    os.environ.pop("V21_FUSED_TRAIN_ROWS", None)
     return out
 
 
-def _worker(rank, world, port, prec, sharded, q):
+def _worker(rank, world, port, prec, sharded, q, fused=False):
     try:
-        q.put((rank, _fit(prec, seed=100 + rank, world=world, rank=rank, sharded=sharded, port=port)))
+        q.put((rank, _fit(prec, seed=100 + rank, world=world, rank=rank, sharded=sharded, port=port, fused=fused)))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
 
 
-@pytest.mark.parametrize("prec,sharded", [("f32", False), ("f32", True), ("f16", True)])
-def test_two_ranks_on_one_gpu_equal_one_process(prec, sharded):
+@pytest.mark.parametrize("prec,sharded,fused", [("f32", False, False), ("f32", True, False), ("f16", True, False), ("f16", False, True)],
+                         ids=["f32-allreduce", "f32-sharded", "f16-sharded", "f16-allreduce-fused_train"])
+def test_two_ranks_on_one_gpu_equal_one_process(prec, sharded, fused):
+    """(the last case: every rank's share of every batch goes through the fused training kernel, csrc/fused_train.h, then
+    the split-K weight gradients, the exchange and Adam -- the route of large data-parallel steps)"""
     world, port = 2, _free_port()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, prec, sharded, q)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, prec, sharded, q, fused)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
@@ -87,11 +98,11 @@ def test_two_ranks_on_one_gpu_equal_one_process(prec, sharded):
     assert l0 == l1 and v0 == v1                               # ... and saw the same losses (callbacks decide alike)
     assert s0[0] == s1[0] == 9
     np.testing.assert_array_equal(s0[1], s1[1])                # gathered Adam moments
-    ws, ls, vs, ss = _fit(prec, seed=100)                      # one process, rank 0's seed
+    ws, ls, vs, ss = _fit(prec, seed=100, fused=fused)         # one process, rank 0's seed
     tol = 2e-5 if prec == "f32" else 2e-3                      # the split batch sums in another order (and in f16 operands)
     assert max(abs(a - b) / b for a, b in zip(l0, ls)) < tol, (l0, ls)
     assert max(abs(a - b) / b for a, b in zip(v0, vs)) < tol
-    d1, ds = w0 - _init_weights(), ws - _init_weights()
+    d1, ds = w0 - _init_weights(fused), ws - _init_weights(fused)
     cos = float(d1 @ ds / (np.linalg.norm(d1) * np.linalg.norm(ds)))
     assert cos > (0.99999 if prec == "f32" else 0.999), cos
     np.testing.assert_allclose(s0[1], ss[1], rtol=0, atol=(1e-5 if prec == "f32" else 2e-3) * np.abs(ss[1]).max())
@@ -162,10 +173,11 @@ def test_joint_step_two_ranks_equal_one_process(prec):
         assert max(abs(x - y) / y for x, y in zip(a, b)) < (5e-3 if prec == "f16" else 1e-4), (a, b)
 
 
-def _init_weights():
+def _init_weights(fused=False):
     eng = pkg("engine")
     eng.set_random_seed(100)
-    m = eng.Sequential([eng.Input((451,))] + [eng.Dense(u, a) for u, a in zip(DIMS[1:], ACT)])
+    dims, acts = (DIMS_T1, ACT_T1) if fused else (DIMS, ACT)
+    m = eng.Sequential([eng.Input((451,))] + [eng.Dense(u, a) for u, a in zip(dims[1:], acts)])
     return np.concatenate([a.ravel() for a in m.get_weights()])
 
 
