@@ -20,6 +20,7 @@ ctx.h2d(d_x, y); ctx.h2d(d_rw, w)
 res = {}
 for name, env in (("chain", "0"), ("fused", "1")):
     os.environ["V21_FUSED_TRAIN"] = env
+    os.environ["V21_FUSED_TRAIN_ROWS"] = "1"   # (the default threshold is 24,576 rows: the probe compares the routes at any size)
     st = native.Stack(ctx, dims, act); st.set_weights(flat)
     tr = native.Trainer(st, prec, rows); tr.set_adam(lr=1e-3)
     tr.step_dev(d_x, None, d_rw, rows, rows)
