@@ -116,14 +116,21 @@ std::string lib_dir() {
   }
   return ".";
 }
-std::string user_cache_dir() {
-  if (const char* e = getenv("V21_KERNEL_CACHE")) return e;
-  const char* home = getenv("HOME");
-  return std::string(home && *home ? home : "/tmp") + "/.cache/21cmvae_amd/kernels";
-}
 void mkdirs(const std::string& d) {
   for (size_t i = 1; i <= d.size(); ++i)
     if (i == d.size() || d[i] == '/') mkdir(d.substr(0, i).c_str(), 0755);
+}
+// $V21_KERNEL_CACHE, else ~/.cache/21cmvae_amd/kernels, else (no home directory, or one that cannot be written: a
+// container running as another user) a per-user directory under /tmp
+std::string user_cache_dir() {
+  if (const char* e = getenv("V21_KERNEL_CACHE")) return e;
+  const char* home = getenv("HOME");
+  if (home && *home) {
+    const std::string d = std::string(home) + "/.cache/21cmvae_amd/kernels";
+    mkdirs(d);
+    if (access(d.c_str(), W_OK | X_OK) == 0) return d;
+  }
+  return "/tmp/21cmvae_amd_kernels_" + std::to_string((long)getuid());
 }
 
 constexpr char kMagic[8] = {'V', '2', '1', 'K', 'O', 'B', 'J', '1'};

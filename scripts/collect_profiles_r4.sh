@@ -58,6 +58,7 @@ echo "forward + joint + sweep done"
 cd $ROOT
 $PY scripts/diag/k1_wide_probe.py > $OUT/k1_wide_variant_and_clock_probe.txt 2>&1
 $PY scripts/diag/jit_parity_probe.py > $OUT/jit_parity_probe.txt 2>&1
+$PY scripts/diag/jit_fuzz.py 40 1 > $OUT/jit_fuzz_40_random_stacks.txt 2>&1
 for n in 16384 32768; do $PY scripts/diag/fused_train_probe.py $n f16 > $OUT/fused_train_probe_b${n}_f16.txt 2>&1; done
 $PY scripts/power_probe.py > $OUT/power_probe_fused_random_vs_zero_operands.txt 2>&1
 rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t*f16 $OUT/t*f32 $OUT/t32kc $OUT/tpmc_* $OUT/fwd $OUT/joint $OUT/joint32 $OUT/sweep_f16 $OUT/sweep_f32
