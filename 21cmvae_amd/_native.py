@@ -100,6 +100,7 @@ SIGNATURES = {
     "v21_trainer_use_graph": (C.c_int, [_P, C.c_int]),
     "v21_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
     "v21_debug_check_chain_jobs": (C.c_int, [_P, C.c_longlong, C.c_longlong]),
+    "v21_debug_trainer_counters": (C.c_int, [_P, C.POINTER(C.c_longlong)]),
     "v21_debug_clock_probe_start": (C.c_int, [_P, C.c_double, C.c_double]),
     "v21_debug_clock_probe_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
@@ -562,6 +563,14 @@ class Trainer:
         """Diagnostics: validate the small-batch f32 chain's job table against packed streams of the given sizes
         (bytes; -1 = the allocated ones).  Raises EngineError where a row points outside."""
         check(self.lib.v21_debug_check_chain_jobs(self.h, int(fw_bytes), int(bw_bytes)))
+
+    def route_counters(self):
+        """Diagnostics: eager 16-bit steps so far by route: dict(chain=, fused=, stream_packs=, stream_adam=) -- steps through
+        the 32-row chain, through the fused training kernel, fused steps that launched the stream pack first, Adam passes
+        that wrote the fused kernel's stream (include/v21.h: v21_debug_trainer_counters)."""
+        out = (C.c_longlong * 4)()
+        check(self.lib.v21_debug_trainer_counters(self.h, out))
+        return dict(zip(("chain", "fused", "stream_packs", "stream_adam"), (int(v) for v in out)))
 
     def enable_stamps(self, on=True):
         """Cycle stamps of the chain kernel's phases (diagnostics; off by default: they cost 2-3 us per step)."""

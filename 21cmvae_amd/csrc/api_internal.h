@@ -191,6 +191,10 @@ struct v21_trainer {
   int train_arch = -1;
   unsigned char* d_tstream = nullptr;
   int tstream_total = 0, tstream_padded = 0;
+  std::vector<int> ts_first;    // first fragment of every virtual layer (2 L - 1 of them)
+  bool ts_write = false;        // the Adam pass that ends the current step also rewrites d_tstream (the step took the fused kernel)
+  long long n_chain_steps = 0, n_fused_steps = 0, n_stream_packs = 0, n_stream_adam = 0;  // v21_debug_trainer_counters
+  bool tstream_fresh = false;   // d_tstream holds the arena's current weights (cleared by every ensure_copies: any other step, eval, sweep, joint)
   int* d_dworder = nullptr;            // dw_adam.h: tile order per XCD (two-dimensional blocks per layer)
   int dw_xper = 0;
   long long BS = 0;                    // batch steps of 16 per feature tile

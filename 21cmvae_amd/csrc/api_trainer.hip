@@ -109,7 +109,12 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
       CHK(zalloc(&t->d_partial, (size_t)(max_batch + 31) / 32 + 4, st));
       HIPCHK(hipMalloc((void**)&t->d_ticket, 16)); HIPCHK(hipMemsetAsync(t->d_ticket, 0, 16, st));
       HIPCHK(hipMalloc((void**)&t->d_stamps, kStampSlots * 8)); HIPCHK(hipMemsetAsync(t->d_stamps, 0, kStampSlots * 8, st));
-      t->BS = ((long long)max_batch + 31) / 32 * 2 + 2;
+      // 16-row groups per feature tile of the operand buffers, for whole 128-row blocks: the fused training kernel
+      // (fused_train.h) stores every group of a workgroup's 128 rows, pad rows included, and a group past BS would land in
+      // the NEXT feature tile's first rows (r4: with BS from 32-row blocks, a ragged step whose last 128-row block reached
+      // past it -- 777 rows of max_batch 777 -- had rows 0-63 of the following tile overwritten by whichever workgroup
+      // finished last; launch_fused_train checks the bound)
+      t->BS = ((long long)max_batch + 127) / 128 * 8 + 2;
       t->d_ht16.assign(L + 1, nullptr); t->d_dzt16.assign(L + 1, nullptr);
       const unsigned short one = precision == V21_PREC_F16 ? 0x3C00 : 0x3F80;
       for (int l = 0; l < L; ++l) {
@@ -139,6 +144,7 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
         for (int v = 0; v < 2 * L - 1; ++v) {
           const int l = v < L ? v : 2 * L - 1 - v;
           const int K = v < L ? m->dims[l] : m->dims[l + 1], N = v < L ? m->dims[l + 1] : m->dims[l];
+          t->ts_first.push_back(total);
           total += ((N + 31) / 32) * ((K + 15) / 16 + 1);
         }
         t->tstream_total = total;
@@ -318,6 +324,8 @@ static int adam_and_copies(v21_trainer* t, bool do_adam, float alpha, bool skip_
   HIPCHK(hipGetLastError());
   t->copies_ok = true;
   t->nt_ok = !skip_nt;
+  t->tstream_fresh = a.ts != nullptr;
+  if (a.ts) t->n_stream_adam += 1;
   return V21_OK;
 }
 AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_nt) {
@@ -340,6 +348,15 @@ AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_nt) {
   }
   if (t->chain) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->prec == V21_PREC_F16 ? 1 : 2; }
   if (t->chain32) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->chain32s ? 4 : 3; }
+  if (t->ts_write && t->d_tstream) {  // fused_train.h's stream from the same pass (api_trainer.hip: train_on_rows)
+    a.ts = t->d_tstream; a.ts_bf16 = t->prec == V21_PREC_BF16;
+    const int L = m->L;
+    for (int l = 0; l < L; ++l) {
+      AdamLayer& al = a.lt[l];
+      al.tsf = t->ts_first[l]; al.tkf = (m->dims[l] + 15) / 16;
+      al.tsb = l >= 1 ? t->ts_first[2 * L - 1 - l] : -1; al.tkb = (m->dims[l + 1] + 15) / 16;
+    }
+  }
   a.skip_nt = (skip_nt && (t->chain || t->chain32)) ? 1 : 0;
   if (do_adam && t->chain32 && t->loss_slot_pending > -2) {  // a single-rank f32 chain step: this launch publishes its loss
     a.loss_acc = (unsigned long long*)t->d_ticket; a.loss_out = t->d_g + t->P; a.loss_out2 = t->d_steploss;
@@ -390,6 +407,7 @@ int reduce_and_update(v21_trainer* t, bool chain_copies, int fold) {
 
 // need_nt: the caller reads the fp32 copies (per-layer forward/backward); chain steps do not
 int ensure_copies(v21_trainer* t, bool need_nt) {
+  t->tstream_fresh = false;  // (every step, evaluation, sweep or joint step passes here: only a fused-route step's Adam pass sets it again)
   // the arena may have been rewritten behind our back (set_weights): wpad_ok doubles as the dirty flag
   if (t->copies_ok && t->mlp->wpad_ok && (t->nt_ok || !need_nt)) return V21_OK;
   CHK(adam_and_copies(t, false, 0.f));
@@ -645,10 +663,16 @@ int chain_prefetchers(int ncons, int models) {
 // layers with the transposed weights -- is rebuilt from the arena (the previous step's Adam moved it), then one launch
 // carries 128 rows per workgroup through forward pass, loss and activation gradients.
 static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
-                              const int* d_idx, long long first, int rows, int brows, long long row0) {
+                              const int* d_idx, long long first, int rows, int brows, long long row0, bool stream_fresh) {
   v21_mlp* m = t->mlp;
   const int L = m->L;
   hipStream_t st = t->ctx->stream;
+  // (the previous step's Adam pass wrote the stream itself when that step took this route too: adam_repack_element)
+  if ((long long)((rows + kTrainRowsPerWg - 1) / kTrainRowsPerWg) * (kTrainRowsPerWg / 16) > t->BS)
+    return fail(V21_ERR_STATE, "fused training step of %d rows: its 128-row blocks reach past the operand buffers (%lld groups of 16)", rows, t->BS);
+  t->n_fused_steps += 1;
+  if (!stream_fresh) {
+  t->n_stream_packs += 1;
   PackArgs pa{};
   pa.w = m->d_w; pa.mean = nullptr; pa.stream = t->d_tstream;
   pa.L = 2 * L - 1; pa.total = t->tstream_total; pa.padded = t->tstream_padded;
@@ -666,6 +690,7 @@ static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, con
   }
   hipLaunchKernelGGL(pack_stream_kernel, dim3((pa.padded + 3) / 4), dim3(256), 0, st, pa);
   HIPCHK(hipGetLastError());
+  }
   ChainArgs a{};
   static_cast<ChainModel&>(a) = chain_model(t);
   static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, m->dims[L], nullptr, row0);
@@ -1073,17 +1098,22 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   hipStream_t st = t->ctx->stream;
   int fold = 1;
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
+  bool fused_step = false;
   if (rows > 0) {
+    const bool ts_fresh = t->tstream_fresh && t->copies_ok && t->mlp->wpad_ok;  // (read before ensure_copies clears it)
     CHK(ensure_copies(t, false));
-    // steps of >= V21_FUSED_TRAIN_ROWS rows (default 24,576) of a stack with a compiled fused training kernel: 128 rows per
-    // workgroup, weights through an LDS ring, activations in registers (fused_train.h); below, the 32-row chain
-    // (measured r4, autoencoder stack, f16, whole step: 16,384 rows 98 us either way -- 128 workgroups fill half the chip --
-    //  24,576 rows 116 against 137 us, 32,768 rows 141 against 179, 65,536 rows 303 against 360; read per step: tests force it)
+    // steps of >= V21_FUSED_TRAIN_ROWS rows (default 16,384) of a stack with a compiled fused training kernel: 128 rows per
+    // workgroup, weights through an LDS ring, activations in registers (fused_train.h); below, the 32-row chain.  The
+    // kernel's weight stream is written by the previous step's Adam pass (AdamArgs::ts), so a step is 3 launches
+    // (measured r4, autoencoder stack, f16, whole step, fused against chain: 9,216-14,336 rows 76-82 against 77-83 us,
+    //  a tie; 16,384 rows 90 against 96-100; 20,480 rows 103 against 125; 24,576 rows 114 against 137; 32,768 rows
+    //  139-147 against 171-180; read per step: tests force it)
     const char* efr = getenv("V21_FUSED_TRAIN_ROWS");
-    const int fused_rows = efr ? atoi(efr) : 24576;
+    const int fused_rows = efr ? atoi(efr) : 16384;
     const bool fused = t->train_arch >= 0 && rows >= fused_rows && !t->capturing;
-    if (fused) CHK(launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
-    else CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0));
+    fused_step = fused;
+    if (fused) CHK(launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, ts_fresh));
+    else { CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0)); if (!t->capturing) t->n_chain_steps += 1; }
     // Single rank, nothing to exchange: gradients, Adam and the packed copies in one launch (dw_adam.h) -- up to the
     // batch where its 32 x 32 tiles, each pulling its operands over the WHOLE batch through one CU, lose to the
     // 128 x 128 LDS-staged split-K kernel + an Adam launch that sums the slabs (V21_DW_SPLIT_ROWS overrides the
@@ -1119,7 +1149,10 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     CHK(adam_and_copies(t, true, 0.f, true, fold));
     return V21_OK;
   }
-  CHK(reduce_and_update(t, true, fold));
+  t->ts_write = fused_step;  // the next step probably takes the fused kernel too: its stream comes out of this Adam pass
+  const int ru = reduce_and_update(t, true, fold);
+  t->ts_write = false;
+  CHK(ru);
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
   invalidate_streams(m);
   m->wpad_ok = true;
@@ -1490,6 +1523,11 @@ extern "C" int v21_debug_check_chain_jobs(v21_trainer* t, long long fw_bytes, lo
   if (const char* why = c32s_validate_jobs(a, tab.data(), (fw_bytes < 0 ? t->fw_bytes : fw_bytes) / 16,
                                            (bw_bytes < 0 ? t->bw_bytes : bw_bytes) / 16, (long long)t->P))
     return fail(V21_ERR_STATE, "%s", why);
+  return V21_OK;
+}
+extern "C" int v21_debug_trainer_counters(v21_trainer* t, long long out[4]) {
+  if (!t || !out) return fail(V21_ERR_ARG, "null argument");
+  out[0] = t->n_chain_steps; out[1] = t->n_fused_steps; out[2] = t->n_stream_packs; out[3] = t->n_stream_adam;
   return V21_OK;
 }
 extern "C" int v21_trainer_use_graph(v21_trainer* t, int enable) {

@@ -24,6 +24,7 @@
 #include "fused_fwd.h"
 #include "gemm_nt.h"
 #include "train_chain.h"
+#include "archs.h"
 
 namespace v21 {
 
@@ -35,7 +36,7 @@ constexpr int kTrainStageBytes = 4 * 32 * kTrainStagePitch * 2;         // four 
 constexpr int kTrainMaskTiles = 48;                                     // ReLU mask tiles of a stack (16 bits per lane and tile, kept in LDS)
 constexpr int kTrainMaskBytes = 4 * kTrainMaskTiles * 64 * 2;
 template <class P> constexpr int fused_train_lds() { return fused_lds<P>() + kTrainStageBytes + kTrainMaskBytes; }
-constexpr int kTrainRowsPerWg = 128;
+// (kTrainRowsPerWg = 128 rows per workgroup: archs.h)
 #ifndef V21_TRAIN_WPS
 #define V21_TRAIN_WPS 1
 #endif

@@ -267,6 +267,9 @@ static __global__ void sum_group_kernel(const SumGroup a) {  // one workgroup pe
 struct AdamLayer {
   long long w_off, wt_off, wp_off; int K, N; long long ldwt, ldwp;
   long long fw_off, bw_off; int KS, NS;  // train_chain.h streams (element offsets; k-/n-steps padded to whole units: chain_steps())
+  // fused_train.h stream (AdamArgs::ts): first fragment of this layer as a forward virtual layer and as an
+  // activation-gradient virtual layer (-1: layer 0 has none), k-steps of 16 per tile of either (a tile = 1 aux + k-steps)
+  int tsf, tsb, tkf, tkb;
 };
 struct AdamArgs {
   float *w, *m, *v;
@@ -287,6 +290,10 @@ struct AdamArgs {
   // f32 chain steps on a single rank (train_chain32.h): thread 0 turns the fixed-point batch loss into the float
   // slot(s) and clears the accumulator (the 16-bit chain leaves that to its weight-gradient kernel)
   unsigned long long* loss_acc; float* loss_out; float* loss_out2; int loss_slot;
+  // the packed stream of the fused training kernel (fused_train.h), rewritten in this pass when the step that ends here took
+  // that kernel (the next one probably will: it then needs no pack launch); nullptr otherwise.  Same element placement as
+  // pack_stream_kernel below; padding and the zero aux fragments of the activation-gradient layers are never written.
+  unsigned char* ts; int ts_bf16;
   AdamLayer lt[16];
 };
 // The layer an arena element belongs to: every block of 256 consecutive elements lies in ONE layer except the few
@@ -326,10 +333,23 @@ __device__ __forceinline__ float adam_update_element(const AdamArgs& a, long lon
   }
   return wi;
 }
+// 16-bit element e of lane `lane` of fragment `frag` of the fused_train.h stream
+__device__ __forceinline__ void ts_store(const AdamArgs& a, long long frag, int lane, int e, float v) {
+  unsigned char* p = a.ts + ((frag * 64 + lane) << 4) + 2 * e;
+  if (a.ts_bf16) *reinterpret_cast<__bf16*>(p) = (__bf16)v;
+  else *reinterpret_cast<_Float16*>(p) = (_Float16)v;
+}
 __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long i, float alpha, const AdamLayer& L) {
   const float wi = adam_update_element(a, i, alpha);
   if (a.no_pack) return;
   const long long r = i - L.w_off;
+  if (a.ts && r >= (long long)L.K * L.N) {
+    // a bias: element [h][reg] of the aux fragment of its forward tile (fp32: the accumulator's initial value),
+    // n = 32 nt + (reg & 3) + 8 (reg >> 2) + 4 h
+    const int n = (int)(r - (long long)L.K * L.N), m = n & 31;
+    const long long frag = L.tsf + (long long)(n >> 5) * (L.tkf + 1);
+    reinterpret_cast<float*>(a.ts + (frag << 10))[((m >> 2) & 1) * 16 + (m >> 3) * 4 + (m & 3)] = wi;
+  }
   if (r < (long long)L.K * L.N) {  // a kernel element (biases have no copies)
     int k, n;
     if ((long long)L.K * L.N < (1ll << 32)) {  // (uniform) 32-bit division: a 64-bit one is ~150 instructions
@@ -341,6 +361,13 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
     if (!a.skip_nt) {
       a.wt[L.wt_off + (long long)n * L.ldwt + k] = wi;
       a.wp[L.wp_off + (long long)k * L.ldwp + n] = wi;
+    }
+    if (a.ts) {
+      // fused_train.h (pack_stream_kernel's placement): forward tile n/32, k-step k/16: lane = 32 h + n%32 with
+      // k%16 = 8 (e >> 2) + 4 h + (e & 3); activation-gradient tile k/32, step n/16: the same with k and n exchanged
+      ts_store(a, L.tsf + (long long)(n >> 5) * (L.tkf + 1) + 1 + (k >> 4), 32 * ((k >> 2) & 1) + (n & 31), 4 * ((k >> 3) & 1) + (k & 3), wi);
+      if (L.tsb >= 0)
+        ts_store(a, L.tsb + (long long)(k >> 5) * (L.tkb + 1) + 1 + (n >> 4), 32 * ((n >> 2) & 1) + (k & 31), 4 * ((n >> 3) & 1) + (n & 3), wi);
     }
     if (a.cprec) {
       // forward fragment (tile n/32, k-step k/16): lane = 32*((k%16)/8) + n%32, element k%8

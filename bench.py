@@ -939,15 +939,20 @@ def main():
                     t16k["roofline"] = train_roofline(t16k, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
                                                       "kernel_stats_train_b16384_%s.csv" % args.precision,
                                                       "pmc_train_b16384_%s.json" % args.precision)
+                    # r4: steps of >= 16,384 rows take the fused training kernel (csrc/fused_train.h: 128 rows per workgroup,
+                    # weights through an LDS ring, activations in registers, its weight stream written by the previous step's
+                    # Adam pass); V21_FUSED_TRAIN_ROWS sets the threshold
+                    fused_route = "fused training kernel (fused_train<ArchT1, Prec%st>) + split-K weight gradients + Adam" % args.precision.upper()
+                    if args.precision in ("f16", "bf16"):
+                        t16k["route"] = fused_route
                     out["train_b16384"] = t16k
-                    # r4: steps of >= 24,576 rows take the fused training kernel (csrc/fused_train.h: 128 rows per workgroup,
-                    # weights through an LDS ring, activations in registers); V21_FUSED_TRAIN_ROWS sets the threshold
                     t32k = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier, sync_all, 32768,
                                      args.precision, max(10, args.train_steps // 4), 5)
                     t32k["roofline"] = train_roofline(t32k, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
                                                       "kernel_stats_train_b32768_%s.csv" % args.precision,
                                                       "pmc_train_b32768_%s.json" % args.precision)
-                    t32k["route"] = "fused training kernel (fused_train<ArchT1, Prec%st>) + split-K weight gradients + Adam" % args.precision.upper()
+                    if args.precision in ("f16", "bf16"):
+                        t32k["route"] = fused_route
                     out["train_b32768"] = t32k
                     out["train_variational"] = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier,
                                                          sync_all, args.train_batch, args.precision, args.train_steps, 20,

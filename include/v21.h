@@ -242,6 +242,12 @@ int v21_debug_clock_probe_read(v21_ctx* ctx, double* ghz_mean, double* ghz_min, 
  * streams (V21_ERR_STATE instead of a GPU memory fault).  This repeats that check against stream sizes the caller names
  * (bytes; negative = the real ones): the tests hand in a truncated stream.  V21_ERR_UNSUPPORTED for trainers on other paths. */
 int v21_debug_check_chain_jobs(v21_trainer* tr, long long fw_bytes, long long bw_bytes);
+/* diagnostics: which route the eager 16-bit steps of this trainer took since it was created:
+ * out[0] steps through the 32-row chain kernel (csrc/train_chain.h), out[1] steps through the fused training kernel
+ * (csrc/fused_train.h), out[2] of those that had to launch pack_stream_kernel first (the others found the kernel's
+ * weight stream already written by the previous step's Adam pass), out[3] Adam passes that wrote that stream.
+ * The tests assert on these so that "fused route == chain route" cannot pass with both taking the same kernel. */
+int v21_debug_trainer_counters(v21_trainer* tr, long long out[4]);
 /* diagnostics: s_memtime stamps of workgroup 0 of the last chain-kernel launch (train_chain.h):
  * [0] start, [1] batch gathered, [2..L+1] after forward layer l, [L+2] loss reduced,
  * [L+3..] after each backward layer (top down).  Off by default (a stamp holds its wave for ~600 cycles and the

@@ -20,13 +20,16 @@ ctx.h2d(d_x, y); ctx.h2d(d_rw, w)
 res = {}
 for name, env in (("chain", "0"), ("fused", "1")):
     os.environ["V21_FUSED_TRAIN"] = env
-    os.environ["V21_FUSED_TRAIN_ROWS"] = "1"   # (the default threshold is 24,576 rows: the probe compares the routes at any size)
+    os.environ["V21_FUSED_TRAIN_ROWS"] = "1"   # (the default threshold is 16,384 rows: the probe compares the routes at any size)
     st = native.Stack(ctx, dims, act); st.set_weights(flat)
     tr = native.Trainer(st, prec, rows); tr.set_adam(lr=1e-3)
     tr.step_dev(d_x, None, d_rw, rows, rows)
     loss = tr.last_step_loss() / rows
     g = tr.get_grad()
-    for _ in range(10): tr.step_dev(d_x, None, d_rw, rows, rows)
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < 0.3:      # (the clock needs ~50 ms of load to come up from idle)
+        for _ in range(10): tr.step_dev(d_x, None, d_rw, rows, rows)
+        ctx.sync()
     ctx.sync(); t0 = time.perf_counter()
     n = 50
     for _ in range(n): tr.step_dev(d_x, None, d_rw, rows, rows)

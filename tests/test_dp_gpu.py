@@ -37,7 +37,7 @@ def _data():
 
 def _fit(prec, seed, world=1, rank=0, sharded=False, port=0, fused=False):
     import importlib
-    if fused:  # every step through the fused training kernel (large steps take it by default: >= 24,576 rows)
+    if fused:  # every step through the fused training kernel (large steps take it by default: >= 16,384 rows)
         os.environ["V21_FUSED_TRAIN_ROWS"] = "1"
     else:
         os.environ.pop("V21_FUSED_TRAIN_ROWS", None)

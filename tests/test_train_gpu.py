@@ -254,15 +254,17 @@ FUSED_TRAIN_STACKS = [   # csrc/archs.h: the stacks with a compiled fused traini
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 @pytest.mark.parametrize("case", range(len(FUSED_TRAIN_STACKS)), ids=[c[0].split()[0] for c in FUSED_TRAIN_STACKS])
 def test_fused_training_kernel_matches_chain_route_and_oracle(ctx, case, prec, monkeypatch):
-    """Large steps of f16 / bf16 trainers (>= 24,576 rows by default) take csrc/fused_train.h: 128 rows per workgroup,
+    """Large steps of f16 / bf16 trainers (>= 16,384 rows by default) take csrc/fused_train.h: 128 rows per workgroup,
     weights through an LDS ring shared by four waves, activations, ReLU masks and the activation gradients in registers,
     forward pass + loss + activation-gradient chain as ONE unrolled virtual stack.  Forced here onto a ragged step of
-    1,000 rows (7 workgroups of 128 + one of 104; 1,000 = 62.5 groups of 16) of every stack it is compiled for: loss and
+    777 rows (6 workgroups of 128 + one of 9; 48.6 groups of 16; the last 128-row block reaches past max_batch rounded up
+    to 32 rows -- the operand buffers are sized for whole blocks since that case overwrote another tile's rows in r4) of
+    every stack it is compiled for: loss and
     FULL gradient against the 32-row chain route (the same 16-bit arithmetic in another order) and the float64 oracle, a
     second step (the packed stream is rebuilt from the arena Adam moved), targets = inputs and separate targets."""
     native, synth = pkg("_native"), pkg("synth")
     name, dims, act, ae = FUSED_TRAIN_STACKS[case]
-    n = 1000
+    n = 777
     rng = np.random.default_rng(40 + case)
     Ws, bs = ora.init_mlp(dims, seed=30 + case)
     bs = [rng.normal(scale=0.05, size=b.shape).astype(np.float32) for b in bs]
@@ -290,6 +292,10 @@ def test_fused_training_kernel_matches_chain_route_and_oracle(ctx, case, prec, m
         g1 = tr.get_grad()
         l2 = tr.run_epoch(ora.epoch_permutation(n, 3, 0), n)     # gathered through an index table, weights moved by Adam
         res[route] = (l1, g1, l2, st.get_weights())
+        rc = tr.route_counters()   # "the routes agree" must not pass with both taking the same kernel
+        assert (rc["chain"], rc["fused"]) == ((2, 0) if route == "chain" else (0, 2)), (route, rc)
+        if route == "fused":       # the first step packs the stream, the second finds it written by the first's Adam pass
+            assert rc["stream_packs"] == 1 and rc["stream_adam"] == 2, rc
     # float64 oracle: loss and gradient of the first step
     W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
     acts = [x.astype(np.float64)]
@@ -318,6 +324,50 @@ def test_fused_training_kernel_matches_chain_route_and_oracle(ctx, case, prec, m
     assert cos > 0.99999 and np.abs(gc - gf).max() <= 2e-3 * np.abs(gc).max(), (name, cos, np.abs(gc - gf).max(), np.abs(gc).max())
     dc, df = wc - flat, wf - flat
     assert float(dc @ df / (np.linalg.norm(dc) * np.linalg.norm(df))) > 0.999
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_fused_training_stream_written_by_adam_equals_the_packed_one(ctx, prec, monkeypatch):
+    """From its second consecutive step on, the fused training kernel reads a weight stream that the previous step's Adam
+    pass scattered element by element (csrc/train_kernels.h: adam_repack_element, AdamArgs::ts) instead of one rebuilt
+    by pack_stream_kernel.  After three fused steps: the fourth step's loss and FULL gradient equal those of a fresh
+    trainer handed the same weights (whose first step packs the stream from the arena) bit for bit, on a
+    ragged autoencoder step and on the direct emulator; then set_weights between fused steps invalidates the stream
+    (the next step packs again and reproduces the very first loss)."""
+    native, synth = pkg("_native"), pkg("synth")
+    monkeypatch.setenv("V21_FUSED_TRAIN_ROWS", "1")
+    for name, dims, act, ae in (FUSED_TRAIN_STACKS[0], FUSED_TRAIN_STACKS[3]):
+        n = 777
+        rng = np.random.default_rng(5)
+        Ws, bs = ora.init_mlp(dims, seed=77)
+        bs = [rng.normal(scale=0.05, size=b.shape).astype(np.float32) for b in bs]
+        flat = ora.flatten_params(Ws, bs)
+        sig = synth.make_signals(n, seed=11)
+        tgt = ora.preproc(sig, sig)
+        w = ora.relative_mse_row_weight(tgt, sig).astype(np.float32)
+        x, y = (tgt, None) if ae else (rng.uniform(-1, 1, size=(n, dims[0])).astype(np.float32), tgt)
+        st = native.Stack(ctx, dims, act); st.set_weights(flat)
+        tr = native.Trainer(st, prec, n); tr.set_adam(lr=1e-3)
+        tr.set_data(0, x, y, w)
+        l1 = tr.run_epoch(None, n)
+        for _ in range(2):
+            tr.run_epoch(None, n)
+        w3 = st.get_weights()
+        assert np.abs(w3 - flat).max() > 1e-3          # Adam moved the weights: a stale stream would show
+        l4 = tr.run_epoch(None, n); g4 = tr.get_grad()
+        rc = tr.route_counters()
+        assert rc["fused"] == 4 and rc["stream_packs"] == 1 and rc["chain"] == 0, rc
+        st2 = native.Stack(ctx, dims, act); st2.set_weights(w3)
+        tr2 = native.Trainer(st2, prec, n); tr2.set_adam(lr=1e-3)
+        tr2.set_data(0, x, y, w)
+        l4p = tr2.run_epoch(None, n); g4p = tr2.get_grad()
+        assert tr2.route_counters()["stream_packs"] == 1
+        # the same bits in the stream, the same kernels in the same order: identical results
+        assert l4 == l4p and np.array_equal(g4, g4p), (name, l4, l4p, np.abs(g4 - g4p).max(), np.abs(g4p).max())
+        st.set_weights(flat)
+        l5 = tr.run_epoch(None, n)
+        assert tr.route_counters()["stream_packs"] == 2
+        assert l5 == l1, (name, l5, l1)
 
 
 # ---- A13: variational latent layer (V21_ACT_GAUSS) -- build-side extension ----------------
