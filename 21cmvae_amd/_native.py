@@ -166,6 +166,15 @@ def precision_id(p):
         raise ValueError("unknown precision %r (use f32, f16 or bf16)" % (p,)) from None
 
 
+def _row_table(perm, n_rows, who):
+    """An epoch's row table as the C ABI takes it: int32, contiguous, one entry per row of the training set (the library
+    reads exactly that many entries from the pointer: a shorter array would be read past its end)."""
+    perm = np.ascontiguousarray(perm, dtype=np.int32)
+    if n_rows is not None and perm.shape != (n_rows,):
+        raise ValueError("%s: the row table has shape %s, the training set has %d rows" % (who, perm.shape, n_rows))
+    return perm
+
+
 def _fptr(a):
     return a.ctypes.data_as(_F)
 
@@ -510,12 +519,14 @@ class Trainer:
         check(self.lib.v21_trainer_set_data(self.h, which, _fptr(x), _fptr(y) if y is not None else None,
                                             _fptr(rw), x.shape[0]))
         self._resident[which] = key
+        if which == 0:
+            self.n_train = int(x.shape[0])
 
     def run_epoch(self, perm, batch):
         loss = C.c_double(0)
         pp = None
         if perm is not None:
-            perm = np.ascontiguousarray(perm, dtype=np.int32)
+            perm = _row_table(perm, getattr(self, "n_train", None), "Trainer.run_epoch")
             pp = perm.ctypes.data_as(C.POINTER(C.c_int32))
         with self.ctx.lock:
             check(self.lib.v21_trainer_run_epoch(self.h, pp, int(batch), C.byref(loss)))
@@ -610,7 +621,7 @@ class Joint:
         out = (C.c_double * 2)()
         pp = None
         if perm is not None:
-            perm = np.ascontiguousarray(perm, dtype=np.int32)
+            perm = _row_table(perm, getattr(self.trainers[0], "n_train", None), "Joint.run_epoch")
             pp = perm.ctypes.data_as(C.POINTER(C.c_int32))
         check(self.lib.v21_joint_run_epoch(self.h, pp, int(batch), out))
         return float(out[0]), float(out[1])
@@ -646,7 +657,7 @@ class Sweep:
         losses = (C.c_double * len(self.trainers))()
         pp = None
         if perm is not None:
-            perm = np.ascontiguousarray(perm, dtype=np.int32)
+            perm = _row_table(perm, getattr(self.trainers[0], "n_train", None), "Sweep.run_epoch")
             pp = perm.ctypes.data_as(C.POINTER(C.c_int32))
         with self.ctx.lock:
             check(self.lib.v21_sweep_run_epoch(self.h, pp, int(batch), losses))

@@ -240,7 +240,8 @@ static int launch_nt(int prec, GROUP& grp, hipStream_t st) {
     if (g.b_scale == 0.f) g.b_scale = 1.f;
     if (g.out_scale == 0.f) g.out_scale = 1.f;
     if (g.nz == 1) { g.k_chunk = g.K > 0 ? g.K : 1; g.slab_stride = 0; }
-    if (g.k_chunk > kNtMaxKPerWg) return fail(V21_ERR_UNSUPPORTED, "contraction range %d > %d per workgroup", g.k_chunk, kNtMaxKPerWg);
+    // (kNtMaxKPerWg = 512 is the range a workgroup keeps in flight at once -- the split of the weight gradient's batch
+    //  contraction aims at it; a longer range, e.g. a layer fed by 600 features, is walked in rounds by the same loop)
     grp.first[i] = blocks;
     blocks += g.nx * g.ny * g.nz;
   }
@@ -267,6 +268,9 @@ int chain_prefetchers(int ncons, int models);  // api_trainer.hip
 ChainStep chain_step(const float* x, long long ldx, const float* y, long long ldy, const float* rw, const int* d_idx, long long first, int rows, int brows, int dout, const v21_trainer* vae = nullptr, long long row0 = 0);  // api_trainer.hip
 void destroy_graphs(v21_trainer* t);  // api_trainer.hip
 void dw16_problems(v21_trainer* t, int rows, int brows, int* nslice_out, std::vector<Dw16Args>& probs, float* loss_out2 = nullptr);  // api_trainer.hip
+// every entry of an epoch's row table names a row of the training set (an entry outside it is a GPU memory fault in the
+// gather of whichever kernel takes the step: checked on the host, one pass over n ints per epoch)
+int check_row_table(const int32_t* perm, long long n);
 int ensure_copies(v21_trainer* t, bool need_nt = true);  // api_trainer.hip
 int gather_batch(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy_src, const float* rw, const int* d_idx, long long first, int rows);  // api_trainer.hip
 float grad_opscale(int brows, int dout);  // api_trainer.hip

@@ -72,6 +72,7 @@ extern "C" int v21_joint_run_epoch(v21_joint* j, const int32_t* perm, int batch,
   if (batch < 1 || (batch + R - 1) / R > ta->max_batch) return fail(V21_ERR_ARG, "per-rank batch %d not in [1, max_batch %d]", (batch + R - 1) / R, ta->max_batch);
   const int* d_idx = nullptr;
   if (perm) {
+    CHK(check_row_table(perm, n));
     if (ta->perm_cap < n) {
       if (ta->d_perm) HIPCHK(hipFree(ta->d_perm));
       HIPCHK(hipMalloc((void**)&ta->d_perm, (size_t)n * sizeof(int)));

@@ -365,6 +365,7 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
   if ((batch + R - 1) / R > t0->max_batch) return fail(V21_ERR_ARG, "per-rank batch %d exceeds max_batch %d", (batch + R - 1) / R, t0->max_batch);
   const int* d_idx = nullptr;
   if (perm) {
+    CHK(check_row_table(perm, n));
     if (t0->perm_cap < n) {
       if (t0->d_perm) HIPCHK(hipFree(t0->d_perm));
       HIPCHK(hipMalloc((void**)&t0->d_perm, (size_t)n * sizeof(int)));

@@ -1262,6 +1262,13 @@ static void after_replay(v21_trainer* t) {
   t->mlp->wpad_ok = true;
 }
 
+int check_row_table(const int32_t* perm, long long n) {
+  for (long long i = 0; i < n; ++i)
+    if (perm[i] < 0 || perm[i] >= n)
+      return fail(V21_ERR_ARG, "row table: entry %lld = %d is outside the training set's %lld rows (the table must hold one entry per row)",
+                  i, (int)perm[i], n);
+  return V21_OK;
+}
 extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int batch, double* loss) {
   if (!t || !loss) return fail(V21_ERR_ARG, "null argument");
   if (t->n[0] < 1) return fail(V21_ERR_STATE, "no training data set");
@@ -1274,6 +1281,7 @@ extern "C" int v21_trainer_run_epoch(v21_trainer* t, const int32_t* perm, int ba
   if ((batch + R - 1) / R > t->max_batch) return fail(V21_ERR_ARG, "per-rank batch %d exceeds max_batch %d", (batch + R - 1) / R, t->max_batch);
   const int* d_idx = nullptr;
   if (perm) {
+    CHK(check_row_table(perm, n));
     if (t->perm_cap < n) {
       if (t->d_perm) HIPCHK(hipFree(t->d_perm));
       HIPCHK(hipMalloc((void**)&t->d_perm, (size_t)n * sizeof(int)));

@@ -856,6 +856,25 @@ def main():
                 pc[prec + "_table_driven"] = fwd_rate(cst, cdims, prec, flags | native.FWD_FORCE_CHAIN)
             out["predict_custom"] = pc
             out["predict_custom"]["model"] = "7->[64,128]->451 (notebooks/sample_notebook.ipynb), %d rows, device-resident" % B
+            # r4: BASELINE.json's ">= 50 % MFMA on the widest hidden layer", measured on a stack that is almost nothing else
+            # (7 -> 352 x 6 -> 9: five 352 -> 352 layers = 99.1 % of its multiply-adds, 64 B of HBM traffic per row) through
+            # the same fused kernel, instantiated at run time; rocprofv3 duration and MFMA-pipe counters of this stack:
+            # profiles/<tag>/hidden_layers_352_* (scripts/hidden_layer_probe.py)
+            try:
+                hdims = [7] + [352] * 6 + [9]
+                hst = native.Stack(ctx, hdims, [1] * 6 + [0])
+                hst.set_weights(glorot(hdims, seed=6))
+                hst.jit(args.precision if args.precision != "f32" else "f16")
+                hp = fwd_rate(hst, hdims, args.precision if args.precision != "f32" else "f16", 0, n=max(10, args.steps))
+                hp["model"] = "7->[352 x 6]->9, %d rows: five 352->352 layers = 99.1 %% of the multiply-adds" % B
+                busy_h = os.path.join(ROOT, "profiles", PROFILE_TAG, "hidden_layers_352_%s_mfma_busy.json" % hp["precision"])
+                if os.path.exists(busy_h) and out["roofline"].get("clock_ghz"):
+                    per_simd = json.load(open(busy_h))["mfma_busy_cycles_per_simd"]
+                    hp["mfma_busy_cycles_per_simd"] = per_simd
+                    hp["mfma_pipe_busy_frac_at_headline_clock"] = per_simd / (hp["ms_per_launch_set"] * 1e-3 * out["roofline"]["clock_ghz"] * 1e9)
+                out["predict_hidden_352"] = hp
+            except Exception as e:
+                out["predict_hidden_352"] = {"error": "%s: %s" % (type(e).__name__, e)}
         except Exception as e:
             out["predict_generic_S1"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # host numpy -> numpy predict (PCIe-inclusive); never the headline value

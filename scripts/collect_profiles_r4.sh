@@ -61,5 +61,19 @@ $PY scripts/diag/jit_parity_probe.py > $OUT/jit_parity_probe.txt 2>&1
 $PY scripts/diag/jit_fuzz.py 40 1 > $OUT/jit_fuzz_40_random_stacks.txt 2>&1
 for n in 16384 32768; do $PY scripts/diag/fused_train_probe.py $n f16 > $OUT/fused_train_probe_b${n}_f16.txt 2>&1; done
 $PY scripts/power_probe.py > $OUT/power_probe_fused_random_vs_zero_operands.txt 2>&1
-rm -rf $OUT/bench $OUT/pmc_*/ $OUT/t*f16 $OUT/t*f32 $OUT/t32kc $OUT/tpmc_* $OUT/fwd $OUT/joint $OUT/joint32 $OUT/sweep_f16 $OUT/sweep_f32
+# 6. the widest hidden layer alone (7 -> 352 x 6 -> 9): duration by rocprofv3, MFMA-pipe counters of its 200 timed launches
+cd /tmp
+for pr in f16 bf16; do
+  $PY $ROOT/scripts/hidden_layer_probe.py $pr > $OUT/hidden_layers_352_${pr}_probe.txt 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/hid_kt_$pr -o k --output-format csv -- $PY $ROOT/scripts/hidden_layer_probe.py $pr > /dev/null 2>&1
+  cp $OUT/hid_kt_$pr/k_kernel_stats.csv $OUT/kernel_stats_hidden_layers_352_$pr.csv
+  for grp in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE"; do
+    n=$(echo $grp | cut -d" " -f1)
+    rocprofv3 --pmc $grp --kernel-trace -d $OUT/hid_pmc_${pr}_$n -o p --output-format csv -- $PY $ROOT/scripts/hidden_layer_probe.py $pr > /dev/null 2>&1
+  done
+  $PY $ROOT/scripts/pmc_timed.py fused_fwd 200 0 $OUT/hid_pmc_${pr}_SQ_INSTS_MFMA/p_counter_collection.csv $OUT/hid_pmc_${pr}_GRBM_GUI_ACTIVE/p_counter_collection.csv > $OUT/hidden_layers_352_${pr}_mfma_busy.json
+done
+cd $ROOT
+echo "hidden layers done"
+rm -rf $OUT/bench $OUT/hid_kt_* $OUT/hid_pmc_* $OUT/pmc_*/ $OUT/t*f16 $OUT/t*f32 $OUT/t32kc $OUT/tpmc_* $OUT/fwd $OUT/joint $OUT/joint32 $OUT/sweep_f16 $OUT/sweep_f32
 ls -la $OUT

@@ -189,6 +189,58 @@ def test_trainer_argument_errors(ctx):
     for prec in ("f32", "f16"):  # an output non-linearity would not be differentiated: refused, not mis-trained
         with pytest.raises(native.EngineError, match="output layer"):
             native.Trainer(native.Stack(ctx, [7, 8, 3], [1, 1]), prec, 16)
+    # the epoch's row table: one entry per row of the training set, every entry a row of it -- a short table would be read
+    # past its end and a wrong entry is a GPU memory fault in the gather (r4: checked by the binding AND by the library)
+    with pytest.raises(ValueError, match="row table"):
+        tr.run_epoch(np.arange(8, dtype=np.int32), 8)
+    import ctypes as C
+    bad = np.arange(20, dtype=np.int32); bad[7] = 20
+    loss = C.c_double(0)
+    rc = tr.lib.v21_trainer_run_epoch(tr.h, bad.ctypes.data_as(C.POINTER(C.c_int32)), 8, C.byref(loss))
+    assert rc != 0 and b"entry 7 = 20" in tr.lib.v21_last_error()
+    bad[7] = -1
+    assert tr.lib.v21_trainer_run_epoch(tr.h, bad.ctypes.data_as(C.POINTER(C.c_int32)), 8, C.byref(loss)) != 0
+    assert np.isfinite(tr.run_epoch(np.arange(20, dtype=np.int32)[::-1].copy(), 8))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_layers_wider_than_512_train_on_the_per_layer_path(ctx, prec):
+    """`hidden_dims` is free in the reference (emulator.py:12-48).  Stacks with a layer wider than 512 have no chain kernel
+    and step through the per-layer NT kernels (csrc/gemm_nt.h); until r4 its launcher REFUSED a contraction over more than
+    512 features (V21_ERR_UNSUPPORTED: such a stack could predict but not train) although the kernel walks any range in
+    rounds.  First-step loss and full gradient against the float64 oracle, then the loss falls."""
+    native = pkg("_native")
+    dims, act = [7, 600, 520, 33], [1, 1, 0]
+    n = 300
+    rng = np.random.default_rng(3)
+    Ws, bs = ora.init_mlp(dims, seed=8)
+    bs = [rng.normal(scale=0.05, size=b.shape).astype(np.float32) for b in bs]
+    x = rng.uniform(-1, 1, size=(n, 7)).astype(np.float32)
+    y = rng.normal(size=(n, 33)).astype(np.float32)
+    w = ora.mse_row_weight(y).astype(np.float32)
+    st = native.Stack(ctx, dims, act); st.set_weights(ora.flatten_params(Ws, bs))
+    tr = native.Trainer(st, prec, n); tr.set_adam(lr=1e-3)
+    tr.set_data(0, x, y, w)
+    l1 = tr.run_epoch(None, n); g = tr.get_grad()
+    acts = [x.astype(np.float64)]
+    for W_, b_, a_ in zip(Ws, bs, act):
+        z = acts[-1] @ W_.astype(np.float64) + b_.astype(np.float64)
+        acts.append(np.maximum(z, 0) if a_ else z)
+    lo, dz = ora.batch_loss_and_grad(acts[-1], y.astype(np.float64), w.astype(np.float64))
+    dWs, dbs = [None] * 3, [None] * 3
+    for li in range(2, -1, -1):
+        dWs[li] = acts[li].T @ dz; dbs[li] = dz.sum(0)
+        dh = dz @ Ws[li].astype(np.float64).T
+        dz = dh * (acts[li] > 0) if li > 0 and act[li - 1] else dh
+    go = ora.flatten_params(dWs, dbs)
+    tol = 2e-5 if prec == "f32" else 3e-3
+    assert abs(l1 - lo) <= tol * lo, (l1, lo)
+    if prec == "f32":
+        _close(g, go, 2e-5, "gradient of a 600-wide stack")
+    else:
+        assert float(g @ go / (np.linalg.norm(g) * np.linalg.norm(go))) > 0.9995
+    losses = [tr.run_epoch(None, 100) for _ in range(10)]
+    assert losses[-1] < 0.9 * l1, (l1, losses)
 
 
 def test_rccl_single_rank_communicator_is_identity():
