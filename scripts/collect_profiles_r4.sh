@@ -61,6 +61,12 @@ $PY scripts/diag/jit_parity_probe.py > $OUT/jit_parity_probe.txt 2>&1
 $PY scripts/diag/jit_fuzz.py 40 1 > $OUT/jit_fuzz_40_random_stacks.txt 2>&1
 for n in 16384 32768; do $PY scripts/diag/fused_train_probe.py $n f16 > $OUT/fused_train_probe_b${n}_f16.txt 2>&1; done
 $PY scripts/power_probe.py > $OUT/power_probe_fused_random_vs_zero_operands.txt 2>&1
+# 5b. the round's fuzzers (random cases against the float64 oracle and a bitwise twin; every line ends in OK / BAD / refused)
+$PY scripts/diag/train_fuzz.py 150 11 > $OUT/train_fuzz_150_cases.txt 2>&1
+FUZZ_BIG=1 $PY scripts/diag/train_fuzz.py 20 12 > $OUT/train_fuzz_large_steps_20_cases.txt 2>&1
+$PY scripts/diag/forward_fuzz.py 100 13 > $OUT/forward_fuzz_100_cases.txt 2>&1
+$PY scripts/diag/sweep_fuzz.py 60 14 > $OUT/sweep_fuzz_60_cases.txt 2>&1
+echo "fuzzers done"
 # 6. the widest hidden layer alone (7 -> 352 x 6 -> 9): duration by rocprofv3, MFMA-pipe counters of its 200 timed launches
 cd /tmp
 for pr in f16 bf16; do

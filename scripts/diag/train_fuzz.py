@@ -16,6 +16,9 @@ FAMILIES = [([451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0]), ([7, 352, 352, 352, 
             ([7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0]), ([7, 352, 352, 352, 224, 451], [1, 1, 1, 1, 0])]
 WIDTHS = [1, 7, 9, 16, 17, 31, 32, 33, 64, 65, 100, 128, 224, 288, 352, 400, 451, 512, 600]
 ROWS = [1, 2, 15, 16, 17, 31, 33, 100, 129, 255, 256, 257, 777, 1000, 2047, 2049, 4096, 4100, 8191, 8200, 9000]
+BIG = os.environ.get("FUZZ_BIG") == "1"       # large steps of the reference stacks on the library's own route choice
+if BIG:
+    ROWS = [12288, 16383, 16384, 16385, 20000, 24577, 32768, 40001]
 bad = 0
 
 
@@ -36,7 +39,7 @@ def oracle_step(Ws, bs, act, x, tgt, w):
 
 
 for c in range(cases):
-    if rng.random() < 0.5:
+    if BIG or rng.random() < 0.5:
         dims, act = FAMILIES[int(rng.integers(0, 4))]
     else:
         L = int(rng.integers(1, 6))
@@ -49,6 +52,9 @@ for c in range(cases):
     max_batch = rows + int(rng.choice([0, 0, 5, 100]))
     fused_env = str(int(rng.choice([1, 1000000])))
     os.environ["V21_FUSED_TRAIN_ROWS"] = fused_env
+    if BIG:
+        fused_env = "default"
+        os.environ.pop("V21_FUSED_TRAIN_ROWS", None)
     perm = rng.permutation(n).astype(np.int32) if rng.random() < 0.5 else None
     ae = dims[0] == dims[-1] and rng.random() < 0.7
     Ws, bs = ora.init_mlp(dims, seed=c)
