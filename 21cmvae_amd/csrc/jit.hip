@@ -120,17 +120,28 @@ void mkdirs(const std::string& d) {
   for (size_t i = 1; i <= d.size(); ++i)
     if (i == d.size() || d[i] == '/') mkdir(d.substr(0, i).c_str(), 0755);
 }
-// $V21_KERNEL_CACHE, else ~/.cache/21cmvae_amd/kernels, else (no home directory, or one that cannot be written: a
-// container running as another user) a per-user directory under /tmp
+// A directory whose code objects this process will LOAD AND RUN must be the user's own and closed to others: a
+// world-writable or foreign directory (somebody else created /tmp/21cmvae_amd_kernels_<uid> first) would let another
+// local user plant GPU code.  lstat, not stat: a symbolic link in that place is refused as well.
+bool private_dir(const std::string& d) {
+  struct stat sb;
+  if (lstat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) return false;
+  return sb.st_uid == getuid() && (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0 && access(d.c_str(), W_OK | X_OK) == 0;
+}
+// $V21_KERNEL_CACHE (the caller's word is taken for it), else ~/.cache/21cmvae_amd/kernels, else (no home directory, or one
+// that cannot be written: a container running as another user) a per-user directory under /tmp created 0700; "" when
+// neither is the user's own private directory -- kernels are then compiled per process and nothing is cached on disk
 std::string user_cache_dir() {
   if (const char* e = getenv("V21_KERNEL_CACHE")) return e;
   const char* home = getenv("HOME");
   if (home && *home) {
     const std::string d = std::string(home) + "/.cache/21cmvae_amd/kernels";
     mkdirs(d);
-    if (access(d.c_str(), W_OK | X_OK) == 0) return d;
+    if (private_dir(d)) return d;
   }
-  return "/tmp/21cmvae_amd_kernels_" + std::to_string((long)getuid());
+  const std::string t = "/tmp/21cmvae_amd_kernels_" + std::to_string((long)getuid());
+  mkdir(t.c_str(), 0700);
+  return private_dir(t) ? t : std::string();
 }
 
 constexpr char kMagic[8] = {'V', '2', '1', 'K', 'O', 'B', 'J', '1'};
@@ -309,7 +320,7 @@ JitKernel* jit_request(int L, const int* dims, const int* act, int prec) {
   fill(k, L, dims, act, prec);
   const std::string dirs[2] = {lib_dir() + "/kernel_cache", user_cache_dir()};
   for (const std::string& d : dirs)
-    if (read_cache(d + "/" + k->file, k->sym, k->code)) {
+    if (!d.empty() && read_cache(d + "/" + k->file, k->sym, k->code)) {
       k->state.store(JIT_READY);
       g_reg.all[spec] = k;
       return k;
@@ -321,6 +332,11 @@ JitKernel* jit_request(int L, const int* dims, const int* act, int prec) {
   // library, compiles into the user's cache directory and exits; the thread below only waits for it.
   k->th = std::thread([k] {
     const std::string dir = user_cache_dir(), helper = lib_dir() + "/v21_jitc";
+    if (dir.empty()) {
+      finish(k, JIT_FAILED, "no private directory for compiled kernels (neither ~/.cache/21cmvae_amd/kernels nor /tmp/21cmvae_amd_kernels_<uid> "
+                            "is this user's own, closed to others): set V21_KERNEL_CACHE");
+      return;
+    }
     mkdirs(dir);
     const std::string errfile = dir + "/" + k->file + ".err";
     std::vector<std::string> av = {helper, dir, errfile, std::to_string(k->prec), std::to_string(k->L)};
