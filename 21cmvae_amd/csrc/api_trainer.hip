@@ -694,6 +694,7 @@ static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, con
   ChainArgs a{};
   static_cast<ChainModel&>(a) = chain_model(t);
   static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, m->dims[L], nullptr, row0);
+  a.stamps = t->stamps_on ? t->d_stamps : nullptr;  // (written by diagnostic builds only: -DV21_T_STAMPS)
   a.fw = t->d_tstream; a.fw_bytes = (long long)t->tstream_padded * 1024;
   HIPCHK(g_train[t->train_arch].fn[t->prec == V21_PREC_F16 ? 0 : 1](a, st));
   return V21_OK;

@@ -29,8 +29,16 @@
 namespace v21 {
 
 // one workgroup per CU, one column tile per wave, refill spread over the block being consumed
-struct PrecF16t : PrecF16 { static constexpr int CT = 1, BLK = 24, RING = 4, WPS = 1; static constexpr bool SPREAD_DMA = true; };
-struct PrecBF16t : PrecBF16 { static constexpr int CT = 1, BLK = 24, RING = 4, WPS = 1; static constexpr bool SPREAD_DMA = true; };
+#ifndef V21_TRAIN_DEPTH
+#define V21_TRAIN_DEPTH 2   // LDS read-ahead of the source, in fragments (the compiler sinks the reads to ONE fragment ahead whatever this says: fused_train.h notes, DESIGN K3-fused)
+#endif
+struct PrecF16t : PrecF16 { static constexpr int CT = 1, BLK = 24, RING = 4, WPS = 1, DEPTH = V21_TRAIN_DEPTH; static constexpr bool SPREAD_DMA = true; };
+struct PrecBF16t : PrecBF16 { static constexpr int CT = 1, BLK = 24, RING = 4, WPS = 1, DEPTH = V21_TRAIN_DEPTH; static constexpr bool SPREAD_DMA = true; };
+#ifdef V21_T_STAMPS  // diagnostic build (scripts/diag/fused_train_stamps.py): s_memtime of wave 0 of physical workgroup 0 at the start of every virtual layer
+#define TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); a.stamps[(i)] = t_; } } while (0)
+#else
+#define TSTAMP(i)
+#endif
 constexpr int kTrainStagePitch = 40;                                    // halfs per staged row (80 B: 8-byte aligned, rows 20 banks apart)
 constexpr int kTrainStageBytes = 4 * 32 * kTrainStagePitch * 2;         // four waves
 constexpr int kTrainMaskTiles = 48;                                     // ReLU mask tiles of a stack (16 bits per lane and tile, kept in LDS)
@@ -148,6 +156,7 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
   const int r = lane & 31, h = lane >> 5;
   // XCD-major row blocks, as train_chain_kernel: XCD x carries a contiguous eighth of the batch, where the slices of
   // gemm_dw16_lds_kernel will look for it
+  TSTAMP(0);
   const int nrb = (a.rows + kTrainRowsPerWg - 1) / kTrainRowsPerWg;
   const int rb = (int)(blockIdx.x & 7) * ((nrb + 7) >> 3) + (int)(blockIdx.x >> 3);
   if (rb >= nrb) return;
@@ -252,6 +261,10 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
     });
   }
 
+  TSTAMP(1);
+#ifdef V21_T_STAMPS
+  unsigned long long ring_wait_cycles = 0;
+#endif
   // ---- ring prologue
   static_for<kRing>([&](auto b) __attribute__((always_inline)) { issue_block<G, decltype(b)::value>((const unsigned char*)a.fw, smem, wave, lane); });
 
@@ -377,7 +390,15 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
         constexpr int SA = SCH::ops_before(S) - SCH::ops_before(S_issue);
 #endif
         constexpr int N = (GA + SA) > 63 ? 63 : (GA + SA);
+#ifdef V21_T_STAMPS  // cycles this wave spends at the ring's rendezvous (counted wait + barrier), summed over the kernel
+        unsigned long long tb0_, tb1_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0_)::"memory");
         wait_vmcnt_barrier<N>();
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1_)::"memory");
+        ring_wait_cycles += tb1_ - tb0_;
+#else
+        wait_vmcnt_barrier<N>();
+#endif
       }
       if constexpr (SPREAD && S / kBlkFrags >= 2) {
         constexpr int Bc = S / kBlkFrags, o = S % kBlkFrags;
@@ -430,6 +451,7 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
       if constexpr (it.ks >= 0) {
         constexpr int GT = G::gtile(it.l, it.nt);
         constexpr int GP = GT > 0 ? GT - 1 : 0;
+        if constexpr (it.ks == 0 && it.nt == 0) TSTAMP(2 + it.l);
         constexpr int CPK = G::chunks_per_kstep(GP, NCH);
         constexpr bool whole_first = (GT > 0) && (G::spread_limit(GP) == 0);
         if constexpr (whole_first && it.ks == 0) {
@@ -465,6 +487,10 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
   tile_flush_s(std::integral_constant<int, G::n_tiles() - 1>{});
 #endif
 
+  TSTAMP(2 + 2 * LR - 1);
+#ifdef V21_T_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.stamps) a.stamps[30] = ring_wait_cycles;
+#endif
   // ---- batch loss: this wave's rows as 2^-32 fixed point (an integer sum does not depend on the order of arrival)
   float s = lsum * wi;
 #pragma unroll
