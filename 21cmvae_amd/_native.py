@@ -179,6 +179,44 @@ def _fptr(a):
     return a.ctypes.data_as(_F)
 
 
+class _Owned:
+    """A C handle that must outlive the handles built on it (a Stack its Trainers, a Trainer the Joint / Sweep it is
+    part of).  Python gives no such order: when a script ends, everything reachable from its module namespace is one
+    unreachable cycle (every function defined there refers to it) and the collector calls the finalizers of such a set
+    in ANY order -- a Trainer destroyed before its Joint was a use-after-free in v21_joint_destroy (r4: found by
+    scripts/diag/joint_fuzz.py as a segmentation fault at interpreter exit).  So the wrappers count: finalizing a
+    wrapper only marks it; its handle is destroyed once nothing built on it is left, children first."""
+
+    def _own(self, destroy, parents=()):
+        self._destroy, self._parents, self._children, self._finalized = destroy, list(parents), 0, False
+        for p in self._parents:
+            p._children += 1
+
+    def _release(self):
+        self._finalized = True
+        self._try_destroy()
+
+    def _try_destroy(self):
+        if not self._finalized or self._children > 0 or not getattr(self, "h", None):
+            return
+        h, self.h = self.h, None
+        try:
+            self._destroy(h)
+        except Exception:
+            pass
+        parents, self._parents = self._parents, []
+        for p in parents:
+            p._children -= 1
+            p._try_destroy()
+
+    def __del__(self):
+        try:
+            if hasattr(self, "_finalized"):
+                self._release()
+        except Exception:
+            pass
+
+
 class Context:
     """One per device.  Owns a HIP stream; calls on one context are serialised."""
     _default = {}
@@ -368,7 +406,7 @@ class Context:
         check(self.lib.v21_comm_allreduce_f32(self.h, _P(dptr), n))
 
 
-class Stack:
+class Stack(_Owned):
     """A dense stack (v21_mlp): dims[0] -> ... -> dims[-1], per-layer activation."""
 
     def __init__(self, ctx, dims, act):
@@ -379,18 +417,11 @@ class Stack:
         h = _P()
         check(self.lib.v21_mlp_create(ctx.h, L, (C.c_int * (L + 1))(*self.dims), (C.c_int * L)(*self.act), C.byref(h)))
         self.h = h
+        self._own(self.lib.v21_mlp_destroy)
         n = C.c_size_t(0)
         check(self.lib.v21_mlp_num_params(h, C.byref(n)))
         self.num_params = n.value
         self._mean_keep = None
-
-    def __del__(self):
-        try:
-            if getattr(self, "h", None):
-                self.lib.v21_mlp_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass
 
     def set_weights(self, flat):
         flat = np.ascontiguousarray(flat, dtype=np.float32).ravel()
@@ -469,7 +500,7 @@ def jit_prebuild(dims, act, precision, directory=None):
                                precision_id(precision), directory.encode() if directory else None))
 
 
-class Trainer:
+class Trainer(_Owned):
     """Adam trainer bound to a Stack (v21_trainer)."""
 
     def __init__(self, stack, precision="f32", max_batch=256):
@@ -477,15 +508,8 @@ class Trainer:
         h = _P()
         check(self.lib.v21_trainer_create(stack.h, precision_id(precision), int(max_batch), C.byref(h)))
         self.h = h
+        self._own(self.lib.v21_trainer_destroy, [stack])
         self.max_batch = int(max_batch)
-
-    def __del__(self):
-        try:
-            if getattr(self, "h", None):
-                self.lib.v21_trainer_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass
 
     def set_adam(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
         cfg = Adam(lr, beta1, beta2, eps)
@@ -598,7 +622,7 @@ class Trainer:
         return g
 
 
-class Joint:
+class Joint(_Owned):
     """Autoencoder + latent emulator stepping together on the same rows (v21_joint_*; BASELINE configs[2])."""
 
     def __init__(self, ae_trainer, em_trainer, latent_layer):
@@ -607,14 +631,7 @@ class Joint:
         h = _P()
         check(self.lib.v21_joint_create(ae_trainer.h, em_trainer.h, int(latent_layer), C.byref(h)))
         self.h = h
-
-    def __del__(self):
-        try:
-            if getattr(self, "h", None):
-                self.lib.v21_joint_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass
+        self._own(self.lib.v21_joint_destroy, self.trainers)
 
     def run_epoch(self, perm, batch):
         """-> (autoencoder epoch loss, emulator epoch loss)"""
@@ -633,7 +650,7 @@ class Joint:
         return float(out[0]), float(out[1])
 
 
-class Sweep:
+class Sweep(_Owned):
     """Several Trainers stepped in lock step on one shared batch stream (v21_sweep);
     trainer 0 holds the training set."""
 
@@ -644,14 +661,7 @@ class Sweep:
         h = _P()
         check(self.lib.v21_sweep_create(arr, len(self.trainers), C.byref(h)))
         self.h = h
-
-    def __del__(self):
-        try:
-            if getattr(self, "h", None):
-                self.lib.v21_sweep_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass
+        self._own(self.lib.v21_sweep_destroy, self.trainers)
 
     def run_epoch(self, perm, batch):
         losses = (C.c_double * len(self.trainers))()

@@ -12,6 +12,7 @@
 // ---------------------------------------------------------------------------------
 struct v21_joint {
   v21_trainer *ae = nullptr, *em = nullptr;
+  v21_ctx* ctx = nullptr;  // (kept: destroying the joint object must not look into trainers that may already be gone)
   int latent_layer = 0;
   ChainModel* d_tab = nullptr;
   std::vector<ChainModel> h_tab;
@@ -41,7 +42,7 @@ extern "C" int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_lay
   if (ma->dims[0] != ma->dims[ma->L]) return fail(V21_ERR_ARG, "the first trainer must be an autoencoder (in == out width)");
   CHK(use(ae->ctx));
   v21_joint* j = new v21_joint();
-  j->ae = ae; j->em = em; j->latent_layer = latent_layer; j->f32 = f32;
+  j->ae = ae; j->em = em; j->ctx = ae->ctx; j->latent_layer = latent_layer; j->f32 = f32;
   hipError_t e = hipMalloc((void**)&j->d_tab, 2 * sizeof(ChainModel));
   if (e != hipSuccess) { delete j; return fail(V21_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
   *out = j;
@@ -49,8 +50,8 @@ extern "C" int v21_joint_create(v21_trainer* ae, v21_trainer* em, int latent_lay
 }
 extern "C" int v21_joint_destroy(v21_joint* j) {
   if (!j) return V21_OK;
-  hipSetDevice(j->ae->ctx->device);
-  hipStreamSynchronize(j->ae->ctx->stream);
+  hipSetDevice(j->ctx->device);
+  hipStreamSynchronize(j->ctx->stream);
   hipFree(j->d_tab);
   if (j->d_dwadam) hipFree(j->d_dwadam);
   if (j->d_dw32) hipFree(j->d_dw32);

@@ -204,3 +204,38 @@ def test_fit_shuffle_stream_is_the_sequential_one_despite_the_look_ahead(monkeyp
         _fit_with_fake_trainer(eng, monkeypatch, 5, fail_at=1, seed=8)
     ref.permutation(50); ref.permutation(50)  # two epochs began, two permutations were consumed
     assert eng._rng.bit_generator.state == ref.bit_generator.state
+
+
+def test_native_handles_are_destroyed_children_first_whatever_order_python_finalizes_them():
+    """`_native._Owned`: a Stack outlives its Trainers, a Trainer the Joint / Sweep built on it.  At interpreter exit the
+    collector finalizes a script's objects in any order (they hang in one cycle through the module namespace); a Trainer
+    destroyed before its Joint was a use-after-free in the library (r4: segmentation fault at exit, found by
+    scripts/diag/joint_fuzz.py).  No GPU: the destroy callbacks only record their order."""
+    native = pkg("_native")
+    order = []
+
+    class H(native._Owned):
+        def __init__(self, name, parents=()):
+            self.h, self.name = name, name
+            self._own(lambda h: order.append(h), parents)
+
+    for finalize in (["stack", "ae", "em", "joint"], ["joint", "em", "ae", "stack"], ["ae", "stack", "joint", "em"]):
+        order.clear()
+        stack = H("stack")
+        ae, em = H("ae", [stack]), H("em", [stack])
+        joint = H("joint", [ae, em])
+        objs = {"stack": stack, "ae": ae, "em": em, "joint": joint}
+        for name in finalize:
+            objs[name].__del__()          # what the collector does, in this order
+        assert sorted(order) == ["ae", "em", "joint", "stack"], order
+        assert order[0] == "joint" and order[-1] == "stack", (finalize, order)
+        for o in objs.values():
+            o.__del__()                   # a second finalization (resurrection, explicit call) destroys nothing twice
+        assert len(order) == 4
+    # a handle that is still in use is kept: the stack lives while one trainer does
+    order.clear()
+    stack = H("stack"); t1, t2 = H("t1", [stack]), H("t2", [stack])
+    stack.__del__(); t1.__del__()
+    assert order == ["t1"]
+    t2.__del__()
+    assert order == ["t1", "t2", "stack"]

@@ -5,6 +5,8 @@ Tolerances: the device sums in a different order from numpy (and in f32), so f32
 is compared with the float64 oracle at rtol 2e-4 on gradients / 1e-4 on weights after a
 few steps (relative to the tensor's scale); f16/bf16 operand modes are checked on the
 gradient direction (cosine) and on the loss trajectory."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1384,3 +1386,40 @@ def test_autoencoder_emulator_joint_training_through_the_class_surface(ctx, prec
     with pytest.raises(ValueError):   # the emulator's loss must not depend on the targets
         ae.emulator.compile(optimizer=optm.Adam(1e-3), loss=emu.relative_mse_loss(ae.signal_train))
         ae.train(epochs=1, verbose=0, joint=True)
+
+
+def test_a_script_that_ends_with_live_joint_sweep_and_trainers_exits_cleanly(tmp_path):
+    """Objects left in a script's namespace are finalized in arbitrary order at interpreter exit (r4: a Trainer freed before
+    the Joint built on it crashed the process AFTER its last line).  A fresh interpreter builds trainers, a joint object and
+    a sweep at module level next to a function (the cycle through the module namespace), steps them, and must leave with
+    status 0."""
+    import subprocess, sys, textwrap
+    script = tmp_path / "leave_objects_behind.py"
+    script.write_text(textwrap.dedent('''
+        import importlib, os, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        native = importlib.import_module("21cmvae_amd._native")
+        ctx = native.Context.default()
+        def make(dims, act, n=64):
+            st = native.Stack(ctx, dims, act)
+            st.set_weights((np.random.default_rng(0).normal(size=st.num_params) * 0.05).astype(np.float32))
+            tr = native.Trainer(st, "f16", n); tr.set_adam(lr=1e-3)
+            return st, tr
+        x = np.random.default_rng(1).uniform(-1, 1, size=(64, 33)).astype(np.float32)
+        p = np.random.default_rng(2).uniform(-1, 1, size=(64, 7)).astype(np.float32)
+        w = np.full(64, 1.0 / 33, np.float32)
+        sa, ta = make([33, 16, 4, 16, 33], [1, 0, 1, 0]); se, te = make([7, 16, 4], [1, 0])
+        ta.set_data(0, x, None, w); te.set_data(0, p, np.zeros((64, 4), np.float32), np.full(64, 0.25, np.float32))
+        joint = native.Joint(ta, te, latent_layer=1)
+        print(joint.run_epoch(None, 32))
+        members = [make([33, 8 + k, 33], [1, 0]) for k in range(3)]
+        members[0][1].set_data(0, x, None, w)
+        sweep = native.Sweep([m[1] for m in members])
+        print(sweep.run_epoch(None, 32))
+        keep = [joint, sweep, members, sa, se]       # and a cycle of our own
+        keep.append(keep)
+    ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    for _ in range(3):   # (the order depends on addresses: a few tries)
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
