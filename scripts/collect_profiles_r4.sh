@@ -67,6 +67,7 @@ FUZZ_BIG=1 $PY scripts/diag/train_fuzz.py 20 12 > $OUT/train_fuzz_large_steps_20
 $PY scripts/diag/forward_fuzz.py 100 13 > $OUT/forward_fuzz_100_cases.txt 2>&1
 $PY scripts/diag/sweep_fuzz.py 60 14 > $OUT/sweep_fuzz_60_cases.txt 2>&1
 $PY scripts/diag/joint_fuzz.py 80 15 > $OUT/joint_fuzz_80_cases.txt 2>&1
+$PY scripts/diag/surface_fuzz.py 40 16 > $OUT/class_surface_fuzz_40_cases.txt 2>&1
 echo "fuzzers done"
 # 6. the widest hidden layer alone (7 -> 352 x 6 -> 9): duration by rocprofv3, MFMA-pipe counters of its 200 timed launches
 cd /tmp
