@@ -68,7 +68,7 @@ $PY scripts/diag/forward_fuzz.py 100 13 > $OUT/forward_fuzz_100_cases.txt 2>&1
 $PY scripts/diag/sweep_fuzz.py 60 14 > $OUT/sweep_fuzz_60_cases.txt 2>&1
 $PY scripts/diag/joint_fuzz.py 80 15 > $OUT/joint_fuzz_80_cases.txt 2>&1
 $PY scripts/diag/surface_fuzz.py 40 16 > $OUT/class_surface_fuzz_40_cases.txt 2>&1
-$PY scripts/diag/dp_fuzz.py 12 17 > $OUT/dp_fuzz_12_cases_2_to_4_ranks_on_one_gpu.txt 2>&1
+$PY scripts/diag/dp_fuzz.py 36 2 > $OUT/dp_fuzz_36_cases_2_to_4_ranks_on_one_gpu.txt 2>&1
 echo "fuzzers done"
 # 6. the widest hidden layer alone (7 -> 352 x 6 -> 9): duration by rocprofv3, MFMA-pipe counters of its 200 timed launches
 cd /tmp
