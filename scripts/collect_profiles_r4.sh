@@ -84,5 +84,14 @@ for pr in f16 bf16; do
 done
 cd $ROOT
 echo "hidden layers done"
+# 7. where a workgroup of the fused training kernel spends its cycles (diagnostic build `make -C 21cmvae_amd/csrc tstamp`, if present), and
+# the one-wave-per-SIMD microbenchmarks DESIGN.md section 3 K3-fused quotes (compiled here: hipcc is on the box)
+if [ -f $ROOT/21cmvae_amd/libv21_tstamp.so ]; then
+  for n in 16384 32768; do V21_LIB=$ROOT/21cmvae_amd/libv21_tstamp.so $PY scripts/diag/fused_train_stamps.py $n > $OUT/fused_train_layer_stamps_b${n}_f16.txt 2>&1; done
+fi
+for pb in mfma_chain_probe lds_read_probe mfma_issue_probe; do
+  hipcc -std=c++20 --offload-arch=gfx950 -O3 -o /tmp/$pb scripts/diag/$pb.hip > /dev/null 2>&1 && timeout -k 5 120 /tmp/$pb > $OUT/microbench_$pb.txt 2>&1
+done
+echo "stamps + microbenchmarks done"
 rm -rf $OUT/bench $OUT/hid_kt_* $OUT/hid_pmc_* $OUT/pmc_*/ $OUT/t*f16 $OUT/t*f32 $OUT/t32kc $OUT/tpmc_* $OUT/fwd $OUT/joint $OUT/joint32 $OUT/sweep_f16 $OUT/sweep_f32
 ls -la $OUT
