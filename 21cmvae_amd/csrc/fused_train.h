@@ -227,6 +227,13 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
     flush_s(tile_, nfeat_, dst);
   };
 
+  // ---- ring prologue, FIRST: its pieces land while the input rows below are gathered (the rows come from HBM, 59 MB per launch
+  // at 32,768 rows, all workgroups at once: ~18 k cycles).  Everything the input phase issues is then YOUNGER than the
+  // prologue's pieces: its loads have returned by the time their data is flushed, its kInputStores buffer stores may
+  // still be on their way at the first rendezvous and are added to the waits of the prologue's blocks below.
+  static_for<kRing>([&](auto b) __attribute__((always_inline)) { issue_block<G, decltype(b)::value>((const unsigned char*)a.fw, smem, wave, lane); });
+  constexpr int kInputStores = 2 * ((TA::dims[0] + 31) / 32);
+
   // ---- layer-0 operand: the gathered rows, as 16-bit operand words; flushed as the first weight-gradient operand
   {
     constexpr int K0 = TA::dims[0];
@@ -265,9 +272,6 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
 #ifdef V21_T_STAMPS
   unsigned long long ring_wait_cycles = 0;
 #endif
-  // ---- ring prologue
-  static_for<kRing>([&](auto b) __attribute__((always_inline)) { issue_block<G, decltype(b)::value>((const unsigned char*)a.fw, smem, wave, lane); });
-
   frag q[D + 1];
   f32x16 auxb[2];  // (by tile parity: a 1- or 2-k-step tile's successor reads its aux fragment before this one's k-step 0 has run)
   f32x16 acc[2];   // by tile parity: the epilogue of tile G runs under the k-steps of tile G + 1
@@ -290,13 +294,21 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
     if constexpr (v < LR - 1) {  // forward hidden layer: activation, mask bits, next operand
       w = P::pack2(x0, x1);
       if constexpr (TA::act[v] != 0) {
-        const i16x2 z = {0, 0};
-        w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, w), z));
+        // ReLU and its mask on the PACKED pair, without the condition code: as a 16-bit integer a positive f16 / bf16 is
+        // > 0, so max(min(w, 1), 0) is 1 in the halves that pass and 0 in the others.  (A compare writes VCC and the
+        // select that reads it waits for it; with one wave per SIMD nothing covers that round trip: ~12 cycles per pair,
+        // scripts/diag/mfma_issue_probe.hip -- the single-tile layers around the latent, all epilogue, run 15-25 % faster.)
+        // The mask is that of the ROUNDED activation: a pre-activation that underflows to +0 in 16 bits passes neither
+        // value nor gradient.
+        const i16x2 z = {0, 0}, one = {1, 1};
+        const i16x2 wi = __builtin_bit_cast(i16x2, w);
+        const unsigned m01 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_elementwise_min(wi, one), z));
+        w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(wi, z));
         constexpr int mt = mask_base(v) + nt;
-        const unsigned bits = (x0 > 0.f ? 1u : 0u) | (x1 > 0.f ? 2u : 0u);
-        if constexpr (pr == 0) mcur = bits;
-        else mcur |= bits << (2 * pr);
-        if constexpr (pr == NCH - 1) mk_lds[mt * 64] = (unsigned short)mcur;
+        // bits pr (first value of the pair) and 16 + pr (second) of a 32-bit word; folded to 16 bits for the LDS slot
+        if constexpr (pr == 0) mcur = m01;
+        else mcur |= m01 << pr;
+        if constexpr (pr == NCH - 1) mk_lds[mt * 64] = (unsigned short)(mcur | (mcur >> 8));  // [first values: bits 0-7 | second values: 8-15]
       }
     } else if constexpr (v == LR - 1) {  // the loss: dL/dp = scale w_i (p - y), loss_i = w_i sum (p - y)^2
       constexpr int NO = TA::dims[LR];
@@ -323,14 +335,18 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
       w = P::pack2(gsc * d0, gsc * d1);
     } else {  // activation gradient of real layer l: dX masked by the ReLU of the layer below = dZ of that layer
       constexpr int l = 2 * LR - 1 - v;  // v = LR + j  <->  l = LR - 1 - j
+      w = P::pack2(x0, x1);
       if constexpr (TA::act[l - 1] != 0) {
         constexpr int mt = mask_base(l - 1) + nt;
-        if constexpr (pr == 0) mcur = mk_lds[mt * 64];
-        const unsigned bits = mcur >> (2 * pr);
-        x0 = (bits & 1u) ? x0 : 0.f;
-        x1 = (bits & 2u) ? x1 : 0.f;
+        if constexpr (pr == 0) {  // back to bits pr / 16 + pr
+          const unsigned m16 = mk_lds[mt * 64];
+          mcur = (m16 & 0xFFu) | ((m16 & 0xFF00u) << 8);
+        }
+        // 0xFFFF in the halves that pass: (0 / 1) * 0xFFFF as a packed 16-bit product -- again no condition code
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const u16x2 sel = __builtin_bit_cast(u16x2, (mcur >> pr) & 0x00010001u), ff = {0xFFFF, 0xFFFF};
+        w &= __builtin_bit_cast(unsigned, (u16x2)(sel * ff));
       }
-      w = P::pack2(x0, x1);
     }
     // the packed pair: word e0 / 2 of item `item` of the next virtual layer's operand (kept even where no layer
     // follows or the item lies past its contraction: the flush reads it from there)
@@ -389,7 +405,8 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
 #else
         constexpr int SA = SCH::ops_before(S) - SCH::ops_before(S_issue);
 #endif
-        constexpr int N = (GA + SA) > 63 ? 63 : (GA + SA);
+        constexpr int IN = (B < kRing) ? kInputStores : 0;  // (issued after the prologue's pieces, before everything else)
+        constexpr int N = (GA + SA + IN) > 63 ? 63 : (GA + SA + IN);
 #ifdef V21_T_STAMPS  // cycles this wave spends at the ring's rendezvous (counted wait + barrier), summed over the kernel
         unsigned long long tb0_, tb1_;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0_)::"memory");
