@@ -30,8 +30,8 @@
 #include "train_chain32.h"
 #include "train_chain32s.h"
 #include "dw_adam32.h"
-#ifdef V21_CHAIN_FINE
-constexpr int kStampSlots = 2048;  // (diagnostic build: per-wave stamps)
+#if defined(V21_CHAIN_FINE) || defined(V21_T_STAMPS)
+constexpr int kStampSlots = 2048;  // (diagnostic builds: per-wave / per-workgroup stamps)
 #else
 constexpr int kStampSlots = 64;
 #endif
@@ -189,6 +189,7 @@ struct v21_trainer {
   // large steps of f16 / bf16 trainers whose stack has a compiled fused training kernel (fused_train.h; archs.h: T1 ..):
   // index into the registry of api_trainer.hip or -1, and that kernel's packed stream (rebuilt before every launch)
   int train_arch = -1;
+  bool train16 = false;  // the fused training kernel on 16 rows per wave (fused_train16.h): the stream below is in ITS format
   unsigned char* d_tstream = nullptr;
   int tstream_total = 0, tstream_padded = 0;
   std::vector<int> ts_first;    // first fragment of every virtual layer (2 L - 1 of them)

@@ -4,15 +4,18 @@
 
 // ---- compiled fused training kernels (fused_train.h, one translation unit each: fused_train_inst.hip)
 namespace v21 {
-#define V21_TDECL(a)                                                          \
-  hipError_t launch_fused_train_##a##_F16t(const ChainArgs&, hipStream_t);   \
-  hipError_t launch_fused_train_##a##_BF16t(const ChainArgs&, hipStream_t);
+#define V21_TDECL(a)                                                             \
+  hipError_t launch_fused_train_##a##_F16t(const ChainArgs&, hipStream_t);      \
+  hipError_t launch_fused_train_##a##_BF16t(const ChainArgs&, hipStream_t);     \
+  hipError_t launch_fused_train16_##a##_F16t16(const ChainArgs&, hipStream_t);  \
+  hipError_t launch_fused_train16_##a##_BF16t16(const ChainArgs&, hipStream_t);
 V21_TRAIN_ARCH_LIST(V21_TDECL)
 #undef V21_TDECL
 }  // namespace v21
 typedef hipError_t (*train_launcher)(const ChainArgs&, hipStream_t);
-struct TrainEntry { int L; const int* dims; const int* act; train_launcher fn[2]; /* f16, bf16 */ };
-#define V21_TENTRY(a) {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_train_##a##_F16t, launch_fused_train_##a##_BF16t}},
+struct TrainEntry { int L; const int* dims; const int* act; train_launcher fn[2]; /* f16, bf16 */ train_launcher fn16[2]; /* 16 rows per wave */ };
+#define V21_TENTRY(a) {Arch##a::L, Arch##a::dims, Arch##a::act, {launch_fused_train_##a##_F16t, launch_fused_train_##a##_BF16t}, \
+                       {launch_fused_train16_##a##_F16t16, launch_fused_train16_##a##_BF16t16}},
 static const TrainEntry g_train[] = {V21_TRAIN_ARCH_LIST(V21_TENTRY)};
 #undef V21_TENTRY
 
@@ -140,12 +143,19 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
           if (same) t->train_arch = (int)e;
         }
       if (t->train_arch >= 0) {
+        // Which of the two fused training kernels this trainer's steps take is fixed here, because the packed weight stream
+        // is in the kernel's own format: 16 rows per wave (fused_train16.h: 64-row workgroups, two per CU) for trainers of
+        // fewer than 24,576 rows per step -- a step of 8,193 .. 24,575 rows does not fill the chip with 128-row workgroups --
+        // and 32 rows per wave (fused_train.h) above, where both take the same time (both at ~4.2 TB/s of HBM traffic) and
+        // the 128-row form has the evener workgroups.  V21_FUSED_TRAIN16=0 / 1 overrides.
+        const char* e16 = getenv("V21_FUSED_TRAIN16");
+        t->train16 = e16 ? e16[0] == '1' : max_batch < 24576;
         int total = 0;
         for (int v = 0; v < 2 * L - 1; ++v) {
           const int l = v < L ? v : 2 * L - 1 - v;
           const int K = v < L ? m->dims[l] : m->dims[l + 1], N = v < L ? m->dims[l + 1] : m->dims[l];
           t->ts_first.push_back(total);
-          total += ((N + 31) / 32) * ((K + 15) / 16 + 1);
+          total += t->train16 ? ((N + 15) / 16) * ((K + 31) / 32 + 1) : ((N + 31) / 32) * ((K + 15) / 16 + 1);
         }
         t->tstream_total = total;
         t->tstream_padded = (total + 7) / 8 * 8;
@@ -349,12 +359,12 @@ AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_nt) {
   if (t->chain) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->prec == V21_PREC_F16 ? 1 : 2; }
   if (t->chain32) { a.fw = t->d_fw; a.bw = t->d_bw; a.cprec = t->chain32s ? 4 : 3; }
   if (t->ts_write && t->d_tstream) {  // fused_train.h's stream from the same pass (api_trainer.hip: train_on_rows)
-    a.ts = t->d_tstream; a.ts_bf16 = t->prec == V21_PREC_BF16;
-    const int L = m->L;
+    a.ts = t->d_tstream; a.ts_bf16 = t->prec == V21_PREC_BF16; a.ts_fmt16 = t->train16 ? 1 : 0;
+    const int L = m->L, kstep = t->train16 ? 32 : 16;
     for (int l = 0; l < L; ++l) {
       AdamLayer& al = a.lt[l];
-      al.tsf = t->ts_first[l]; al.tkf = (m->dims[l] + 15) / 16;
-      al.tsb = l >= 1 ? t->ts_first[2 * L - 1 - l] : -1; al.tkb = (m->dims[l + 1] + 15) / 16;
+      al.tsf = t->ts_first[l]; al.tkf = (m->dims[l] + kstep - 1) / kstep;
+      al.tsb = l >= 1 ? t->ts_first[2 * L - 1 - l] : -1; al.tkb = (m->dims[l + 1] + kstep - 1) / kstep;
     }
   }
   a.skip_nt = (skip_nt && (t->chain || t->chain32)) ? 1 : 0;
@@ -676,13 +686,14 @@ static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, con
   PackArgs pa{};
   pa.w = m->d_w; pa.mean = nullptr; pa.stream = t->d_tstream;
   pa.L = 2 * L - 1; pa.total = t->tstream_total; pa.padded = t->tstream_padded;
-  pa.fpi = 16; pa.epi = 8; pa.esize = 2; pa.is_bf16 = t->prec == V21_PREC_BF16; pa.all_hidden = 1;
+  pa.fpi = 16; pa.epi = 8; pa.esize = 2; pa.is_bf16 = t->prec == V21_PREC_BF16; pa.all_hidden = 1; pa.fmt16 = t->train16 ? 1 : 0;
   int f = 0;
   for (int v = 0; v < 2 * L - 1; ++v) {
     const int l = v < L ? v : 2 * L - 1 - v;
     PackLayer& pl = pa.lt[v];
     pl.K = v < L ? m->dims[l] : m->dims[l + 1]; pl.N = v < L ? m->dims[l + 1] : m->dims[l];
-    pl.ks = (pl.K + 15) / 16; pl.nt = (pl.N + 31) / 32;
+    if (t->train16) { pl.ks = (pl.K + 31) / 32; pl.nt = (pl.N + 15) / 16; }
+    else { pl.ks = (pl.K + 15) / 16; pl.nt = (pl.N + 31) / 32; }
     pl.w_off = m->w_off[l]; pl.b_off = m->b_off[l];
     pl.flags = v < L ? 0 : 3;  // activation-gradient layer: transposed weights, no bias
     pl.first = f;
@@ -696,7 +707,8 @@ static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, con
   static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, m->dims[L], nullptr, row0);
   a.stamps = t->stamps_on ? t->d_stamps : nullptr;  // (written by diagnostic builds only: -DV21_T_STAMPS)
   a.fw = t->d_tstream; a.fw_bytes = (long long)t->tstream_padded * 1024;
-  HIPCHK(g_train[t->train_arch].fn[t->prec == V21_PREC_F16 ? 0 : 1](a, st));
+  if (t->train16) HIPCHK(g_train[t->train_arch].fn16[t->prec == V21_PREC_F16 ? 0 : 1](a, st));
+  else HIPCHK(g_train[t->train_arch].fn[t->prec == V21_PREC_F16 ? 0 : 1](a, st));
   return V21_OK;
 }
 static int launch_chain(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
@@ -1103,14 +1115,15 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   if (rows > 0) {
     const bool ts_fresh = t->tstream_fresh && t->copies_ok && t->mlp->wpad_ok;  // (read before ensure_copies clears it)
     CHK(ensure_copies(t, false));
-    // steps of >= V21_FUSED_TRAIN_ROWS rows (default 16,384) of a stack with a compiled fused training kernel: 128 rows per
-    // workgroup, weights through an LDS ring, activations in registers (fused_train.h); below, the 32-row chain.  The
-    // kernel's weight stream is written by the previous step's Adam pass (AdamArgs::ts), so a step is 3 launches
-    // (measured r4, autoencoder stack, f16, whole step, fused against chain: 9,216-14,336 rows 76-82 against 77-83 us,
-    //  a tie; 16,384 rows 90 against 96-100; 20,480 rows 103 against 125; 24,576 rows 114 against 137; 32,768 rows
-    //  139-147 against 171-180; read per step: tests force it)
+    // steps of >= V21_FUSED_TRAIN_ROWS rows of a stack with a compiled fused training kernel take it; below, the 32-row chain.
+    // Default: 8,193 rows for a trainer on the 16-rows-per-wave kernel (fused_train16.h; max_batch < 24,576: the chain's
+    // second round of 256 workgroups starts there -- 9,216 rows 67 against 80 us, 10,240 rows 69 against 81, 12,288 rows 72
+    // against 83, 16,384 rows 78-82 against 90-92, 20,480 rows 94 against 119), 16,384 rows for one on the 128-row kernel
+    // (fused_train.h: 24,576 rows 101 against 127, 32,768 rows 123-130 against 152-160).  The kernel's weight stream is
+    // written by the previous step's Adam pass (AdamArgs::ts), so a step is 3 launches.  (Autoencoder stack, f16, whole
+    // steps, r4; read per step: the tests force it.)
     const char* efr = getenv("V21_FUSED_TRAIN_ROWS");
-    const int fused_rows = efr ? atoi(efr) : 16384;
+    const int fused_rows = efr ? atoi(efr) : (t->train16 ? 8193 : 16384);
     const bool fused = t->train_arch >= 0 && rows >= fused_rows && !t->capturing;
     fused_step = fused;
     if (fused) CHK(launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, ts_fresh));

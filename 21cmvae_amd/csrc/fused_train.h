@@ -36,8 +36,12 @@ struct PrecF16t : PrecF16 { static constexpr int CT = 1, BLK = 24, RING = 4, WPS
 struct PrecBF16t : PrecBF16 { static constexpr int CT = 1, BLK = 24, RING = 4, WPS = 1, DEPTH = V21_TRAIN_DEPTH; static constexpr bool SPREAD_DMA = true; };
 #ifdef V21_T_STAMPS  // diagnostic build (scripts/diag/fused_train_stamps.py): s_memtime of wave 0 of physical workgroup 0 at the start of every virtual layer
 #define TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && a.stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); a.stamps[(i)] = t_; } } while (0)
+// ... and of wave 0 of EVERY workgroup at its start and end (slots 64 + 2 b, 65 + 2 b of physical workgroup b < 992), in ticks of
+// the constant 100 MHz clock (s_memrealtime: one time base for the whole chip, whatever the shader clock does)
+#define WGSTAMP(i) do { if (threadIdx.x == 0 && a.stamps && blockIdx.x < 992) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); a.stamps[64 + 2 * blockIdx.x + (i)] = t_; } } while (0)
 #else
 #define TSTAMP(i)
+#define WGSTAMP(i)
 #endif
 constexpr int kTrainStagePitch = 40;                                    // halfs per staged row (80 B: 8-byte aligned, rows 20 banks apart)
 constexpr int kTrainStageBytes = 4 * 32 * kTrainStagePitch * 2;         // four waves
@@ -157,6 +161,7 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
   // XCD-major row blocks, as train_chain_kernel: XCD x carries a contiguous eighth of the batch, where the slices of
   // gemm_dw16_lds_kernel will look for it
   TSTAMP(0);
+  WGSTAMP(0);
   const int nrb = (a.rows + kTrainRowsPerWg - 1) / kTrainRowsPerWg;
   const int rb = (int)(blockIdx.x & 7) * ((nrb + 7) >> 3) + (int)(blockIdx.x >> 3);
   if (rb >= nrb) return;
@@ -505,6 +510,7 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
 #endif
 
   TSTAMP(2 + 2 * LR - 1);
+  WGSTAMP(1);
 #ifdef V21_T_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.stamps) a.stamps[30] = ring_wait_cycles;
 #endif

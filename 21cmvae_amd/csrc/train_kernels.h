@@ -294,6 +294,7 @@ struct AdamArgs {
   // that kernel (the next one probably will: it then needs no pack launch); nullptr otherwise.  Same element placement as
   // pack_stream_kernel below; padding and the zero aux fragments of the activation-gradient layers are never written.
   unsigned char* ts; int ts_bf16;
+  int ts_fmt16;  // the stream is fused_train16.h's (16-feature tiles, 32-feature k-steps: tkf / tkb count those)
   AdamLayer lt[16];
 };
 // The layer an arena element belongs to: every block of 256 consecutive elements lies in ONE layer except the few
@@ -344,11 +345,17 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
   if (a.no_pack) return;
   const long long r = i - L.w_off;
   if (a.ts && r >= (long long)L.K * L.N) {
-    // a bias: element [h][reg] of the aux fragment of its forward tile (fp32: the accumulator's initial value),
-    // n = 32 nt + (reg & 3) + 8 (reg >> 2) + 4 h
-    const int n = (int)(r - (long long)L.K * L.N), m = n & 31;
-    const long long frag = L.tsf + (long long)(n >> 5) * (L.tkf + 1);
-    reinterpret_cast<float*>(a.ts + (frag << 10))[((m >> 2) & 1) * 16 + (m >> 3) * 4 + (m & 3)] = wi;
+    const int n = (int)(r - (long long)L.K * L.N);
+    if (a.ts_fmt16) {  // float n % 16 of the aux fragment of tile n / 16
+      const long long frag = L.tsf + (long long)(n >> 4) * (L.tkf + 1);
+      reinterpret_cast<float*>(a.ts + (frag << 10))[n & 15] = wi;
+    } else {
+      // a bias: element [h][reg] of the aux fragment of its forward tile (fp32: the accumulator's initial value),
+      // n = 32 nt + (reg & 3) + 8 (reg >> 2) + 4 h
+      const int m = n & 31;
+      const long long frag = L.tsf + (long long)(n >> 5) * (L.tkf + 1);
+      reinterpret_cast<float*>(a.ts + (frag << 10))[((m >> 2) & 1) * 16 + (m >> 3) * 4 + (m & 3)] = wi;
+    }
   }
   if (r < (long long)L.K * L.N) {  // a kernel element (biases have no copies)
     int k, n;
@@ -362,7 +369,13 @@ __device__ __forceinline__ void adam_repack_element(const AdamArgs& a, long long
       a.wt[L.wt_off + (long long)n * L.ldwt + k] = wi;
       a.wp[L.wp_off + (long long)k * L.ldwp + n] = wi;
     }
-    if (a.ts) {
+    if (a.ts && a.ts_fmt16) {
+      // fused_train16.h: forward tile n / 16, k-step k / 32: lane = 16 g + n % 16, half e with k % 32 = 16 (e / 4) + 4 g + e % 4;
+      // activation-gradient tile k / 16, step n / 32: the same with k and n exchanged
+      ts_store(a, L.tsf + (long long)(n >> 4) * (L.tkf + 1) + 1 + (k >> 5), 16 * ((k >> 2) & 3) + (n & 15), 4 * ((k >> 4) & 1) + (k & 3), wi);
+      if (L.tsb >= 0)
+        ts_store(a, L.tsb + (long long)(k >> 4) * (L.tkb + 1) + 1 + (n >> 5), 16 * ((n >> 2) & 3) + (k & 15), 4 * ((n >> 4) & 1) + (n & 3), wi);
+    } else if (a.ts) {
       // fused_train.h (pack_stream_kernel's placement): forward tile n/32, k-step k/16: lane = 32 h + n%32 with
       // k%16 = 8 (e >> 2) + 4 h + (e & 3); activation-gradient tile k/32, step n/16: the same with k and n exchanged
       ts_store(a, L.tsf + (long long)(n >> 5) * (L.tkf + 1) + 1 + (k >> 4), 32 * ((k >> 2) & 1) + (n & 31), 4 * ((k >> 3) & 1) + (k & 3), wi);
@@ -508,6 +521,7 @@ struct PackArgs {
   int L, total, padded, fpi, epi, esize;  // esize: 2 (f16/bf16) or 4 (f32)
   int is_bf16;
   int all_hidden;        // fused_train.h: every layer's aux fragment is the accumulator's initial value (no output-orientation layer)
+  int fmt16;             // fused_train16.h: 16-feature tiles, 32-feature k-steps (lt[].ks / nt counted that way), fragment order kmap
   PackLayer lt[32];
 };
 static __global__ void pack_stream_kernel(const PackArgs a) {
@@ -524,6 +538,29 @@ static __global__ void pack_stream_kernel(const PackArgs a) {
   const PackLayer L = a.lt[l];
   const int rel = F - L.first, tl = L.ks + 1;
   const int nt = rel / tl, ks = rel % tl - 1;
+  if (a.fmt16) {
+    // fused_train16.h: lane = (out feature m = lane % 16 of the tile, group g = lane / 16); half e of the lane is input feature
+    // kmap(ks, g, e) = 32 ks + 16 (e / 4) + 4 g + e % 4; aux fragment: bias[16 nt + 0..15] as 16 floats, zeros after
+    const int m = lane & 15, g = lane >> 4;
+    if (ks < 0) {
+      float out[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 4; ++q) {
+        const int idx = lane * 4 + q, n = 16 * nt + idx;
+        if (idx < 16 && !(L.flags & 2) && n < L.N) out[q] = a.w[L.b_off + n];
+      }
+      ((float4*)dst)[lane] = make_float4(out[0], out[1], out[2], out[3]);
+      return;
+    }
+    const int n = 16 * nt + m;
+    for (int e = 0; e < 8; ++e) {
+      const int f = 32 * ks + 16 * (e >> 2) + 4 * g + (e & 3);
+      float v = 0.f;
+      if (f < L.K && n < L.N) v = (L.flags & 1) ? a.w[L.w_off + (long long)n * L.K + f] : a.w[L.w_off + (long long)f * L.N + n];
+      if (a.is_bf16) ((__bf16*)dst)[lane * 8 + e] = (__bf16)v;
+      else ((_Float16*)dst)[lane * 8 + e] = (_Float16)v;
+    }
+    return;
+  }
   const int r = lane & 31, h = lane >> 5;
   if (ks < 0) {  // aux fragment: 256 floats, 4 per lane
     float out[4] = {0.f, 0.f, 0.f, 0.f};

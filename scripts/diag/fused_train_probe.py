@@ -35,7 +35,11 @@ for name, env in (("chain", "0"), ("fused", "1")):
     for _ in range(n): tr.step_dev(d_x, None, d_rw, rows, rows)
     ctx.sync(); us = (time.perf_counter() - t0) / n * 1e6
     res[name] = (loss, g, us)
-    print("%s: loss %.6e  |g| %.4e  step %.1f us  (%.1f TFLOP/s)" % (name, loss, np.linalg.norm(g), us, rows * 1675840 / us / 1e6), flush=True)
+    # the shader clock beside the same steps (one sampling wave: v21_debug_clock_probe_*)
+    ctx.clock_probe_start(n * us * 1e-3, 25.0)
+    for _ in range(n): tr.step_dev(d_x, None, d_rw, rows, rows)
+    ctx.sync(); ck = ctx.clock_probe_read()
+    print("%s: loss %.6e  |g| %.4e  step %.1f us  (%.1f TFLOP/s)  clock %.2f GHz (%.2f .. %.2f)" % (name, loss, np.linalg.norm(g), us, rows * 1675840 / us / 1e6, ck["ghz_mean"], ck["ghz_min"], ck["ghz_max"]), flush=True)
 if rows <= 20000:
     W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
     h = y.astype(np.float64); acts = [h]

@@ -55,6 +55,10 @@ for c in range(cases):
     if BIG:
         fused_env = "default"
         os.environ.pop("V21_FUSED_TRAIN_ROWS", None)
+    k16 = int(rng.integers(0, 3))            # which fused kernel: the library's choice / 32 rows per wave / 16
+    if k16 == 0: os.environ.pop("V21_FUSED_TRAIN16", None)
+    else: os.environ["V21_FUSED_TRAIN16"] = str(k16 - 1)
+    fused_env += " k16=%s" % ("lib", "0", "1")[k16]
     perm = rng.permutation(n).astype(np.int32) if rng.random() < 0.5 else None
     ae = dims[0] == dims[-1] and rng.random() < 0.7
     Ws, bs = ora.init_mlp(dims, seed=c)

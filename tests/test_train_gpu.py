@@ -305,10 +305,14 @@ FUSED_TRAIN_STACKS = [   # csrc/archs.h: the stacks with a compiled fused traini
 ]
 
 
+@pytest.mark.parametrize("rows_per_wave", [32, 16])
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 @pytest.mark.parametrize("case", range(len(FUSED_TRAIN_STACKS)), ids=[c[0].split()[0] for c in FUSED_TRAIN_STACKS])
-def test_fused_training_kernel_matches_chain_route_and_oracle(ctx, case, prec, monkeypatch):
-    """Large steps of f16 / bf16 trainers (>= 16,384 rows by default) take csrc/fused_train.h: 128 rows per workgroup,
+def test_fused_training_kernel_matches_chain_route_and_oracle(ctx, case, prec, rows_per_wave, monkeypatch):
+    """BOTH fused training kernels: csrc/fused_train.h (32 rows per wave, 128-row workgroups: trainers of >= 24,576 rows per
+    step) and csrc/fused_train16.h (16 rows per wave on the 16 x 16 x 32 MFMA, 64-row workgroups, two per CU: smaller trainers,
+    from 8,193 rows per step) -- which one a trainer takes is fixed at its creation (V21_FUSED_TRAIN16 overrides).
+    Large steps of f16 / bf16 trainers take csrc/fused_train.h: 128 rows per workgroup,
     weights through an LDS ring shared by four waves, activations, ReLU masks and the activation gradients in registers,
     forward pass + loss + activation-gradient chain as ONE unrolled virtual stack.  Forced here onto a ragged step of
     777 rows (6 workgroups of 128 + one of 9; 48.6 groups of 16; the last 128-row block reaches past max_batch rounded up
@@ -317,6 +321,7 @@ def test_fused_training_kernel_matches_chain_route_and_oracle(ctx, case, prec, m
     FULL gradient against the 32-row chain route (the same 16-bit arithmetic in another order) and the float64 oracle, a
     second step (the packed stream is rebuilt from the arena Adam moved), targets = inputs and separate targets."""
     native, synth = pkg("_native"), pkg("synth")
+    monkeypatch.setenv("V21_FUSED_TRAIN16", "1" if rows_per_wave == 16 else "0")
     name, dims, act, ae = FUSED_TRAIN_STACKS[case]
     n = 777
     rng = np.random.default_rng(40 + case)
@@ -380,8 +385,9 @@ def test_fused_training_kernel_matches_chain_route_and_oracle(ctx, case, prec, m
     assert float(dc @ df / (np.linalg.norm(dc) * np.linalg.norm(df))) > 0.999
 
 
+@pytest.mark.parametrize("rows_per_wave", [32, 16])
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
-def test_fused_training_stream_written_by_adam_equals_the_packed_one(ctx, prec, monkeypatch):
+def test_fused_training_stream_written_by_adam_equals_the_packed_one(ctx, prec, rows_per_wave, monkeypatch):
     """From its second consecutive step on, the fused training kernel reads a weight stream that the previous step's Adam
     pass scattered element by element (csrc/train_kernels.h: adam_repack_element, AdamArgs::ts) instead of one rebuilt
     by pack_stream_kernel.  After three fused steps: the fourth step's loss and FULL gradient equal those of a fresh
@@ -390,6 +396,7 @@ def test_fused_training_stream_written_by_adam_equals_the_packed_one(ctx, prec, 
     (the next step packs again and reproduces the very first loss)."""
     native, synth = pkg("_native"), pkg("synth")
     monkeypatch.setenv("V21_FUSED_TRAIN_ROWS", "1")
+    monkeypatch.setenv("V21_FUSED_TRAIN16", "1" if rows_per_wave == 16 else "0")
     for name, dims, act, ae in (FUSED_TRAIN_STACKS[0], FUSED_TRAIN_STACKS[3]):
         n = 777
         rng = np.random.default_rng(5)
