@@ -101,6 +101,7 @@ SIGNATURES = {
     "v21_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
     "v21_debug_check_chain_jobs": (C.c_int, [_P, C.c_longlong, C.c_longlong]),
     "v21_debug_trainer_counters": (C.c_int, [_P, C.POINTER(C.c_longlong)]),
+    "v21_trainer_get_data_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64)]),
     "v21_debug_clock_probe_start": (C.c_int, [_P, C.c_double, C.c_double]),
     "v21_debug_clock_probe_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
@@ -561,6 +562,13 @@ class Trainer(_Owned):
         with self.ctx.lock:
             check(self.lib.v21_trainer_eval(self.h, which, int(batch), C.byref(loss)))
         return loss.value
+
+    def data_dev(self, which=0):
+        """-> (d_x, d_y, d_rw, n): device pointers of the resident split (d_y == d_x when it was set with y=None), for custom
+        loops that step on slices of it with step_dev (include/v21.h: v21_trainer_get_data_dev)."""
+        x, y, rw, n = _P(), _P(), _P(), C.c_int64(0)
+        check(self.lib.v21_trainer_get_data_dev(self.h, int(which), C.byref(x), C.byref(y), C.byref(rw), C.byref(n)))
+        return x.value, y.value, rw.value, n.value
 
     def step_dev(self, d_x, d_y, d_rw, n_rows, global_rows=None):
         check(self.lib.v21_trainer_step_dev(self.h, _P(d_x), _P(d_y) if d_y else None, _P(d_rw), int(n_rows),

@@ -143,6 +143,7 @@ struct v21_trainer {
   size_t P = 0;
   float *d_g = nullptr, *d_m = nullptr, *d_v = nullptr;  // P + 4 floats; d_g[P] = loss slot
   float* d_x[2] = {nullptr, nullptr};
+  unsigned short* d_x16 = nullptr; long long ldx16 = 0;  // the training inputs as 16-bit operand elements (fused training kernels: ChainStep::x16)
   float* d_y[2] = {nullptr, nullptr};
   float* d_rw[2] = {nullptr, nullptr};
   long long n[2] = {0, 0};

@@ -262,6 +262,7 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   if (t->d_zs) { hipFree(t->d_zs); hipFree(t->d_dzs); hipFree(t->d_dzst); hipFree(t->d_klrow); }
   if (t->d_dworder) hipFree(t->d_dworder);
   if (t->d_tstream) hipFree(t->d_tstream);
+  if (t->d_x16) hipFree(t->d_x16);
   if (t->chain32) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_ticket); hipFree(t->d_stamps); if (t->d_jobs) hipFree(t->d_jobs); }
   if (t->chain) { hipFree(t->d_fw); hipFree(t->d_bw); hipFree(t->d_partial); hipFree(t->d_ticket); hipFree(t->d_stamps);
     for (void* p : t->d_ht16) if (p) hipFree(p);
@@ -297,6 +298,17 @@ extern "C" int v21_trainer_set_data(v21_trainer* t, int which, const float* x, c
   if (t->d_rw[which]) { HIPCHK(hipFree(t->d_rw[which])); t->d_rw[which] = nullptr; }
   HIPCHK(hipMalloc((void**)&t->d_x[which], (size_t)n * din * sizeof(float)));
   HIPCHK(hipMemcpyAsync(t->d_x[which], x, (size_t)n * din * sizeof(float), hipMemcpyHostToDevice, st));
+  if (which == 0) {  // the fused training kernels gather the training rows as 16-bit elements (ChainStep::x16)
+    if (t->d_x16) { HIPCHK(hipFree(t->d_x16)); t->d_x16 = nullptr; }
+    if (t->train_arch >= 0 && !(getenv("V21_TRAIN_X16") && getenv("V21_TRAIN_X16")[0] == '0')) {
+      t->ldx16 = (din + 31) / 32 * 32;
+      const long long tot = (long long)n * t->ldx16;
+      HIPCHK(hipMalloc((void**)&t->d_x16, (size_t)tot * 2));
+      hipLaunchKernelGGL(rows_to_half_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)t->d_x[0], din, (long long)n,
+                         t->d_x16, t->ldx16, t->prec == V21_PREC_BF16 ? 1 : 0);
+      HIPCHK(hipGetLastError());
+    }
+  }
   if (y) {
     HIPCHK(hipMalloc((void**)&t->d_y[which], (size_t)n * dout * sizeof(float)));
     HIPCHK(hipMemcpyAsync(t->d_y[which], y, (size_t)n * dout * sizeof(float), hipMemcpyHostToDevice, st));
@@ -707,6 +719,10 @@ static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, con
   static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, m->dims[L], nullptr, row0);
   a.stamps = t->stamps_on ? t->d_stamps : nullptr;  // (written by diagnostic builds only: -DV21_T_STAMPS)
   a.fw = t->d_tstream; a.fw_bytes = (long long)t->tstream_padded * 1024;
+  // rows of the resident training set: the kernels gather their 16-bit copy
+  if (t->d_x16 && ldx == m->dims[0] && x >= t->d_x[0] && x < t->d_x[0] + (size_t)t->n[0] * ldx && (x - t->d_x[0]) % ldx == 0) {
+    a.x16 = t->d_x16 + (size_t)((x - t->d_x[0]) / ldx) * t->ldx16; a.ldx16 = t->ldx16;
+  }
   if (t->train16) HIPCHK(g_train[t->train_arch].fn16[t->prec == V21_PREC_F16 ? 0 : 1](a, st));
   else HIPCHK(g_train[t->train_arch].fn[t->prec == V21_PREC_F16 ? 0 : 1](a, st));
   return V21_OK;
@@ -1426,6 +1442,15 @@ extern "C" int v21_trainer_eval(v21_trainer* t, int which, int batch, double* lo
   return V21_OK;
 }
 
+extern "C" int v21_trainer_get_data_dev(v21_trainer* t, int which, const float** x, const float** y, const float** rw, int64_t* n) {
+  if (!t || which < 0 || which > 1) return fail(V21_ERR_ARG, "bad argument");
+  if (t->n[which] < 1) return fail(V21_ERR_STATE, "no data set for this split");
+  if (x) *x = t->d_x[which];
+  if (y) *y = t->d_y[which];
+  if (rw) *rw = t->d_rw[which];
+  if (n) *n = t->n[which];
+  return V21_OK;
+}
 extern "C" int v21_trainer_step_dev(v21_trainer* t, const float* d_x, const float* d_y, const float* d_rw, int n_rows,
                                     int global_rows) {
   if (!t || !d_x || !d_rw) return fail(V21_ERR_ARG, "null argument");

@@ -242,6 +242,16 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
   // ---- layer-0 operand: the gathered rows, as 16-bit operand words; flushed as the first weight-gradient operand
   {
     constexpr int K0 = TA::dims[0];
+    if (a.x16) {
+      // the rows as 16-bit elements (ChainStep::x16; rows zero-padded to 32 features: no bound checks): two 8-byte loads per item
+      const unsigned short* xh = a.x16 + src * a.ldx16 + 4 * h;
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      static_for<G::ks_of(0)>([&](auto ks_) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_)::value;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(xh + FPI * ks), hi = *reinterpret_cast<const u32x2*>(xh + FPI * ks + 8);
+        bufA[ks][0] = ok ? lo[0] : 0u; bufA[ks][1] = ok ? lo[1] : 0u; bufA[ks][2] = ok ? hi[0] : 0u; bufA[ks][3] = ok ? hi[1] : 0u;
+      });
+    } else
     static_for<G::ks_of(0)>([&](auto ks_) __attribute__((always_inline)) {
       constexpr int ks = decltype(ks_)::value;
       float v[8];

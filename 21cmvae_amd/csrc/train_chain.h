@@ -93,6 +93,11 @@ struct ChainModel {
 // the batch of this step (shared by every model of a sweep)
 struct ChainStep {
   const float* x; long long ldx;   // source rows
+  // the same rows as 16-bit operand elements (f16 / bf16 as the trainer's precision), row pitch ldx16 halves, zero-padded to
+  // a multiple of 32 features: what the fused training kernels gather instead of x when the step reads the trainer's
+  // resident training set (api_trainer.hip: v21_trainer_set_data) -- large steps are bound by HBM traffic, and the input
+  // rows are rounded to 16 bits on their way into the first MFMA either way; nullptr: none
+  const unsigned short* x16; long long ldx16;
   const float* y; long long ldy;   // targets (nullptr: y == x, the autoencoder)
   const float* rw;                 // row weights w_i
   const int* idx; long long first; // row m of the batch = source row idx[first + m] (or first + m)

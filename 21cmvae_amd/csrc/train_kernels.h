@@ -513,6 +513,15 @@ static __global__ void affine_out_kernel(float* __restrict__ y, long long ldy, l
 // lane).  Layer table in `lt`: per layer {K, N, ks, nt, w_off, b_off, first_frag}.
 // flags: 1 = the layer's weights are read TRANSPOSED (element (f, n) = w[w_off + n * K + f]: an activation-gradient layer
 // of fused_train.h, whose K is the real layer's N), 2 = no bias (zero aux fragment)
+// fp32 rows -> 16-bit operand elements (f16 / bf16), row pitch ld16 halves, zero beyond the row's din features
+static __global__ void rows_to_half_kernel(const float* x, int din, long long n, unsigned short* out, long long ld16, int is_bf16) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * ld16) return;
+  const long long r = i / ld16; const int c = (int)(i - r * ld16);
+  const float v = c < din ? x[r * din + c] : 0.f;
+  if (is_bf16) { const __bf16 h = (__bf16)v; out[i] = __builtin_bit_cast(unsigned short, h); }
+  else { const _Float16 h = (_Float16)v; out[i] = __builtin_bit_cast(unsigned short, h); }
+}
 struct PackLayer { int K, N, ks, nt; long long w_off, b_off; int first; int flags; };
 struct PackArgs {
   const float* w;        // flat arena

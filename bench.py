@@ -269,6 +269,9 @@ def train_roofline(leg, flop_per_sample, params, din, dout, stats_csv, pmc_json)
                       if isinstance(v, dict) and v.get("FETCH_SIZE", {}).get("dispatches", 0) >= 10)
             rf["traffic"] = tot
             rf["traffic_source"] = "profiles/%s/%s: sum over the step's kernels of 2*FETCH_SIZE*1024 + WRITE_SIZE*1024" % (PROFILE_TAG, pmc_json)
+            # large steps are bound by these bytes, not by the matrix pipe (per-workgroup stamps on the constant clock, r4:
+            # both fused training kernels and the weight-gradient kernel move ~4.2 TB/s): the step against the 8 TB/s peak
+            rf["hbm_side_frac_of_8TBps"] = tot / step_s / 1e9 / PEAK_HBM_GBS
         except Exception:
             pass
     return rf
@@ -302,8 +305,10 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
     sig = synth.make_signals(batch, seed=2000 + rank)
     y = pp.preproc(sig, sig)
     rw = losses.relative_mse_loss(sig)._v21_row_weight(y).astype(np.float32)
-    d_x, d_rw = ctx.malloc(y.nbytes), ctx.malloc(rw.nbytes)
-    ctx.h2d(d_x, y); ctx.h2d(d_rw, rw)
+    # the batch as the trainer's RESIDENT training set (what Model.fit steps on: v21_trainer_set_data), stepped through its
+    # device pointers: steps of the fused training kernels then gather the 16-bit copy of the rows (ChainStep::x16)
+    tr.set_data(0, y, None, rw)
+    d_x, _, d_rw, _ = tr.data_dev(0)
     for _ in range(warmup):
         tr.step_dev(d_x, None, d_rw, batch, batch * world)
     sync_all(); barrier(); sync_all()
@@ -317,7 +322,6 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     loss = tr.last_step_loss() / (batch * world)
-    ctx.free(d_x); ctx.free(d_rw)
     sps = steps / wall
     return {"steps_per_s": sps, "samples_per_s": sps * batch * world, "ms_per_step": 1e3 / sps,
             "batch_per_gpu": batch, "global_batch": batch * world, "precision": precision,
@@ -961,9 +965,9 @@ def main():
                     # r4: steps of >= 16,384 rows take the fused training kernel (csrc/fused_train.h: 128 rows per workgroup,
                     # weights through an LDS ring, activations in registers, its weight stream written by the previous step's
                     # Adam pass); V21_FUSED_TRAIN_ROWS sets the threshold
-                    fused_route = "fused training kernel (fused_train<ArchT1, Prec%st>) + split-K weight gradients + Adam" % args.precision.upper()
-                    if args.precision in ("f16", "bf16"):
-                        t16k["route"] = fused_route
+                    fused_route = "fused training kernel (fused_train<ArchT1, Prec%st>: 128-row workgroups) + split-K weight gradients + Adam" % args.precision.upper()
+                    if args.precision in ("f16", "bf16"):  # (a trainer of fewer than 24,576 rows per step: 16 rows per wave, 64-row workgroups, two per CU)
+                        t16k["route"] = "fused training kernel (fused_train16<ArchT1, Prec%st16>: 64-row workgroups) + split-K weight gradients + Adam" % args.precision.upper()
                     out["train_b16384"] = t16k
                     t32k = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier, sync_all, 32768,
                                      args.precision, max(10, args.train_steps // 4), 5)

@@ -190,6 +190,11 @@ int v21_trainer_run_epoch(v21_trainer* tr, const int32_t* perm, int batch, doubl
  * evaluate the whole split in ONE forward-only launch (`batch` is then only validated); f32 trainers walk it in
  * batches of min(batch, max_batch). */
 int v21_trainer_eval(v21_trainer* tr, int which, int batch, double* loss);
+/* device pointers of the resident split `which` (v21_trainer_set_data): x (n, in_dim), y (n, out_dim; the same pointer as x
+ * when the split was set with y == NULL), row weights (n) -- for custom loops that step on slices of the resident training
+ * set with v21_trainer_step_dev (a step that reads rows of the resident training inputs lets the fused training kernels gather
+ * their 16-bit copy: half the bytes of the step's largest read).  Valid until the next set_data of that split. */
+int v21_trainer_get_data_dev(v21_trainer* tr, int which, const float** x, const float** y, const float** row_weight, int64_t* n);
 /* single optimizer step on caller-provided device batch (bench / custom loops) */
 int v21_trainer_step_dev(v21_trainer* tr, const float* d_x, const float* d_y,
                          const float* d_row_weight, int n_rows, int global_rows);

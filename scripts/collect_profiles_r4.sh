@@ -59,7 +59,10 @@ cd $ROOT
 $PY scripts/diag/k1_wide_probe.py > $OUT/k1_wide_variant_and_clock_probe.txt 2>&1
 $PY scripts/diag/jit_parity_probe.py > $OUT/jit_parity_probe.txt 2>&1
 $PY scripts/diag/jit_fuzz.py 40 1 > $OUT/jit_fuzz_40_random_stacks.txt 2>&1
-for n in 16384 32768; do $PY scripts/diag/fused_train_probe.py $n f16 > $OUT/fused_train_probe_b${n}_f16.txt 2>&1; done
+# (the library's choice of fused training kernel: 16 rows per wave below 24,576 rows per step, 32 above -- and the other one of each, forced)
+for n in 9216 12288 16384 32768; do $PY scripts/diag/fused_train_probe.py $n f16 > $OUT/fused_train_probe_b${n}_f16.txt 2>&1; done
+V21_FUSED_TRAIN16=0 $PY scripts/diag/fused_train_probe.py 16384 f16 > $OUT/fused_train_probe_b16384_f16_forced_32_rows_per_wave.txt 2>&1
+V21_FUSED_TRAIN16=1 $PY scripts/diag/fused_train_probe.py 32768 f16 > $OUT/fused_train_probe_b32768_f16_forced_16_rows_per_wave.txt 2>&1
 $PY scripts/power_probe.py > $OUT/power_probe_fused_random_vs_zero_operands.txt 2>&1
 # 5b. the round's fuzzers (random cases against the float64 oracle and a bitwise twin; every line ends in OK / BAD / refused)
 $PY scripts/diag/train_fuzz.py 150 11 > $OUT/train_fuzz_150_cases.txt 2>&1
@@ -87,7 +90,9 @@ echo "hidden layers done"
 # 7. where a workgroup of the fused training kernel spends its cycles (diagnostic build `make -C 21cmvae_amd/csrc tstamp`, if present), and
 # the one-wave-per-SIMD microbenchmarks DESIGN.md section 3 K3-fused quotes (compiled here: hipcc is on the box)
 if [ -f $ROOT/21cmvae_amd/libv21_tstamp.so ]; then
-  for n in 16384 32768; do V21_LIB=$ROOT/21cmvae_amd/libv21_tstamp.so $PY scripts/diag/fused_train_stamps.py $n > $OUT/fused_train_layer_stamps_b${n}_f16.txt 2>&1; done
+  for k in 0 1; do for n in 16384 32768; do
+    V21_FUSED_TRAIN16=$k V21_LIB=$ROOT/21cmvae_amd/libv21_tstamp.so $PY scripts/diag/fused_train_stamps.py $n > $OUT/fused_train_stamps_b${n}_f16_$((32 - 16 * k))_rows_per_wave.txt 2>&1
+  done; done
 fi
 for pb in mfma_chain_probe lds_read_probe mfma_issue_probe; do
   hipcc -std=c++20 --offload-arch=gfx950 -O3 -o /tmp/$pb scripts/diag/$pb.hip > /dev/null 2>&1 && timeout -k 5 120 /tmp/$pb > $OUT/microbench_$pb.txt 2>&1

@@ -23,6 +23,9 @@ for name, env in (("chain", "0"), ("fused", "1")):
     os.environ["V21_FUSED_TRAIN_ROWS"] = "1"   # (the default threshold is 16,384 rows: the probe compares the routes at any size)
     st = native.Stack(ctx, dims, act); st.set_weights(flat)
     tr = native.Trainer(st, prec, rows); tr.set_adam(lr=1e-3)
+    if os.environ.get("PROBE_RESIDENT", "1") == "1":   # step on the trainer's resident training set (what Model.fit does): the fused kernels gather its 16-bit copy
+        tr.set_data(0, y, None, w)
+        d_x, _, d_rw, _ = tr.data_dev(0)
     tr.step_dev(d_x, None, d_rw, rows, rows)
     loss = tr.last_step_loss() / rows
     g = tr.get_grad()

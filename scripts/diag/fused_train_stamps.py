@@ -1,5 +1,7 @@
-"""Diagnostics: cycles of workgroup 0 / wave 0 per virtual layer of the fused training kernel (needs a library built with
--DV21_T_STAMPS: V21_LIB=.../libv21_tstamp.so).  python fused_train_stamps.py [rows]"""
+"""Diagnostics: shader cycles of workgroup 0 / wave 0 per virtual layer of a fused training kernel, and the start / end of EVERY
+workgroup on the constant 100 MHz clock (needs a library built with -DV21_T_STAMPS: `make -C 21cmvae_amd/csrc tstamp`,
+V21_LIB=.../libv21_tstamp.so; V21_FUSED_TRAIN16=0 / 1 picks csrc/fused_train.h / fused_train16.h).
+  python fused_train_stamps.py [rows]"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -16,8 +18,8 @@ st = native.Stack(ctx, dims, act); st.set_weights(ora.flatten_params(Ws, bs))
 tr = native.Trainer(st, "f16", rows); tr.set_adam(lr=1e-4)
 x = rng.uniform(-1, 1, size=(rows, 451)).astype(np.float32)
 w = np.full(rows, 1.0 / 451, np.float32)
-d_x, d_rw = ctx.malloc(x.nbytes), ctx.malloc(w.nbytes)
-ctx.h2d(d_x, x); ctx.h2d(d_rw, w)
+tr.set_data(0, x, None, w)              # the batch as the trainer's resident training set (what Model.fit steps on)
+d_x, _, d_rw, _ = tr.data_dev(0)
 tr.enable_stamps(True)
 for _ in range(30):
     tr.step_dev(d_x, None, d_rw, rows, rows)

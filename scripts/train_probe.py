@@ -13,8 +13,8 @@ rng = np.random.default_rng(0)
 st.set_weights(rng.normal(scale=0.05, size=st.num_params).astype(np.float32))
 tr = native.Trainer(st, prec, B)
 x = rng.normal(size=(B, 451)).astype(np.float32); w = np.full(B, 1 / 451, np.float32)
-d_x, d_w = ctx.malloc(x.nbytes), ctx.malloc(w.nbytes)
-ctx.h2d(d_x, x); ctx.h2d(d_w, w)
+tr.set_data(0, x, None, w)              # the batch as the trainer's resident training set (what Model.fit steps on)
+d_x, _, d_w, _ = tr.data_dev(0)
 for _ in range(5):
     tr.step_dev(d_x, None, d_w, B, B)
 ctx.sync()
