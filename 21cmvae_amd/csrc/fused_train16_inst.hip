@@ -1,4 +1,4 @@
-// fused_train_inst.hip -- one translation unit per (stack, precision) of the fused training kernel (fused_train16.h);
+// fused_train16_inst.hip -- one translation unit per (stack, precision) of the 16-rows-per-wave fused training kernel (fused_train16.h);
 // compiled with -DV21_ARCH=T1 -DV21_PREC=F16t16 etc. (see Makefile).
 #include "fused_train16.h"
 #include "archs.h"
