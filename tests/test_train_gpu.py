@@ -1430,3 +1430,45 @@ def test_a_script_that_ends_with_live_joint_sweep_and_trainers_exits_cleanly(tmp
     for _ in range(3):   # (the order depends on addresses: a few tries)
         r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("rows_per_wave", [32, 16])
+def test_fused_training_gathers_the_resident_16_bit_copy_with_identical_results(ctx, rows_per_wave, monkeypatch):
+    """v21_trainer_set_data keeps the training inputs of a trainer with a fused training kernel as 16-bit rows as well
+    (ChainStep::x16); a fused step that reads rows of the RESIDENT set gathers those instead of the fp32 rows (half the bytes of
+    the step's largest read).  The same step on a caller's own device copy of the same rows gathers fp32 and rounds in the
+    kernel: the operands are the same 16-bit values, so loss, gradient and weights must be identical bit for bit -- whole set,
+    and a slice of the resident set stepped through its device pointers (v21_trainer_get_data_dev)."""
+    native, synth = pkg("_native"), pkg("synth")
+    monkeypatch.setenv("V21_FUSED_TRAIN_ROWS", "1")
+    monkeypatch.setenv("V21_FUSED_TRAIN16", "1" if rows_per_wave == 16 else "0")
+    name, dims, act, ae = FUSED_TRAIN_STACKS[0]
+    n = 500
+    sig = synth.make_signals(n, seed=12)
+    x = ora.preproc(sig, sig)
+    w = ora.relative_mse_row_weight(x, sig).astype(np.float32)
+    Ws, bs = ora.init_mlp(dims, seed=5)
+    flat = ora.flatten_params(Ws, bs)
+    res = []
+    for resident in (True, False):
+        st = native.Stack(ctx, dims, act); st.set_weights(flat)
+        tr = native.Trainer(st, "f16", n); tr.set_adam(lr=1e-3)
+        tr.set_data(0, x, None, w)
+        if resident:
+            d_x, d_y, d_rw, rows = tr.data_dev(0)
+            assert rows == n and d_y == d_x
+        else:
+            d_x, d_rw = ctx.malloc(x.nbytes), ctx.malloc(w.nbytes)
+            ctx.h2d(d_x, x); ctx.h2d(d_rw, w)
+        out = []
+        for first, cnt in ((0, n), (123, 300)):      # the whole set, then rows 123 .. 422
+            tr.step_dev(d_x + 4 * 451 * first, None, d_rw + 4 * first, cnt, cnt)
+            out.append((tr.last_step_loss(), tr.get_grad()))
+        res.append((out, st.get_weights(), tr.route_counters()))
+        if not resident:
+            ctx.free(d_x); ctx.free(d_rw)
+    (oa, wa, ca), (ob, wb, cb) = res
+    assert ca["fused"] == cb["fused"] == 2
+    for (la, ga), (lb, gb) in zip(oa, ob):
+        assert la == lb and np.array_equal(ga, gb)
+    assert np.array_equal(wa, wb)
