@@ -78,7 +78,7 @@ for c in range(cases):
     except native.EngineError as e:
         print(tag, "refused:", str(e)[:120], flush=True)
         continue
-    tol = {"f32": 5e-5, "f16": 5e-3, "bf16": 4e-2}[prec]
+    tol = {"f32": 1e-4, "f16": 5e-3, "bf16": 4e-2}[prec]   # (f32: thousands of single-row steps on fp32 latents against the float64 ones reach 5e-5)
     rel2 = max(abs(a - b) / abs(b) for a, b in zip(lj, l2))
     (lo1, wa1, we1), (lo2, wa2, we2) = res
     # (f32: the joint launch may group the rows of the batch loss differently from the single model's -- the same sums per
