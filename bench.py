@@ -962,9 +962,11 @@ def main():
                     t16k["roofline"] = train_roofline(t16k, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
                                                       "kernel_stats_train_b16384_%s.csv" % args.precision,
                                                       "pmc_train_b16384_%s.json" % args.precision)
-                    # r4: steps of >= 16,384 rows take the fused training kernel (csrc/fused_train.h: 128 rows per workgroup,
-                    # weights through an LDS ring, activations in registers, its weight stream written by the previous step's
-                    # Adam pass); V21_FUSED_TRAIN_ROWS sets the threshold
+                    # r4: large steps of the reference stacks take a fused training kernel (weights through an LDS ring, activations
+                    # in registers, the weight stream written by the previous step's Adam pass, rows from the 16-bit resident
+                    # copy): csrc/fused_train16.h (16 rows per wave, 64-row workgroups) from 8,193 rows for a trainer of fewer
+                    # than 24,576 rows per step, csrc/fused_train.h (128-row workgroups) from 16,384 rows for a larger one;
+                    # V21_FUSED_TRAIN_ROWS / V21_FUSED_TRAIN16 override
                     fused_route = "fused training kernel (fused_train<ArchT1, Prec%st>: 128-row workgroups) + split-K weight gradients + Adam" % args.precision.upper()
                     if args.precision in ("f16", "bf16"):  # (a trainer of fewer than 24,576 rows per step: 16 rows per wave, 64-row workgroups, two per CU)
                         t16k["route"] = "fused training kernel (fused_train16<ArchT1, Prec%st16>: 64-row workgroups) + split-K weight gradients + Adam" % args.precision.upper()
