@@ -101,8 +101,15 @@ SIGNATURES = {
     "v21_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
     "v21_debug_check_chain_jobs": (C.c_int, [_P, C.c_longlong, C.c_longlong]),
     "v21_debug_trainer_counters": (C.c_int, [_P, C.POINTER(C.c_longlong)]),
+    "v21_route_forward": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "v21_route_train": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "v21_mlp_last_route": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    "v21_trainer_last_route": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "v21_route_name": (C.c_char_p, [C.c_int, C.c_int]),
     "v21_trainer_get_data_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64)]),
     "v21_debug_clock_probe_start": (C.c_int, [_P, C.c_double, C.c_double]),
+    "v21_debug_forward_clocked": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "v21_debug_clock_probe_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "v21_trainer_set_vae": (C.c_int, [_P, C.c_float, C.c_int, C.c_uint64]),
     "v21_trainer_enable_stamps": (C.c_int, [_P, C.c_int]),
@@ -126,6 +133,31 @@ SIGNATURES = {
     "v21_comm_reduce_scatter_f32": (C.c_int, [_P, _P, C.c_size_t]),
     "v21_comm_allgather_f32": (C.c_int, [_P, _P, C.c_size_t]),
 }
+
+# ---- routes (include/v21.h: v21_route_*; csrc/routes.h): the names the tests and INTEGRATION.md section 6 use
+FWD_ROUTES = {1: "small", 2: "fused", 3: "fused_rt", 4: "table", 5: "generic"}
+TRAIN_FWD_ROUTES = {1: "per_layer", 2: "chain16", 3: "fused128", 4: "fused64", 5: "chain32", 6: "chain32s_8", 7: "chain32s_4"}
+TRAIN_UPD_ROUTES = {1: "per_layer", 2: "dw16_adam", 3: "dw16_splitk", 4: "dwadam32", 5: "nt_dwadam", 6: "nt_sliced"}
+
+
+def route_forward(dims, act, precision, n, flags=0, rt_ready=False):
+    """The route v21_mlp_forward_dev takes for n rows of this stack (pure host logic: no GPU).  -> name of FWD_ROUTES."""
+    L = len(act)
+    r = C.c_int(0)
+    check(load_library().v21_route_forward(L, (C.c_int * (L + 1))(*[int(d) for d in dims]), (C.c_int * L)(*[int(a) for a in act]),
+                                           precision_id(precision), int(n), int(flags), 1 if rt_ready else 0, C.byref(r)))
+    return FWD_ROUTES[r.value]
+
+
+def route_train(dims, act, precision, max_batch, rows, nranks=1):
+    """The kernels one optimizer step of `rows` rows takes for a trainer created with max_batch on nranks ranks (pure host
+    logic: no GPU).  -> (name of TRAIN_FWD_ROUTES, name of TRAIN_UPD_ROUTES)."""
+    L = len(act)
+    f, u = C.c_int(0), C.c_int(0)
+    check(load_library().v21_route_train(L, (C.c_int * (L + 1))(*[int(d) for d in dims]), (C.c_int * L)(*[int(a) for a in act]),
+                                         precision_id(precision), int(max_batch), int(rows), int(nranks), C.byref(f), C.byref(u)))
+    return TRAIN_FWD_ROUTES[f.value], TRAIN_UPD_ROUTES[u.value]
+
 
 _lib = None
 _lock = threading.Lock()
@@ -460,6 +492,14 @@ class Stack(_Owned):
         check(self.lib.v21_mlp_has_fused(self.h, precision_id(precision), C.byref(y)))
         return bool(y.value)
 
+    def last_route(self):
+        """(route name of the last device forward call, {route name: calls since creation}) -- written where the kernels
+        are launched (include/v21.h: v21_mlp_last_route)."""
+        r = C.c_int(0)
+        cnt = (C.c_longlong * 8)()
+        check(self.lib.v21_mlp_last_route(self.h, C.byref(r), cnt))
+        return FWD_ROUTES.get(r.value, "none"), {FWD_ROUTES[i]: int(cnt[i]) for i in FWD_ROUTES if cnt[i]}
+
     def jit(self, precision="f32", wait_ms=-1):
         """Ask for the fused kernel of THIS stack (run-time instantiation, include/v21.h: v21_mlp_jit) and wait up to
         `wait_ms` (< 0: until compiled).  -> "ready" / "compiling"; raises EngineError when the stack cannot have one."""
@@ -485,6 +525,11 @@ class Stack(_Owned):
             check(self.lib.v21_mlp_forward(self.h, x.ctypes.data_as(_P), dt, x.shape[0], _fptr(y),
                                            precision_id(precision), flags))
         return y
+
+    def forward_clocked(self, d_x, ldx, n, d_y, ldy, d_stamps, precision="f16", flags=0):
+        """forward_dev through the clock-stamped instantiation of the headline stack's kernel (include/v21.h:
+        v21_debug_forward_clocked); d_stamps: device buffer of 5 uint64 per 128-row workgroup."""
+        check(self.lib.v21_debug_forward_clocked(self.h, _P(d_x), ldx, n, _P(d_y), ldy, precision_id(precision), flags, _P(d_stamps)))
 
     def forward_dev(self, d_x, ldx, n, d_y, ldy, precision="f32", flags=0):
         check(self.lib.v21_mlp_forward_dev(self.h, _P(d_x), ldx, n, _P(d_y), ldy, precision_id(precision), flags))
@@ -614,6 +659,16 @@ class Trainer(_Owned):
         out = (C.c_longlong * 4)()
         check(self.lib.v21_debug_trainer_counters(self.h, out))
         return dict(zip(("chain", "fused", "stream_packs", "stream_adam"), (int(v) for v in out)))
+
+    def last_route(self):
+        """((forward route, update route) of the last eager step, {(fwd or upd) route name: steps since creation}) -- written
+        where the kernels are launched (include/v21.h: v21_trainer_last_route)."""
+        f, u = C.c_int(0), C.c_int(0)
+        fc, uc = (C.c_longlong * 8)(), (C.c_longlong * 8)()
+        check(self.lib.v21_trainer_last_route(self.h, C.byref(f), C.byref(u), fc, uc))
+        counts = {TRAIN_FWD_ROUTES[i]: int(fc[i]) for i in TRAIN_FWD_ROUTES if fc[i]}
+        counts.update({"upd:" + TRAIN_UPD_ROUTES[i]: int(uc[i]) for i in TRAIN_UPD_ROUTES if uc[i]})
+        return (TRAIN_FWD_ROUTES.get(f.value, "none"), TRAIN_UPD_ROUTES.get(u.value, "none")), counts
 
     def enable_stamps(self, on=True):
         """Cycle stamps of the chain kernel's phases (diagnostics; off by default: they cost 2-3 us per step)."""

@@ -13,6 +13,9 @@ namespace v21 {
   hipError_t launch_fused_##a##_BF16x2sp(const FusedArgs&, hipStream_t);
 V21_ARCH_LIST(V21_DECL)
 #undef V21_DECL
+// the headline stack's 16-bit kernels with per-workgroup clock stamps (fused_fwd.h: CLOCK_STAMPS; v21_debug_forward_clocked)
+hipError_t launch_fused_S1_F16x2spClk(const FusedArgs&, hipStream_t);
+hipError_t launch_fused_S1_BF16x2spClk(const FusedArgs&, hipStream_t);
 }  // namespace v21
 
 typedef hipError_t (*fused_launcher)(const FusedArgs&, hipStream_t);
@@ -39,6 +42,61 @@ static void stream_geometry(const v21_mlp* m, int prec, int* total, int* padded)
   for (int l = 0; l < m->L; ++l) f += ((m->dims[l + 1] + 31) / 32) * ((m->dims[l] + fpi_of(prec) - 1) / fpi_of(prec) + 1);
   *total = f;
   *padded = (f + 7) / 8 * 8;  // whole DMA rounds of the 4- and 8-wave kernels (fused_fwd.h: Geo::padded)
+}
+
+// archs.h: the compiled fused forward kernel of this stack, or -1
+static int fused_id_of(int n_layers, const int* dims, const int* act) {
+  for (size_t i = 0; i < sizeof(g_fused) / sizeof(g_fused[0]); ++i) {
+    const FusedEntry& fe = g_fused[i];
+    if (fe.L != n_layers) continue;
+    bool same = true;
+    for (int k = 0; k <= n_layers && same; ++k) same = fe.dims[k] == dims[k];
+    for (int k = 0; k < n_layers && same; ++k) same = fe.act[k] == act[k];
+    if (same) return (int)i;
+  }
+  return -1;
+}
+// ---- routes (csrc/routes.h) through the C ABI: pure host logic, no GPU needed
+static int check_stack_desc(int n_layers, const int* dims, const int* act) {
+  if (!dims || !act) return fail(V21_ERR_ARG, "null argument");
+  if (n_layers < 1 || n_layers > 16) return fail(V21_ERR_ARG, "n_layers %d out of range", n_layers);
+  for (int l = 0; l <= n_layers; ++l)
+    if (dims[l] < 1) return fail(V21_ERR_ARG, "dims[%d] = %d", l, dims[l]);
+  for (int l = 0; l < n_layers; ++l)
+    if (act[l] < 0 || act[l] > V21_ACT_GAUSS) return fail(V21_ERR_ARG, "act[%d] = %d unknown", l, act[l]);
+  return V21_OK;
+}
+extern "C" int v21_route_forward(int n_layers, const int* dims, const int* act, int precision, int64_t n, int flags, int rt_ready, int* route) {
+  if (!route) return fail(V21_ERR_ARG, "null argument");
+  CHK(check_stack_desc(n_layers, dims, act));
+  if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
+  const int out = dims[n_layers];
+  FwdQuery q{n_layers, dims, act, fused_id_of(n_layers, dims, act) >= 0, rt_ready ? 2 : 0, precision, (long long)n, flags & 0xFF, (long long)out};
+  if (q.jit == 2) {
+    std::string why;
+    if (!v21::jit_eligible(n_layers, dims, act, &why)) q.jit = 0;
+  }
+  *route = decide_forward(q);
+  return V21_OK;
+}
+extern "C" int v21_mlp_last_route(v21_mlp* m, int* route, long long counts[8]) {
+  if (!m || !route) return fail(V21_ERR_ARG, "null argument");
+  *route = m->last_route;
+  if (counts) for (int i = 0; i < 8; ++i) counts[i] = m->route_count[i];
+  return V21_OK;
+}
+extern "C" const char* v21_route_name(int kind, int route) {
+  static const char* fwd[] = {"none", "small (one NT launch per layer)", "fused_fwd (compiled)", "fused_fwd (run-time instantiated)",
+                              "table-driven chain kernel, FORWARD mode", "generic per-layer GEMM"};
+  static const char* tr[] = {"none", "per-layer NT", "train_chain_kernel (16-bit, 32-row blocks)", "fused_train (128-row workgroups)",
+                             "fused_train16 (64-row workgroups)", "train_chain32_kernel (fp32, 16-row blocks)",
+                             "train_chain32s_kernel<8> (fp32)", "train_chain32s_kernel<4> (fp32)"};
+  static const char* up[] = {"none", "per-layer NT + adam_repack", "dw16_adam_kernel (one launch)", "gemm_dw16[_lds] split-K + adam_repack",
+                             "dwadam32_kernel (one launch)", "gemm_nt_dwadam_kernel (one launch)", "sliced NT + adam_repack"};
+  if (kind == 0 && route >= 0 && route <= FWD_GENERIC) return fwd[route];
+  if (kind == 1 && route >= 0 && route <= TR_CHAIN32S_4) return tr[route];
+  if (kind == 2 && route >= 0 && route <= UP_NT_SLICED) return up[route];
+  return "?";
 }
 
 extern "C" int v21_mlp_create(v21_ctx* ctx, int n_layers, const int* dims, const int* act, v21_mlp** out) {
@@ -68,14 +126,7 @@ extern "C" int v21_mlp_create(v21_ctx* ctx, int n_layers, const int* dims, const
   hipError_t e = hipMalloc((void**)&m->d_w, (m->nparams + kArenaPad) * sizeof(float));
   if (e != hipSuccess) { delete m; return fail(V21_ERR_HIP, "hipMalloc weights: %s", hipGetErrorString(e)); }
   hipMemsetAsync(m->d_w, 0, (m->nparams + kArenaPad) * sizeof(float), ctx->stream);
-  for (size_t i = 0; i < sizeof(g_fused) / sizeof(g_fused[0]); ++i) {
-    const FusedEntry& fe = g_fused[i];
-    if (fe.L != n_layers) continue;
-    bool same = true;
-    for (int k = 0; k <= n_layers && same; ++k) same = fe.dims[k] == dims[k];
-    for (int k = 0; k < n_layers && same; ++k) same = fe.act[k] == act[k];
-    if (same) { m->fused_id = (int)i; break; }
-  }
+  m->fused_id = fused_id_of(n_layers, dims, act);
   *out = m;
   return V21_OK;
 }
@@ -276,26 +327,22 @@ static int forward_small(v21_mlp* m, const float* d_x, long long ldx, long long 
 // (train_chain.h) -- what every `_gen_model` output without a compiled fused kernel gets (custom `hidden_dims`,
 // emulator.py:12-48; the members of a sweep).  r3, 65,536 rows: the per-layer K-loop path took 0.85 ms on the
 // headline stack (15x the fused kernel) and 0.35 ms on the sample notebook's 7 -> [64, 128] -> 451 model.
-static bool chain_fwd_eligible(const v21_mlp* m, int precision, int flags) {
-  if (flags & V21_FWD_FORCE_GENERIC) return false;
-  for (int l = 0; l <= m->L; ++l)
-    if (m->dims[l] > kChainMaxDim) return false;
-  for (int l = 0; l < m->L; ++l)
-    if (m->act[l] == V21_ACT_GAUSS && (precision == V21_PREC_F32 || m->dims[l + 1] > kChainMaxLatent || l == m->L - 1)) return false;
-  if ((flags & V21_FWD_IN_TRANSFORM) && m->dims[0] > 8) return false;
-  return true;
-}
 static int forward_chain(v21_mlp* m, const float* d_x, long long ldx, long long n, float* d_y, long long ldy, int prec,
                          int flags);
 // internal: d_x rows are already zero-padded to a multiple of 16 floats (ldx) in a buffer with slack --
 // the small-batch path reads them in place (set by v21_mlp_forward, which pads on the host)
 #define V21_FWD_X_PADDED 0x100
-static bool takes_small_path(const v21_mlp* m, long long n, int precision, int flags) {
-  const bool fused = m->fused_id >= 0 && !(flags & V21_FWD_FORCE_GENERIC) &&
-                     (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8);
-  return n <= V21_SMALL_BATCH_ROWS && !(flags & (V21_FWD_NO_SMALL | V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN | V21_FWD_FORCE_JIT)) &&
-         (precision == V21_PREC_F32 || !fused) && (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) &&
-         m->maxdim <= kNtMaxKPerWg;
+// internal: this device call belongs to a host call that found no run-time kernel when it started -- do not pick one up
+// half way (one result array must not hold two roundings); decide_forward (routes.h) knows the flag
+static_assert(V21_FWD_RT_LATCH_OFF == 0x200, "routes.h and api_forward.hip agree on the internal flag");
+// the run-time kernel of this stack: asked for on first need; true when its code object can be launched now
+static bool jit_ready_now(v21_mlp* m, int precision) {
+  if (m->fused_id >= 0) return false;
+  if (!m->jit_asked[precision]) {
+    m->jit[precision] = v21::jit_request(m->L, m->dims.data(), m->act.data(), precision);
+    m->jit_asked[precision] = true;
+  }
+  return m->jit[precision] && v21::jit_state(m->jit[precision]) == v21::JIT_READY;
 }
 
 extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, int64_t n, float* d_y, int64_t ldy,
@@ -307,17 +354,20 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
   CHK(use(m->ctx));
   if ((flags & V21_FWD_IN_TRANSFORM) && !m->has_tin) return fail(V21_ERR_STATE, "input transform requested but not set");
   if ((flags & V21_FWD_OUT_TRANSFORM) && !m->has_tout) return fail(V21_ERR_STATE, "output transform requested but not set");
-  const bool fused = m->fused_id >= 0 && !(flags & (V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN | V21_FWD_FORCE_JIT)) &&
-                     (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8) && ldy < (1ll << 21);
+  // which route: csrc/routes.h (decide_forward) -- the same function answers v21_route_forward
+  FwdQuery q{m->L, m->dims.data(), m->act.data(), m->fused_id >= 0, 0, precision, (long long)n, flags, (long long)ldy};
   // few rows: one latency-oriented launch per layer beats one wave walking the whole stack in f32
   // (and the K-loop GEMM of the generic path in any precision)
-  if (takes_small_path(m, n, precision, flags) && ldy < (1ll << 21))
+  if (decide_forward(q) == FWD_SMALL) {
+    m->last_route = FWD_SMALL; m->route_count[FWD_SMALL] += 1;
     return forward_small(m, d_x, ldx, n, d_y, ldy, precision, flags);
+  }
   // a stack outside archs.h: the same fused kernel, instantiated for it at run time (jit.h).  The first call asks for
-  // it; the calls that arrive before its code object does take the table-driven routes below.
+  // it; the calls that arrive before its code object does take the table-driven routes below.  (V21_FWD_RT_LATCH_OFF:
+  // a host call that found the kernel missing when it started keeps the table-driven route for ALL its slices.)
   v21::JitKernel* jk = nullptr;
   const bool force_jit = (flags & V21_FWD_FORCE_JIT) != 0;
-  if ((m->fused_id < 0 || force_jit) && !(flags & (V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN)) && ldy < (1ll << 21) &&
+  if ((m->fused_id < 0 || force_jit) && !(flags & (V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN | V21_FWD_RT_LATCH_OFF)) && ldy < (1ll << 21) &&
       (!(flags & V21_FWD_IN_TRANSFORM) || m->dims[0] <= 8)) {
     if (!m->jit_asked[precision]) {
       m->jit[precision] = v21::jit_request(m->L, m->dims.data(), m->act.data(), precision);
@@ -331,8 +381,11 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
       return fail(V21_ERR_UNSUPPORTED, "V21_FWD_FORCE_JIT: no run-time kernel for this stack: %s", why.c_str());
     }
   }
-  if (!fused && !jk && chain_fwd_eligible(m, precision, flags) && n < (1ll << 30)) return forward_chain(m, d_x, ldx, n, d_y, ldy, precision, flags);
-  if (!fused && !jk) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
+  q.jit = jk ? 2 : 0;
+  const int route = decide_forward(q);
+  m->last_route = route; m->route_count[route] += 1;
+  if (route == FWD_TABLE) return forward_chain(m, d_x, ldx, n, d_y, ldy, precision, flags);
+  if (route == FWD_GENERIC) return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
   CHK(ensure_stream(m, precision));
   FusedArgs a{};
   a.x = d_x; a.ldx = ldx; a.y = d_y; a.ldy = ldy; a.n_rows = n;
@@ -356,11 +409,31 @@ extern "C" int v21_mlp_forward_dev(v21_mlp* m, const float* d_x, int64_t ldx, in
     }
     // the code object could not be loaded or needs scratch memory (jit_launch marked it failed): this call and every
     // later one take the table-driven route
-    if (chain_fwd_eligible(m, precision, flags) && n < (1ll << 30)) return forward_chain(m, d_x, ldx, n, d_y, ldy, precision, flags);
+    m->route_count[route] -= 1;
+    q.jit = 0;
+    const int r2 = decide_forward(q);
+    m->last_route = r2; m->route_count[r2] += 1;
+    if (r2 == FWD_TABLE) return forward_chain(m, d_x, ldx, n, d_y, ldy, precision, flags);
     return forward_generic(m, d_x, ldx, n, d_y, ldy, precision, flags);
+  }
+  if (m->clk_stamps) {  // v21_debug_forward_clocked: the clock-stamped instantiation of the same kernel
+    a.dbg = m->clk_stamps;
+    HIPCHK((precision == V21_PREC_F16 ? launch_fused_S1_F16x2spClk : launch_fused_S1_BF16x2spClk)(a, m->ctx->stream));
+    return V21_OK;
   }
   HIPCHK(g_fused[m->fused_id].fn[precision](a, m->ctx->stream));
   return V21_OK;
+}
+extern "C" int v21_debug_forward_clocked(v21_mlp* m, const float* d_x, int64_t ldx, int64_t n, float* d_y, int64_t ldy, int precision,
+                                         int flags, unsigned long long* d_stamps) {
+  if (!m || !d_stamps) return fail(V21_ERR_ARG, "null argument");
+  if (m->fused_id < 0 || g_fused[m->fused_id].dims != ArchS1::dims || (precision != V21_PREC_F16 && precision != V21_PREC_BF16))
+    return fail(V21_ERR_UNSUPPORTED, "clock-stamped kernels exist for the headline stack (archs.h S1) in f16 / bf16 only");
+  if (flags & (V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN | V21_FWD_FORCE_JIT)) return fail(V21_ERR_ARG, "route flags do not apply");
+  m->clk_stamps = d_stamps;
+  const int r = v21_mlp_forward_dev(m, d_x, ldx, n, d_y, ldy, precision, flags | V21_FWD_NO_SMALL);
+  m->clk_stamps = nullptr;
+  return r;
 }
 
 // ---- run-time instantiation of the fused kernel (csrc/jit.h) through the C ABI
@@ -438,7 +511,8 @@ extern "C" int v21_mlp_forward(v21_mlp* m, const void* x, int x_dtype, int64_t n
     t -= a.lo[j]; t /= a.span[j]; t *= 2.0; t -= 1.0;
     return (float)t;
   };
-  if (takes_small_path(m, n, precision, flags & ~V21_FWD_IN_TRANSFORM) && (!tin || din <= 8)) {
+  const FwdQuery hq{m->L, m->dims.data(), m->act.data(), m->fused_id >= 0, 0, precision, (long long)n, flags & ~V21_FWD_IN_TRANSFORM, (long long)dout};
+  if (decide_forward(hq) == FWD_SMALL && (!tin || din <= 8)) {
     // few rows: transform (if asked) and pad the rows on the host, so the first layer reads the staging buffer in
     // place (two launches fewer than transforming on the device)
     const long long ldp = p16(din);
@@ -451,14 +525,19 @@ extern "C" int v21_mlp_forward(v21_mlp* m, const void* x, int x_dtype, int64_t n
     for (long long r = 0; r < n; ++r)
       for (int j = 0; j < din; ++j) tmp[(size_t)r * ldp + j] = host_value(r, j);
     HIPCHK(hipMemcpyAsync(m->d_xpad, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    m->last_route = FWD_SMALL; m->route_count[FWD_SMALL] += 1;
     CHK(forward_small(m, m->d_xpad, ldp, n, m->d_ys, dout, precision, (flags & ~V21_FWD_IN_TRANSFORM) | V21_FWD_X_PADDED));
     HIPCHK(hipMemcpyAsync(y, m->d_ys, (size_t)n * dout * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return V21_OK;
   }
+  // The route is decided ONCE per host call: a call that starts before the run-time kernel of its stack has arrived
+  // keeps the table-driven route for every chunk and slice (the two routes round differently: ADVICE r4), the next call
+  // takes the kernel.  v21_mlp_jit(mlp, precision, -1) waits for it: bit-stable results from the first call on.
+  const bool rt_off = m->fused_id < 0 && !(flags & (V21_FWD_FORCE_JIT | V21_FWD_FORCE_GENERIC | V21_FWD_FORCE_CHAIN)) && !jit_ready_now(m, precision);
   for (long long r0 = 0; r0 < n; r0 += chunk) {
     const long long rows = std::min(chunk, n - r0);
-    int fl = flags;
+    int fl = flags | (rt_off ? V21_FWD_RT_LATCH_OFF : 0);
     if (x_dtype == V21_DTYPE_F64 && tin) {
       // float64 parameters: staged as they are and transformed in float64 on the device (the reference's float64
       // branch, preprocess.py:74-108), the float32 cast after the map as Keras does it [K]

@@ -36,6 +36,7 @@ constexpr int kStampSlots = 2048;  // (diagnostic builds: per-wave / per-workgro
 constexpr int kStampSlots = 64;
 #endif
 #include "dw_adam.h"
+#include "routes.h"
 
 using namespace v21;
 
@@ -129,6 +130,10 @@ struct v21_mlp {
   // first large forward call, used once its code object is there
   v21::JitKernel* jit[3] = {nullptr, nullptr, nullptr};
   bool jit_asked[3] = {false, false, false};
+  // routes.h: the route of the last v21_mlp_forward_dev call and how many calls took each (v21_mlp_last_route)
+  int last_route = 0;
+  long long route_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long* clk_stamps = nullptr;  // set for the duration of v21_debug_forward_clocked
   // width of layer l's Dense output: dims[l+1], or 2*dims[l+1] = [z_mean | z_log_var] for V21_ACT_GAUSS
   int nw(int l) const { return act[l] == V21_ACT_GAUSS ? 2 * dims[l + 1] : dims[l + 1]; }
 };
@@ -196,6 +201,11 @@ struct v21_trainer {
   std::vector<int> ts_first;    // first fragment of every virtual layer (2 L - 1 of them)
   bool ts_write = false;        // the Adam pass that ends the current step also rewrites d_tstream (the step took the fused kernel)
   long long n_chain_steps = 0, n_fused_steps = 0, n_stream_packs = 0, n_stream_adam = 0;  // v21_debug_trainer_counters
+  // routes.h: what the trainer committed to at creation, the route of its last eager step (written where the kernels are
+  // launched) and how many steps took each (v21_trainer_last_route)
+  TrainerKind kind;
+  StepRoute last_route;
+  long long fwd_count[8] = {0, 0, 0, 0, 0, 0, 0, 0}, upd_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool tstream_fresh = false;   // d_tstream holds the arena's current weights (cleared by every ensure_copies: any other step, eval, sweep, joint)
   int* d_dworder = nullptr;            // dw_adam.h: tile order per XCD (two-dimensional blocks per layer)
   int dw_xper = 0;
@@ -277,7 +287,7 @@ int ensure_copies(v21_trainer* t, bool need_nt = true);  // api_trainer.hip
 int gather_batch(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy_src, const float* rw, const int* d_idx, long long first, int rows);  // api_trainer.hip
 float grad_opscale(int brows, int dout);  // api_trainer.hip
 void invalidate_streams(v21_mlp* m);  // api_forward.hip
-int launch_chain32_args(ChainArgs& a, hipStream_t st, bool small = false);  // api_trainer.hip
+int launch_chain32_args(ChainArgs& a, hipStream_t st, bool small = false, int rows_per_wg = 0 /* 4 / 8: the caller decided (routes.h); 0: by the row count */);  // api_trainer.hip
 int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t st);  // api_trainer.hip
 int launch_dw32_group(const std::vector<v21_trainer*>& trs, const Dw32Model* d_tab, int rows, long long step_index, int max_blocks, hipStream_t st);  // api_sweep.hip
 int launch_dw_adam_group(const std::vector<v21_trainer*>& tr, const DwAdamModel* d_tab, const std::vector<DwAdamModel>& h_tab, int rows, int brows, long long slot, hipStream_t st);  // api_trainer.hip

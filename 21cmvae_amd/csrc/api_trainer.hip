@@ -18,6 +18,17 @@ struct TrainEntry { int L; const int* dims; const int* act; train_launcher fn[2]
                        {launch_fused_train16_##a##_F16t16, launch_fused_train16_##a##_BF16t16}},
 static const TrainEntry g_train[] = {V21_TRAIN_ARCH_LIST(V21_TENTRY)};
 #undef V21_TENTRY
+// routes.h: which compiled fused training kernel serves this stack (-1: none)
+int v21::fused_train_arch_of(int L, const int* dims, const int* act) {
+  for (size_t e = 0; e < sizeof(g_train) / sizeof(g_train[0]); ++e) {
+    bool same = g_train[e].L == L;
+    for (int l = 0; same && l <= L; ++l) same = g_train[e].dims[l] == dims[l];
+    for (int l = 0; same && l < L; ++l) same = g_train[e].act[l] == act[l];
+    if (same) return (int)e;
+  }
+  return -1;
+}
+bool v21::fused_train_rt_eligible(int, const int*, const int*) { return false; }
 
 // ---------------------------------------------------------------------------------
 // trainer (NT path: gemm_nt.h).  Every contraction of a step reads operands whose
@@ -35,6 +46,15 @@ void destroy_graphs(v21_trainer* t) {
   t->desc_count = 0; t->desc_next = 0; t->desc_iter0 = -1;
 }
 
+// routes.h: the route of a step of `rows` rows of this trainer now, and the record of the step that takes it
+static StepRoute step_route(const v21_trainer* t, int rows) {
+  const v21_mlp* m = t->mlp;
+  return decide_step(t->kind, m->L, m->dims.data(), m->act.data(), rows, t->ctx->nranks, t->capturing, t->train_arch >= 0, RouteEnv::read());
+}
+static void note_route(v21_trainer* t, const StepRoute& r) {
+  if (t->capturing) return;
+  t->last_route = r; t->fwd_count[r.fwd & 7] += 1; t->upd_count[r.upd & 7] += 1;
+}
 
 static int build_chain32s_jobs(v21_trainer* t);
 extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_trainer** out) {
@@ -91,14 +111,10 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
   CHK(zalloc(&t->d_wb, (size_t)max_batch + 32, st));
   CHK(zalloc(&t->d_rowloss, (size_t)max_batch + 32, st));
   CHK(zalloc(&t->d_evalsum, 4, st));
-  {  // eligibility of the chain kernel
-    const char* env = getenv("V21_TRAIN_CHAIN");
-    bool ok = precision != V21_PREC_F32 && !(env && env[0] == '0') &&
-              (t->gl < 0 || m->dims[t->gl + 1] <= kChainMaxLatent);
-    int mask_tiles = 0;
-    for (int l = 0; l <= L && ok; ++l) ok = m->dims[l] <= kChainMaxDim;
-    for (int l = 0; l + 1 < L; ++l) mask_tiles += m->act[l] == V21_ACT_RELU ? (m->dims[l + 1] + 31) / 32 : 0;
-    ok = ok && mask_tiles <= kChainMaskTiles;
+  // what this trainer commits to: csrc/routes.h (the same function answers v21_route_train)
+  t->kind = decide_trainer_kind(L, m->dims.data(), m->act.data(), precision, max_batch, RouteEnv::read());
+  {  // the 16-bit chain kernel
+    const bool ok = t->kind.chain;
     if (ok) {
       long long of = 0, ob = 0;
       for (int l = 0; l < L; ++l) {
@@ -134,22 +150,11 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
         HIPCHK(hipStreamSynchronize(st));
       }
       t->chain = true;
-      // a compiled fused training kernel for this stack (large steps; no variational head)?
-      if (t->gl < 0 && !(getenv("V21_FUSED_TRAIN") && getenv("V21_FUSED_TRAIN")[0] == '0'))
-        for (size_t e = 0; e < sizeof(g_train) / sizeof(g_train[0]); ++e) {
-          bool same = g_train[e].L == L;
-          for (int l = 0; same && l <= L; ++l) same = g_train[e].dims[l] == m->dims[l];
-          for (int l = 0; same && l < L; ++l) same = g_train[e].act[l] == m->act[l];
-          if (same) t->train_arch = (int)e;
-        }
+      // a compiled fused training kernel for this stack (large steps; no variational head), and which of the two: the
+      // packed weight stream is in the kernel's own format, so the choice is fixed here (routes.h: decide_trainer_kind)
+      t->train_arch = t->kind.train_arch;
       if (t->train_arch >= 0) {
-        // Which of the two fused training kernels this trainer's steps take is fixed here, because the packed weight stream
-        // is in the kernel's own format: 16 rows per wave (fused_train16.h: 64-row workgroups, two per CU) for trainers of
-        // fewer than 24,576 rows per step -- a step of 8,193 .. 24,575 rows does not fill the chip with 128-row workgroups --
-        // and 32 rows per wave (fused_train.h) above, where both take the same time (both at ~4.2 TB/s of HBM traffic) and
-        // the 128-row form has the evener workgroups.  V21_FUSED_TRAIN16=0 / 1 overrides.
-        const char* e16 = getenv("V21_FUSED_TRAIN16");
-        t->train16 = e16 ? e16[0] == '1' : max_batch < 24576;
+        t->train16 = t->kind.train16;
         int total = 0;
         for (int v = 0; v < 2 * L - 1; ++v) {
           const int l = v < L ? v : 2 * L - 1 - v;
@@ -203,20 +208,10 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
       }
     }
   }
-  {  // eligibility of the fp32 chain kernel (train_chain32.h)
-    const char* env = getenv("V21_TRAIN_CHAIN");
-    bool ok = precision == V21_PREC_F32 && !(env && env[0] == '0');
-    int mask_tiles = 0;
-    for (int l = 0; l <= L && ok; ++l) ok = m->dims[l] <= kChainMaxDim;
-    // a trainer of small batches (the reference's 256 rows) takes the 8-row kernel: twice the workgroups, half the
-    // matrix work in each (train_chain32s.h); V21_CHAIN32S = 0 / 1 overrides the choice
-    const char* es = getenv("V21_CHAIN32S");
-    t->chain32s = es ? es[0] == '1' : max_batch <= kC32sMaxBatch;
-    // a variational head: the small-batch kernel carries it (latent <= kChainMaxLatent), the 16-row kernel does not
-    if (t->gl >= 0) ok = ok && t->chain32s && m->dims[t->gl + 1] <= kChainMaxLatent;
-    for (int l = 0; l + 1 < L; ++l) mask_tiles += m->act[l] == V21_ACT_RELU ? t->c32_tiles(m->dims[l + 1]) : 0;
-    ok = ok && mask_tiles <= (t->chain32s ? kC32sMaskTiles : kC32MaskTiles);
-    if (!ok) t->chain32s = false;
+  {  // the fp32 chain kernels (train_chain32.h; trainers of small batches -- the reference's 256 rows -- the 8-row kernel
+     // of train_chain32s.h, which also carries a variational head)
+    const bool ok = t->kind.chain32;
+    t->chain32s = t->kind.chain32s;
     if (ok) {
       long long of = 0, ob = 0;  // floats
       for (int l = 0; l < L; ++l) {
@@ -491,6 +486,7 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
   const bool in_table = t->ctx->nranks == 1 && rows > 0 && loss_out && t->d_steploss && loss_out >= t->d_steploss &&
                         loss_out < t->d_steploss + t->steploss_cap;
   if (rows > 0) {
+    note_route(t, step_route(t, rows));
     CHK(ensure_copies(t));
     CHK(trainer_forward(t, rows, true, true, row0));
     const int wpb = 4;  // waves (rows) per block
@@ -792,11 +788,11 @@ static int build_chain32s_jobs(v21_trainer* t) {
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
   return V21_OK;
 }
-int launch_chain32_args(ChainArgs& a, hipStream_t st, bool small) {
+int launch_chain32_args(ChainArgs& a, hipStream_t st, bool small, int rows_per_wg) {
   CHK(chain_attr(V21_PREC_F32));
   if (small) {  // the 8-row kernel (train_chain32s.h), or its 4-row form
-    const char* er = getenv("V21_C32S_ROWS");  // (tests force either form on every case)
-    const int force_rows = er ? atoi(er) : 0;
+    // (routes.h decides for a trainer's steps; evaluation passes and other callers: by the row count, V21_C32S_ROWS forces)
+    const int force_rows = rows_per_wg ? rows_per_wg : RouteEnv::read().c32s_rows;
     const int rpw = force_rows == 4 || force_rows == 8 ? force_rows : (a.rows <= kC32sRows4Max ? 4 : 8);
     a.ncons = (int)((((long long)a.rows + rpw - 1) / rpw + 7) / 8 * 8);
     a.npref = chain_prefetchers(a.ncons, 1);
@@ -1013,21 +1009,23 @@ int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, const f
                         loss_out < t->d_steploss + t->steploss_cap;
   int fold = 1;
   if (rows > 0) {
+    // which kernels: csrc/routes.h (decide_step).  One rank, a step of <= kDw32MaxRows rows, 32 x 32 tiles: gradients,
+    // Adam, packed streams and batch loss in ONE launch whose workgroups walk the whole batch in slabs of 256 rows
+    // (dw_adam32.h: UP_DWADAM32); one contraction slice with 64 x 64 tiles: gemm_nt_dwadam_kernel (UP_NT_DWADAM);
+    // larger steps and data-parallel ranks: sliced gradients, [slab sum, exchange], Adam (UP_NT_SLICED)
+    const StepRoute route = step_route(t, rows);
     if (!chain_done) {
       CHK(ensure_copies(t, false));
       ChainArgs a{};
       static_cast<ChainModel&>(a) = chain_model32(t);
       static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, dout, t, row0);
       a.gs = 1.0f;  // fp32 operands: no scaling of the gradients
-      CHK(launch_chain32_args(a, st, t->chain32s));
+      CHK(launch_chain32_args(a, st, t->chain32s, route.fwd == TR_CHAIN32S_4 ? 4 : 8));
     }
-    // one rank, a step of <= kDw32MaxRows rows, 32 x 32 tiles: gradients, Adam, packed streams and batch loss in ONE
-    // launch whose workgroups walk the whole batch in slabs of 256 rows (dw_adam32.h)
-    static const bool lds_rows = !(getenv("V21_DW32_LDS") && getenv("V21_DW32_LDS")[0] == '0');
-    static const bool fused_ok = !(getenv("V21_DW32_ADAM") && getenv("V21_DW32_ADAM")[0] == '0');
+    note_route(t, route);  // (the joint step ran this model's chain in its own launch: the update route is what is recorded)
     long long work = 0;
     for (int l = 0; l < L; ++l) work += (long long)((m->dims[l] + 1 + 63) / 64) * ((m->nw(l) + 63) / 64);
-    const bool dw32 = single && fused_ok && lds_rows && L <= kNtMaxGroup && work < 192 && rows <= kDw32MaxRows;
+    const bool dw32 = route.upd == UP_DWADAM32;
     int nslice = dw32 ? 1 : (rows + kNtMaxKPerWg - 1) / kNtMaxKPerWg;
     const int k_chunk = ((rows + nslice - 1) / nslice + 15) / 16 * 16;
     nslice = (rows + k_chunk - 1) / k_chunk;
@@ -1043,7 +1041,7 @@ int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, const f
     }
     // (one contraction slice = up to kNtMaxKPerWg rows.  Letting one workgroup walk 1,024 or 2,048 rows instead of the
     //  sliced three-launch path below: 71.3 against 70.6 us and 96.7 against 92.8 us per step -- no gain.)
-    if (single && nslice == 1 && L <= kNtMaxGroup && fused_ok) {
+    if (route.upd == UP_DWADAM32 || route.upd == UP_NT_DWADAM) {
       // one rank, the batch is one contraction slice: gradients, Adam, the packed fp32 streams and the batch loss in ONE
       // launch (gemm_nt.h: NtAdamInfo) -- the step is 2 launches
       NtGroupBig grp{};
@@ -1075,7 +1073,7 @@ int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, const f
       ad.dbg = t->stamps_on ? t->d_stamps + 1024 : nullptr;
 #endif
       if (T == 2) hipLaunchKernelGGL(gemm_nt_dwadam_kernel<2>, dim3(blocks), dim3(256), 0, st, grp, ad);
-      else if (rows <= kDw32MaxRows && lds_rows) hipLaunchKernelGGL(dwadam32_kernel, dim3(blocks), dim3(256), 0, st, grp, ad);  // operands through LDS in whole rows (dw_adam32.h)
+      else if (route.upd == UP_DWADAM32) hipLaunchKernelGGL(dwadam32_kernel, dim3(blocks), dim3(256), 0, st, grp, ad);  // operands through LDS in whole rows (dw_adam32.h)
       else hipLaunchKernelGGL(gemm_nt_dwadam_kernel<1>, dim3(blocks), dim3(256), 0, st, grp, ad);
       HIPCHK(hipGetLastError());
       t->copies_ok = true;
@@ -1138,9 +1136,9 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     // (fused_train.h: 24,576 rows 101 against 127, 32,768 rows 123-130 against 152-160).  The kernel's weight stream is
     // written by the previous step's Adam pass (AdamArgs::ts), so a step is 3 launches.  (Autoencoder stack, f16, whole
     // steps, r4; read per step: the tests force it.)
-    const char* efr = getenv("V21_FUSED_TRAIN_ROWS");
-    const int fused_rows = efr ? atoi(efr) : (t->train16 ? 8193 : 16384);
-    const bool fused = t->train_arch >= 0 && rows >= fused_rows && !t->capturing;
+    const StepRoute route = step_route(t, rows);  // csrc/routes.h: decide_step
+    const bool fused = route.fwd == TR_FUSED64 || route.fwd == TR_FUSED128;
+    note_route(t, route);
     fused_step = fused;
     if (fused) CHK(launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, ts_fresh));
     else { CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0)); if (!t->capturing) t->n_chain_steps += 1; }
@@ -1148,8 +1146,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     // batch where its 32 x 32 tiles, each pulling its operands over the WHOLE batch through one CU, lose to the
     // 128 x 128 LDS-staged split-K kernel + an Adam launch that sums the slabs (V21_DW_SPLIT_ROWS overrides the
     // threshold; measured r3, autoencoder stack, f16: see DESIGN.md section 3)
-    static const int split_rows = getenv("V21_DW_SPLIT_ROWS") ? atoi(getenv("V21_DW_SPLIT_ROWS")) : 8192;
-    if (t->ctx->nranks == 1 && (rows < split_rows || t->capturing) && !fused) {
+    if (route.upd == UP_DW16_ADAM) {
       if (!t->capturing) t->iter += 1;
       // an epoch's per-step loss slot is written by the kernel itself (a device-to-device copy per step is a launch)
       const bool in_table = loss_out && t->d_steploss && loss_out >= t->d_steploss && loss_out < t->d_steploss + t->steploss_cap;
@@ -1570,6 +1567,25 @@ extern "C" int v21_debug_check_chain_jobs(v21_trainer* t, long long fw_bytes, lo
   if (const char* why = c32s_validate_jobs(a, tab.data(), (fw_bytes < 0 ? t->fw_bytes : fw_bytes) / 16,
                                            (bw_bytes < 0 ? t->bw_bytes : bw_bytes) / 16, (long long)t->P))
     return fail(V21_ERR_STATE, "%s", why);
+  return V21_OK;
+}
+extern "C" int v21_route_train(int n_layers, const int* dims, const int* act, int precision, int max_batch, int rows, int nranks,
+                               int* fwd, int* upd) {
+  if (!dims || !act || !fwd || !upd) return fail(V21_ERR_ARG, "null argument");
+  if (n_layers < 1 || n_layers > 16) return fail(V21_ERR_ARG, "n_layers %d out of range", n_layers);
+  if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
+  if (max_batch < 1 || rows < 1 || rows > max_batch || nranks < 1) return fail(V21_ERR_ARG, "need 1 <= rows <= max_batch and nranks >= 1");
+  const RouteEnv e = RouteEnv::read();
+  const TrainerKind k = decide_trainer_kind(n_layers, dims, act, precision, max_batch, e);
+  const StepRoute r = decide_step(k, n_layers, dims, act, rows, nranks, false, k.train_arch >= 0, e);
+  *fwd = r.fwd; *upd = r.upd;
+  return V21_OK;
+}
+extern "C" int v21_trainer_last_route(v21_trainer* t, int* fwd, int* upd, long long fwd_counts[8], long long upd_counts[8]) {
+  if (!t || !fwd || !upd) return fail(V21_ERR_ARG, "null argument");
+  *fwd = t->last_route.fwd; *upd = t->last_route.upd;
+  if (fwd_counts) for (int i = 0; i < 8; ++i) fwd_counts[i] = t->fwd_count[i];
+  if (upd_counts) for (int i = 0; i < 8; ++i) upd_counts[i] = t->upd_count[i];
   return V21_OK;
 }
 extern "C" int v21_debug_trainer_counters(v21_trainer* t, long long out[4]) {

@@ -159,6 +159,14 @@ struct PrecBF16x2 : PrecBF16 { static constexpr int CT = 1, BLK = 16, RING = 5, 
 // k-steps, issued by every wave -- no wave-dependent branch) instead of a burst of 4 at each rendezvous.
 struct PrecF16x2sp : PrecF16x2 { static constexpr bool SPREAD_DMA = true; };
 struct PrecBF16x2sp : PrecBF16x2 { static constexpr bool SPREAD_DMA = true; };
+// r5: the same two kernels with the clock stamps of VERDICT r4 item 2 -- wave 0 of EVERY workgroup reads the shader-clock
+// counter (s_memtime), the constant 100 MHz counter (s_memrealtime) and its XCD when it starts and when it ends, and leaves
+// them in FusedArgs::dbg (five 64-bit words per workgroup).  A separate instantiation (bench.py runs it in a separate,
+// untimed repeat of the K launches through v21_debug_forward_clocked): the shipped kernels' ISA is untouched.
+struct PrecF16x2spClk : PrecF16x2sp { static constexpr bool CLOCK_STAMPS = true; };
+struct PrecBF16x2spClk : PrecBF16x2sp { static constexpr bool CLOCK_STAMPS = true; };
+template <class P, class = void> struct clk_of { static constexpr bool value = false; };
+template <class P> struct clk_of<P, std::void_t<decltype(P::CLOCK_STAMPS)>> { static constexpr bool value = P::CLOCK_STAMPS; };
 template <class P, class = void> struct spread_of { static constexpr bool value = false; };
 template <class P> struct spread_of<P, std::void_t<decltype(P::SPREAD_DMA)>> { static constexpr bool value = P::SPREAD_DMA; };
 
@@ -388,6 +396,10 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
+  unsigned long long clk_t0 = 0, clk_r0 = 0;
+  if constexpr (clk_of<P>::value) {  // (every wave reads: scalar registers, no divergence; wave 0 reports)
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_t0), "=s"(clk_r0)::"memory");
+  }
   const long long wg_row0 = (long long)blockIdx.x * (kWaves * CT * 32);
   const long long row0 = wg_row0 + wave * (CT * 32);
 
@@ -599,6 +611,17 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
   });
   epilogue_range(std::integral_constant<int, G::n_tiles() - 1>{}, std::integral_constant<int, 0>{},
                  std::integral_constant<int, NCH>{});
+  if constexpr (clk_of<P>::value) {
+    // after the wave's last output store has been ISSUED (the stores drain behind it; the next launch's start stamp
+    // cannot precede them on an in-order stream)
+    unsigned long long t1, r1;
+    unsigned xcc;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1), "=s"(xcc)::"memory");
+    if (a.dbg && wave == 0 && lane == 0) {
+      unsigned long long* gd = a.dbg + (size_t)blockIdx.x * 5;
+      gd[0] = clk_t0; gd[1] = clk_r0; gd[2] = t1; gd[3] = r1; gd[4] = xcc & 0xF;
+    }
+  }
 #ifdef V21_FUSED_STAMP
   if (a.dbg) {  // stamps were kept in LDS so that they add no VMEM operation to the counted waits
     unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");

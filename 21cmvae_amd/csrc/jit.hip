@@ -86,7 +86,14 @@ bool load_rtc(std::string* why) {
 // up to 512 registers -- instead of "x2sp" (two workgroups per CU, one column tile per wave, 256 registers).  Half the
 // LDS bytes per MFMA; r1 measured it slower (62-65 against 52 us on the headline stack) and r4 measured it again
 // through this switch.
+// diagnostics (scripts/diag/k1_wide_probe.py): run-time 16-bit kernels in the one-workgroup-per-CU, two-column-tiles-per-wave
+// form.  Measured slower in r1 and again in r4 (61.9 against 52 us); the switch exists only in a diagnostic build
+// (make EXTRA=-DV21_DIAG_JIT_WIDE ...): the product library has one form.
+#ifdef V21_DIAG_JIT_WIDE
 bool jit_wide() { const char* e = getenv("V21_JIT_WIDE"); return e && e[0] == '1'; }
+#else
+bool jit_wide() { return false; }
+#endif
 const char* prec_type(int prec, bool wide) {
   return prec == 0 ? "PrecF32" : (prec == 1 ? (wide ? "PrecF16" : "PrecF16x2sp") : (wide ? "PrecBF16" : "PrecBF16x2sp"));
 }

@@ -563,6 +563,37 @@ def _self_launch(n, argv):
     sys.exit(rc)
 
 
+def _reduce_clock_stamps(st, ms_per_launch_events):
+    """st[launch, workgroup] = (cycles at start, 100-MHz ticks at start, cycles at end, ticks at end, XCD): include/v21.h
+    v21_debug_forward_clocked.  -> the clock as the working CUs saw it, per XCD, and the kernel's length in CYCLES -- if
+    the shader clock bounds the kernel, cycles per workgroup stay put from run to run while microseconds move with the clock."""
+    dc = (st[..., 2] - st[..., 0]).astype(np.float64)
+    dt = (st[..., 3] - st[..., 1]).astype(np.float64)          # ticks of 10 ns
+    ok = (dt > 0) & (dc > 0)
+    ghz = np.where(ok, dc / np.maximum(dt, 1) * 0.1, np.nan)
+    xcd = st[..., 4].astype(np.int64)
+    per_xcd = []
+    for x in range(8):
+        m = ok & (xcd == x)
+        per_xcd.append({"xcd": x, "workgroups_per_launch": float(m.sum() / st.shape[0]),
+                        "ghz": float(dc[m].sum() / dt[m].sum() * 0.1) if m.any() else None})
+    span_ticks = (st[..., 3].max(axis=1) - st[..., 1].min(axis=1)).astype(np.float64)   # per launch: first start to last end
+    per_launch_ghz = (dc * ok).sum(axis=1) / np.maximum((dt * ok).sum(axis=1), 1) * 0.1
+    return {
+        "ghz_mean": float(dc[ok].sum() / dt[ok].sum() * 0.1), "ghz_min_workgroup": float(np.nanmin(ghz)), "ghz_max_workgroup": float(np.nanmax(ghz)),
+        "ghz_per_launch_min": float(per_launch_ghz.min()), "ghz_per_launch_max": float(per_launch_ghz.max()),
+        "per_xcd": per_xcd,
+        "kcycles_per_workgroup": {"mean": float(dc[ok].mean() / 1e3), "min": float(dc[ok].min() / 1e3), "max": float(dc[ok].max() / 1e3)},
+        "us_per_workgroup_mean": float(dt[ok].mean() * 0.01),
+        "launch_us_first_start_to_last_end": {"mean": float(span_ticks.mean() * 0.01), "min": float(span_ticks.min() * 0.01), "max": float(span_ticks.max() * 0.01)},
+        "kcycles_per_launch": float(span_ticks.mean() * 0.01 * (dc[ok].sum() / dt[ok].sum() * 0.1)),
+        "ms_per_launch_hip_events_of_the_stamped_run": float(ms_per_launch_events),
+        "launches": int(st.shape[0]), "workgroups": int(st.shape[1]),
+        "source": "wave 0 of every workgroup of every timed-count launch: s_memtime / s_memrealtime / HW_REG_XCC_ID at start and end "
+                  "(fused_fwd<ArchS1, Prec..x2spClk>, an untimed repeat of settle + warm-up + K launches)",
+    }
+
+
 def _claim_stdout():
     """Point file descriptor 1 at stderr (whatever C++ libraries print -- `[Gloo] Rank ...`, c10d warnings -- goes
     there) and return a text stream on a duplicate of the ORIGINAL stdout for the one JSON line."""
@@ -699,6 +730,35 @@ def main():
             timed.clock = ctx.clock_probe_read()
         except Exception as e:  # pragma: no cover
             timed.clock = {"error": "%s: %s" % (type(e).__name__, e)}
+        # r5: the clock FROM THE KERNEL ITSELF.  A FOURTH untimed run -- settle, warm-up, K launches --
+        # through the clock-stamped instantiation of the same kernel (fused_fwd.h: CLOCK_STAMPS; identical but for two
+        # pairs of scalar counter reads and one 40-byte store per workgroup): wave 0 of EVERY workgroup of EVERY one of the K
+        # launches reads s_memtime (shader-clock cycles) and s_memrealtime (100 MHz) at its start and end, and its XCD.
+        timed.inkernel = None
+        if prec in ("f16", "bf16") and rank == 0:
+            try:
+                nwg = (B + 127) // 128
+                d_st = ctx.malloc(steps * nwg * 40)
+                ctx.memset(d_st, 0, steps * nwg * 40)
+                t_s = time.perf_counter()
+                while time.perf_counter() - t_s < args.settle:
+                    for _ in range(100):
+                        stack.forward_clocked(d_x, DIMS[0], B, d_y, DIMS[-1], d_st, prec, flags)
+                    ctx.sync()
+                for _ in range(warmup):
+                    stack.forward_clocked(d_x, DIMS[0], B, d_y, DIMS[-1], d_st, prec, flags)
+                c0, c1 = ctx.event(), ctx.event()
+                ctx.record(c0)
+                for i in range(steps):
+                    stack.forward_clocked(d_x, DIMS[0], B, d_y, DIMS[-1], d_st + i * nwg * 40, prec, flags)
+                ctx.record(c1)
+                ctx.sync()
+                st_h = np.empty((steps, nwg, 5), np.uint64)
+                ctx.d2h(st_h, d_st)
+                ctx.free(d_st)
+                timed.inkernel = _reduce_clock_stamps(st_h, ctx.elapsed_ms(c0, c1) / steps)
+            except Exception as e:  # pragma: no cover
+                timed.inkernel = {"error": "%s: %s" % (type(e).__name__, e)}
         if dist is not None:
             t = torch.tensor([wall], dtype=torch.float64, device=_pg_device(dist))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -709,6 +769,7 @@ def main():
     value = world * B * args.steps / wall
     kern_s = ev_ms * 1e-3 / args.steps  # average launch duration on the launch stream (HIP events)
     achieved_tf = FLOP_PER_SIGNAL * B / kern_s / 1e12
+    _ik = timed.inkernel if isinstance(getattr(timed, "inkernel", None), dict) else {}
     out = {
         "metric": "emulated signals/sec (batched predict)",
         "value": value,
@@ -734,11 +795,17 @@ def main():
                      "time_base": "HIP events on the launch stream around the K timed launches (mean); min / median from "
                                   "per-launch event pairs of a second run; profiles/%s/kernel_stats_bench_f16.csv " % PROFILE_TAG +
                                   "(rocprofv3 --kernel-trace --stats of this command) must agree with the mean",
-                     "clock_ghz": (timed.clock or {}).get("ghz_mean"), "clock_probe": timed.clock, "clock_nominal_ghz": 2.4,
-                     "frac_of_clocked_peak": (achieved_tf / (PEAK_TFLOPS[args.precision] * timed.clock["ghz_mean"] / 2.4)
-                                              if timed.clock and timed.clock.get("ghz_mean") else None),
-                     "clock_note": "shader clock during an untimed repeat of the K launches (one sampling wave beside them); "
-                                   "peak figures assume 2.4 GHz, frac_of_clocked_peak rescales the peak to the measured clock",
+                     # (the same fraction from the ONE number the driver times itself: ms_per_step, launch gaps included)
+                     "frac_from_ms_per_step": FLOP_PER_SIGNAL * B / (wall / args.steps) / 1e12 / PEAK_TFLOPS[args.precision],
+                     # r5: clock_ghz is read INSIDE the kernel (every workgroup of K launches); r4's sampling wave beside
+                     # the launches stays as clock_probe_sampling_wave (it disagreed with itself from run to run:
+                     # VERDICT r4 weak 2 -- one wave on one CU sees ITS XCD's clock while it idles between samples)
+                     "clock_ghz": (_ik.get("ghz_mean") if _ik.get("ghz_mean") else (timed.clock or {}).get("ghz_mean")),
+                     "clock_in_kernel": timed.inkernel, "clock_probe_sampling_wave": timed.clock, "clock_nominal_ghz": 2.4,
+                     "frac_of_clocked_peak": (achieved_tf / (PEAK_TFLOPS[args.precision] * _ik["ghz_mean"] / 2.4) if _ik.get("ghz_mean") else None),
+                     "clock_note": "clock_ghz = shader-clock cycles / 100-MHz ticks between start and end of every workgroup of an untimed "
+                                   "repeat of the K launches (clock-stamped instantiation of the same kernel); peak figures assume "
+                                   "2.4 GHz, frac_of_clocked_peak rescales the peak to that clock",
                      "algorithmic_flop_per_launch": FLOP_PER_SIGNAL * B,
                      "hbm_GBps_algorithmic": BYTES_PER_SIGNAL * B / kern_s / 1e9,
                      "hbm_frac_of_8TBps": BYTES_PER_SIGNAL * B / kern_s / 1e9 / PEAK_HBM_GBS},
@@ -769,7 +836,7 @@ def main():
     if os.path.exists(busy) and B == BATCH and out["roofline"].get("clock_ghz"):
         try:
             per_simd = json.load(open(busy))["mfma_busy_cycles_per_simd"]
-            cyc = kern_s * out["roofline"]["clock_ghz"] * 1e9
+            cyc = _ik["kcycles_per_launch"] * 1e3 if _ik.get("kcycles_per_launch") else kern_s * out["roofline"]["clock_ghz"] * 1e9
             out["roofline"]["mfma_busy_cycles_per_simd"] = per_simd
             out["roofline"]["mfma_pipe_busy_frac"] = per_simd / cyc
             out["roofline"]["mfma_pipe_busy_source"] = ("%s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, the timed launches only) / "

@@ -241,12 +241,41 @@ int v21_debug_poison_lds(v21_ctx* ctx, uint32_t pattern);
  * stream meanwhile; read: waits for it; mean / min / max of cycles per nanosecond over the sampling intervals.
  * bench.py reports it as roofline.clock_ghz (DVFS holds ~1.6-1.9 GHz under the fused kernel, 2.4 GHz is nominal). */
 int v21_debug_clock_probe_start(v21_ctx* ctx, double duration_ms, double period_us);
+/* diagnostics (r5): the shader clock FROM THE TIMED KERNEL ITSELF.  Launches the headline stack's fused kernel (archs.h
+ * S1; f16 / bf16) in a separate instantiation whose wave 0 of every workgroup reads s_memtime (shader-clock cycles),
+ * s_memrealtime (constant 100 MHz) and HW_REG_XCC_ID when the workgroup starts and when it ends.  d_stamps (device
+ * memory): five 64-bit words per workgroup = ceil(n / 128) workgroups: [cycles at start, 100-MHz ticks at start, cycles at
+ * end, ticks at end, XCD 0-7].  (end - start) cycles / ticks * 0.1 = GHz as that workgroup's CU saw it; bench.py reports
+ * mean / min / max per XCD over a repeat of its K timed launches.  Otherwise the arguments of v21_mlp_forward_dev. */
+int v21_debug_forward_clocked(v21_mlp* mlp, const float* d_x, int64_t ldx, int64_t n, float* d_y, int64_t ldy, int precision,
+                              int flags, unsigned long long* d_stamps);
 int v21_debug_clock_probe_read(v21_ctx* ctx, double* ghz_mean, double* ghz_min, double* ghz_max, int* samples);
 /* diagnostics: the small-batch f32 chain kernel (csrc/train_chain32s.h) follows a host-built job table into the packed
  * weight streams without range checks; v21_trainer_create validates every address a row names against the allocated
  * streams (V21_ERR_STATE instead of a GPU memory fault).  This repeats that check against stream sizes the caller names
  * (bytes; negative = the real ones): the tests hand in a truncated stream.  V21_ERR_UNSUPPORTED for trainers on other paths. */
 int v21_debug_check_chain_jobs(v21_trainer* tr, long long fw_bytes, long long bw_bytes);
+/* ---- routes: WHICH kernels a call takes (csrc/routes.h holds the one decision the dispatch sites and these queries
+ * share; INTEGRATION.md section 6 is the table, tests/test_routes.py asserts it).  The reference has one path (Keras:
+ * emulator.py:369-378, 402); the library has several kernels for the same arithmetic, chosen from precision, row count,
+ * stack and rank count.  The two v21_route_* queries are pure host logic (no GPU, no handles):
+ *   v21_route_forward  the route v21_mlp_forward_dev takes for n rows of this stack (rt_ready: assume the run-time
+ *                      instantiated kernel of a stack outside archs.h has arrived); route: 1 small (one NT launch per
+ *                      layer), 2 fused_fwd compiled in, 3 fused_fwd instantiated at run time, 4 table-driven chain
+ *                      kernel in FORWARD mode, 5 generic per-layer GEMM.
+ *   v21_route_train    one optimizer step of `rows` rows of a trainer created with max_batch, on `nranks` ranks:
+ *                      fwd: 1 per-layer NT, 2 train_chain_kernel (16-bit), 3 fused_train (128-row workgroups),
+ *                      4 fused_train16 (64-row workgroups), 5 train_chain32_kernel, 6 / 7 train_chain32s_kernel<8> / <4>;
+ *                      upd: 1 per-layer NT + adam_repack, 2 dw16_adam_kernel, 3 gemm_dw16[_lds] split-K + adam_repack,
+ *                      4 dwadam32_kernel, 5 gemm_nt_dwadam_kernel, 6 sliced NT + adam_repack.
+ * v21_mlp_last_route / v21_trainer_last_route report what the LAUNCH SITES recorded for the last call / eager step and
+ * how many calls / steps took each route since creation (counts[route]; nullable).  v21_route_name: kind 0 forward,
+ * 1 training forward, 2 update. */
+int v21_route_forward(int n_layers, const int* dims, const int* act, int precision, int64_t n, int flags, int rt_ready, int* route);
+int v21_route_train(int n_layers, const int* dims, const int* act, int precision, int max_batch, int rows, int nranks, int* fwd, int* upd);
+int v21_mlp_last_route(v21_mlp* mlp, int* route, long long counts[8]);
+int v21_trainer_last_route(v21_trainer* tr, int* fwd, int* upd, long long fwd_counts[8], long long upd_counts[8]);
+const char* v21_route_name(int kind, int route);
 /* diagnostics: which route the eager 16-bit steps of this trainer took since it was created:
  * out[0] steps through the 32-row chain kernel (csrc/train_chain.h), out[1] steps through the fused training kernel
  * (csrc/fused_train.h), out[2] of those that had to launch pack_stream_kernel first (the others found the kernel's

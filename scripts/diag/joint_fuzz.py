@@ -1,45 +1,63 @@
-"""Diagnostics (r4): random joint steps (v21_joint_*: autoencoder + latent emulator stepping on the same rows, BASELINE
-configs[2]) checked through two invariants that need no second implementation:
+"""Diagnostics (r4; r5: importable -- tests/test_fuzz_gpu.py runs a seeded slice under `pytest -m gpu`): random joint steps
+(v21_joint_*: autoencoder + latent emulator stepping on the same rows, BASELINE configs[2]) checked through two invariants
+that need no second implementation:
   (1) both models training: the autoencoder's half is BIT-IDENTICAL to the same autoencoder trained alone;
   (2) autoencoder frozen (lr 0): the emulator's epochs equal those of a separate trainer fed the float64 oracle's
       latents of the (unchanged) encoder, to the precision's tolerance;
-and a twin joint object bit for bit.   python joint_fuzz.py [cases] [seed]"""
+and a twin joint object bit for bit.   python joint_fuzz.py [cases] [seed]
+Tolerance of (2) in f32: 2e-5 per epoch loss for epochs of up to 64 optimizer steps, 1e-4 beyond -- the separate trainer
+is fed float32 ROUNDINGS of the oracle's float64 latents while the joint launch forms them in fp32 arithmetic, and the two
+weight trajectories drift apart step by step (tests/test_fuzz_gpu.py::test_f32_joint_drift_against_the_separate_trainer_grows_with_the_step_count
+shows the drift at 100 / 500 / 1,500 single-row steps: VERDICT r4 weak 1)."""
 import importlib, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-native = importlib.import_module("21cmvae_amd._native")
-from oracle import ref_numpy as ora
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-DRY = os.environ.get("FUZZ_DRY") == "1"
-ctx = None if DRY else native.Context.default()
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 HID = [8, 16, 17, 32, 33, 64, 96, 128, 224, 288, 352, 400, 512]
-bad = 0
-for c in range(cases):
-    D = int(rng.choice([33, 100, 451]))
-    lat = int(rng.choice([1, 4, 9, 12, 16, 32]))
-    enc = [int(rng.choice(HID)) for _ in range(int(rng.integers(0, 3)))]
-    dec = [int(rng.choice(HID)) for _ in range(int(rng.integers(0, 3)))]
-    ae_dims = [D] + enc + [lat] + dec + [D]
-    ae_act = [1] * len(enc) + [0] + [1] * len(dec) + [0]
-    gl = len(enc)                                              # the encoder's linear output layer
-    em_dims = [7] + [int(rng.choice(HID)) for _ in range(int(rng.integers(1, 5)))] + [lat]
+
+
+def gen_cases(cases, seed):
+    rng = np.random.default_rng(seed)
+    for c in range(cases):
+        D = int(rng.choice([33, 100, 451]))
+        lat = int(rng.choice([1, 4, 9, 12, 16, 32]))
+        enc = [int(rng.choice(HID)) for _ in range(int(rng.integers(0, 3)))]
+        dec = [int(rng.choice(HID)) for _ in range(int(rng.integers(0, 3)))]
+        em_hid = [int(rng.choice(HID)) for _ in range(int(rng.integers(1, 5)))]
+        prec = ["f16", "f32", "bf16"][int(rng.integers(0, 3))]
+        n = int(rng.choice([40, 256, 300, 700, 1500]))
+        batch = min(n, int(rng.choice([1, 32, 100, 128, 256, 257, 600, 1024, 2048])))
+        yield dict(c=c, D=D, lat=lat, enc=enc, dec=dec, em_hid=em_hid, prec=prec, n=n, batch=batch, use_perm=bool(rng.random() < 0.6),
+                   data_seed=int(rng.integers(0, 1 << 30)))
+
+
+def shapes(k):
+    ae_dims = [k["D"]] + k["enc"] + [k["lat"]] + k["dec"] + [k["D"]]
+    ae_act = [1] * len(k["enc"]) + [0] + [1] * len(k["dec"]) + [0]
+    em_dims = [7] + k["em_hid"] + [k["lat"]]
     em_act = [1] * (len(em_dims) - 2) + [0]
-    prec = ["f16", "f32", "bf16"][int(rng.integers(0, 3))]
-    n = int(rng.choice([40, 256, 300, 700, 1500]))
-    batch = min(n, int(rng.choice([1, 32, 100, 128, 256, 257, 600, 1024, 2048])))
-    perm = rng.permutation(n).astype(np.int32) if rng.random() < 0.6 else None
-    tag = "case %3d %-4s ae %-34s em %-28s n %-5d batch %-5d %s" % (c, prec, ae_dims, em_dims, n, batch, "perm" if perm is not None else "seq ")
+    return ae_dims, ae_act, len(k["enc"]), em_dims, em_act      # gl = the encoder's linear output layer
+
+
+def tag_of(k):
+    ae_dims, _, _, em_dims, _ = shapes(k)
+    return "case %3d %-4s ae %-34s em %-28s n %-5d batch %-5d %s" % (k["c"], k["prec"], ae_dims, em_dims, k["n"], k["batch"], "perm" if k["use_perm"] else "seq ")
+
+
+def frozen_encoder_run(ctx, k, epochs=2):
+    """invariant (2) alone: -> (joint emulator losses, separate-trainer losses, encoder untouched)"""
+    native = importlib.import_module("21cmvae_amd._native")
+    from oracle import ref_numpy as ora
+    ae_dims, ae_act, gl, em_dims, em_act = shapes(k)
+    prec, n, batch, D, lat = k["prec"], k["n"], k["batch"], k["D"], k["lat"]
+    rng = np.random.default_rng(k["data_seed"])
+    perm = rng.permutation(n).astype(np.int32) if k["use_perm"] else None
     x = rng.uniform(-1, 1, size=(n, D)).astype(np.float32)
     par = rng.uniform(-1, 1, size=(n, 7)).astype(np.float32)
     wa = (rng.uniform(0.5, 1.5, size=n) / D).astype(np.float32)
-    Wa, ba = ora.init_mlp(ae_dims, seed=300 + c)
-    We, be = ora.init_mlp(em_dims, seed=600 + c)
-    if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:
-        continue
-    print(tag, "...", flush=True)
-    if DRY:
-        continue
+    Wa, ba = ora.init_mlp(ae_dims, seed=300 + k["c"])
+    We, be = ora.init_mlp(em_dims, seed=600 + k["c"])
     h = x.astype(np.float64)
     for W_, b_, a_ in list(zip(Wa, ba, ae_act))[:gl + 1]:
         h = h @ W_.astype(np.float64) + b_.astype(np.float64)
@@ -51,34 +69,45 @@ for c in range(cases):
         st = native.Stack(ctx, dims, act); st.set_weights(ora.flatten_params(Ws, bs))
         tr = native.Trainer(st, prec, batch); tr.set_adam(lr=lr)
         return st, tr
+    sta, tra = trainer(ae_dims, ae_act, Wa, ba, 0.0)
+    ste, tre = trainer(em_dims, em_act, We, be, 1e-3)
+    st2, tr2 = trainer(em_dims, em_act, We, be, 1e-3)
+    tra.set_data(0, x, None, wa)
+    tre.set_data(0, par, np.zeros((n, lat), np.float32), wz)
+    tr2.set_data(0, par, z.astype(np.float32), wz)
+    joint = native.Joint(tra, tre, latent_layer=gl)
+    lj = [joint.run_epoch(perm, batch)[1] for _ in range(epochs)]
+    l2 = [tr2.run_epoch(perm, batch) for _ in range(epochs)]
+    frozen_ok = np.array_equal(sta.get_weights(), ora.flatten_params(Wa, ba))
+    return lj, l2, frozen_ok, dict(x=x, par=par, wa=wa, wz=wz, Wa=Wa, ba=ba, We=We, be=be, perm=perm, trainer=trainer)
+
+
+def run_case(ctx, k):
+    """-> ("OK" | "BAD" | "refused", message)"""
+    native = importlib.import_module("21cmvae_amd._native")
+    ae_dims, ae_act, gl, em_dims, em_act = shapes(k)
+    prec, n, batch, lat = k["prec"], k["n"], k["batch"], k["lat"]
     try:
         # (2) frozen encoder against a separate trainer on the oracle's latents
-        sta, tra = trainer(ae_dims, ae_act, Wa, ba, 0.0)
-        ste, tre = trainer(em_dims, em_act, We, be, 1e-3)
-        st2, tr2 = trainer(em_dims, em_act, We, be, 1e-3)
-        tra.set_data(0, x, None, wa)
-        tre.set_data(0, par, np.zeros((n, lat), np.float32), wz)
-        tr2.set_data(0, par, z.astype(np.float32), wz)
-        joint = native.Joint(tra, tre, latent_layer=gl)
-        lj = [joint.run_epoch(perm, batch)[1] for _ in range(2)]
-        l2 = [tr2.run_epoch(perm, batch) for _ in range(2)]
-        frozen_ok = np.array_equal(sta.get_weights(), ora.flatten_params(Wa, ba))
+        lj, l2, frozen_ok, d = frozen_encoder_run(ctx, k)
+        x, par, wa, wz, perm, trainer = d["x"], d["par"], d["wa"], d["wz"], d["perm"], d["trainer"]
         # (1) both training against the autoencoder alone; twin joint
         res = []
         for _ in range(2):
-            a_st, a_tr = trainer(ae_dims, ae_act, Wa, ba, 1e-3)
-            e_st, e_tr = trainer(em_dims, em_act, We, be, 1e-3)
+            a_st, a_tr = trainer(ae_dims, ae_act, d["Wa"], d["ba"], 1e-3)
+            e_st, e_tr = trainer(em_dims, em_act, d["We"], d["be"], 1e-3)
             a_tr.set_data(0, x, None, wa); e_tr.set_data(0, par, np.zeros((n, lat), np.float32), wz)
             jj = native.Joint(a_tr, e_tr, latent_layer=gl)
             losses = [jj.run_epoch(perm, batch) for _ in range(2)]
             res.append((losses, a_st.get_weights(), e_st.get_weights()))
-        s_st, s_tr = trainer(ae_dims, ae_act, Wa, ba, 1e-3)
+        s_st, s_tr = trainer(ae_dims, ae_act, d["Wa"], d["ba"], 1e-3)
         s_tr.set_data(0, x, None, wa)
         ls = [s_tr.run_epoch(perm, batch) for _ in range(2)]
     except native.EngineError as e:
-        print(tag, "refused:", str(e)[:120], flush=True)
-        continue
-    tol = {"f32": 1e-4, "f16": 5e-3, "bf16": 4e-2}[prec]   # (f32: thousands of single-row steps on fp32 latents against the float64 ones reach 5e-5)
+        return "refused", str(e)[:120]
+    steps_per_epoch = -(-n // batch)
+    # (f32: see the header -- the drift of two fp32 trajectories grows with the number of optimizer steps)
+    tol = {"f32": 2e-5 if steps_per_epoch <= 64 else 1e-4, "f16": 5e-3, "bf16": 4e-2}[prec]
     rel2 = max(abs(a - b) / abs(b) for a, b in zip(lj, l2))
     (lo1, wa1, we1), (lo2, wa2, we2) = res
     # (f32: the joint launch may group the rows of the batch loss differently from the single model's -- the same sums per
@@ -86,9 +115,25 @@ for c in range(cases):
     alone = np.array_equal(wa1, s_st.get_weights()) and max(abs(a[0] - b) / abs(b) for a, b in zip(lo1, ls)) <= (1e-6 if prec == "f32" else 0.0)
     alone_diff = (max(abs(a[0] - b) / abs(b) for a, b in zip(lo1, ls)), float(np.abs(wa1 - s_st.get_weights()).max()))
     twin = lo1 == lo2 and np.array_equal(wa1, wa2) and np.array_equal(we1, we2)
-    finite = np.isfinite(we1).all() and np.isfinite(wa1).all()
-    flag = "OK " if rel2 <= tol and frozen_ok and alone and twin and finite else "BAD"
-    bad += flag == "BAD"
-    print(tag, flag, "frozen: emulator loss rel %.1e (tol %.0e), encoder untouched %s | autoencoder == alone %s | twin identical %s"
-          % (rel2, tol, frozen_ok, alone if alone else "False (loss rel %.1e, weights max diff %.1e)" % alone_diff, twin), flush=True)
-print("cases %d, BAD %d" % (cases, bad))
+    finite = bool(np.isfinite(we1).all() and np.isfinite(wa1).all())
+    ok = rel2 <= tol and frozen_ok and alone and twin and finite
+    return ("OK" if ok else "BAD"), "frozen: emulator loss rel %.1e (tol %.0e, %d steps per epoch), encoder untouched %s | autoencoder == alone %s | twin identical %s" % (
+        rel2, tol, steps_per_epoch, frozen_ok, alone if alone else "False (loss rel %.1e, weights max diff %.1e)" % alone_diff, twin)
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    DRY = os.environ.get("FUZZ_DRY") == "1"
+    ctx = None if DRY else importlib.import_module("21cmvae_amd._native").Context.default()
+    bad = 0
+    for k in gen_cases(cases, seed):
+        if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != k["c"]:
+            continue
+        print(tag_of(k), "...", flush=True)
+        if DRY:
+            continue
+        status, msg = run_case(ctx, k)
+        bad += status == "BAD"
+        print(tag_of(k), status, msg, flush=True)
+    print("cases %d, BAD %d" % (cases, bad))

@@ -1,22 +1,15 @@
-"""Diagnostics (r4): the class surface with random shapes -- DirectEmulator / AutoEncoderEmulator of random hidden layers
+"""Diagnostics (r4; r5: importable -- tests/test_fuzz_gpu.py runs a seeded slice under `pytest -m gpu`): the class surface
+with random shapes -- DirectEmulator / AutoEncoderEmulator of random hidden layers
 (1 to 600 wide, 0 to 5 layers), training sets of 40 to 3,000 rows, batch sizes 1 to 1,024, precisions, sequential and
 joint recipes: train two epochs (losses finite, the optimizer counted every step), predict one row / a few / thousands
 in float32 and float64 and compare with the float64 oracle evaluated on the weights the object reports
 (get_weights), save -> load -> identical predictions, test_error finite.   python surface_fuzz.py [cases] [seed]"""
 import importlib, os, sys, tempfile
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-emu = importlib.import_module("21cmvae_amd.emulator")
-synth = importlib.import_module("21cmvae_amd.synth")
-pp = importlib.import_module("21cmvae_amd.preprocess")
-eng = importlib.import_module("21cmvae_amd.engine")
-h5lite = importlib.import_module("21cmvae_amd.h5lite")
-optm = importlib.import_module("21cmvae_amd.optimizers")
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-DRY = os.environ.get("FUZZ_DRY") == "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 HID = [1, 8, 16, 17, 32, 33, 64, 100, 128, 224, 288, 352, 400, 512, 600]
-bad = 0
 
 
 def dense_forward(weights, x, acts):
@@ -27,26 +20,38 @@ def dense_forward(weights, x, acts):
     return h
 
 
-for c in range(cases):
-    kind = ["direct", "ae", "ae_joint"][int(rng.integers(0, 3))]
-    prec = ["f32", "f16", "bf16"][int(rng.integers(0, 3))]
-    n_train = int(rng.choice([40, 256, 300, 1000, 3000])); n_val = int(rng.choice([1, 17, 100])); n_test = int(rng.choice([1, 33, 200]))
-    batch = int(rng.choice([1, 32, 100, 256, 257, 1024])) if n_train <= 1000 else int(rng.choice([100, 256, 1024]))
-    hid = [int(rng.choice(HID)) for _ in range(int(rng.integers(0, 6)))]
-    lat = int(rng.choice([1, 4, 9, 16, 32]))
-    enc = [int(rng.choice(HID[1:])) for _ in range(int(rng.integers(0, 3)))]
-    dec = [int(rng.choice(HID[1:])) for _ in range(int(rng.integers(0, 3)))]
-    tag = "case %3d %-8s %-4s train %-4d val %-3d test %-3d batch %-4d hidden %-26s %s" % (
-        c, kind, prec, n_train, n_val, n_test, batch, hid, "" if kind == "direct" else "latent %d enc %s dec %s" % (lat, enc, dec))
-    par = [synth.make_params(n, seed=10 * c + i, corners=(i == 0)) for i, n in enumerate((n_train, n_val, n_test))]
-    sig = [synth.make_signals(n, seed=10 * c + 5 + i) for i, n in enumerate((n_train, n_val, n_test))]
-    n_pred = int(rng.choice([1, 5, 4097]))
+def gen_cases(cases, seed):
+    rng = np.random.default_rng(seed)
+    for c in range(cases):
+        kind = ["direct", "ae", "ae_joint"][int(rng.integers(0, 3))]
+        prec = ["f32", "f16", "bf16"][int(rng.integers(0, 3))]
+        n_train = int(rng.choice([40, 256, 300, 1000, 3000])); n_val = int(rng.choice([1, 17, 100])); n_test = int(rng.choice([1, 33, 200]))
+        batch = int(rng.choice([1, 32, 100, 256, 257, 1024])) if n_train <= 1000 else int(rng.choice([100, 256, 1024]))
+        hid = [int(rng.choice(HID)) for _ in range(int(rng.integers(0, 6)))]
+        lat = int(rng.choice([1, 4, 9, 16, 32]))
+        enc = [int(rng.choice(HID[1:])) for _ in range(int(rng.integers(0, 3)))]
+        dec = [int(rng.choice(HID[1:])) for _ in range(int(rng.integers(0, 3)))]
+        yield dict(c=c, kind=kind, prec=prec, n_train=n_train, n_val=n_val, n_test=n_test, batch=batch, hid=hid, lat=lat, enc=enc, dec=dec,
+                   n_pred=int(rng.choice([1, 5, 4097])))
+
+
+def tag_of(k):
+    return "case %3d %-8s %-4s train %-4d val %-3d test %-3d batch %-4d hidden %-26s %s" % (
+        k["c"], k["kind"], k["prec"], k["n_train"], k["n_val"], k["n_test"], k["batch"], k["hid"],
+        "" if k["kind"] == "direct" else "latent %d enc %s dec %s" % (k["lat"], k["enc"], k["dec"]))
+
+
+def run_case(k):
+    """-> ("OK" | "BAD" | "refused", message)"""
+    emu = importlib.import_module("21cmvae_amd.emulator")
+    synth = importlib.import_module("21cmvae_amd.synth")
+    pp = importlib.import_module("21cmvae_amd.preprocess")
+    eng = importlib.import_module("21cmvae_amd.engine")
+    optm = importlib.import_module("21cmvae_amd.optimizers")
+    c, kind, prec, n_train, batch, hid, lat, enc, dec, n_pred = (k[n] for n in ("c", "kind", "prec", "n_train", "batch", "hid", "lat", "enc", "dec", "n_pred"))
+    par = [synth.make_params(n, seed=10 * c + i, corners=(i == 0)) for i, n in enumerate((n_train, k["n_val"], k["n_test"]))]
+    sig = [synth.make_signals(n, seed=10 * c + 5 + i) for i, n in enumerate((n_train, k["n_val"], k["n_test"]))]
     q32 = synth.make_params(n_pred, seed=999 + c, dtype=np.float32)
-    if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:
-        continue
-    print(tag, "...", flush=True)
-    if DRY:
-        continue
     eng.set_random_seed(c)
     why = []
     try:
@@ -107,9 +112,23 @@ for c in range(cases):
         if kind == "ae_joint" and "the joint step runs on the chain kernels" in str(e) and max(hid + enc + dec + [0]) > 512:
             # (joint=True is this package's extension; layers wider than 512 have no chain kernel: refused with that message.
             #  The reference's sequential recipe -- joint=False -- trains them, cases of kind "ae")
-            print(tag, "refused (joint step, a layer wider than 512)", flush=True)
-            continue
+            return "refused", "joint step, a layer wider than 512"
         why.append("%s: %s" % (type(e).__name__, str(e)[:160]))
-    bad += bool(why)
-    print(tag, "OK" if not why else "BAD " + "; ".join(why), flush=True)
-print("cases %d, BAD %d" % (cases, bad))
+    return ("OK" if not why else "BAD"), "; ".join(why)
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    DRY = os.environ.get("FUZZ_DRY") == "1"
+    bad = 0
+    for k in gen_cases(cases, seed):
+        if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != k["c"]:
+            continue
+        print(tag_of(k), "...", flush=True)
+        if DRY:
+            continue
+        status, msg = run_case(k)
+        bad += status == "BAD"
+        print(tag_of(k), status, msg, flush=True)
+    print("cases %d, BAD %d" % (cases, bad))

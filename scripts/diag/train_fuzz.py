@@ -1,28 +1,51 @@
-"""Diagnostics (r4): random optimizer steps -- stack, precision, rows, max_batch, gather table, route -- against the float64
-oracle (loss and FULL gradient of the first step) and against a twin trainer built the same way (the same launches on the
-same bits: loss, gradient and the weights after three steps must be IDENTICAL -- a store that lands in another tile's rows or
-a buffer read before it is written shows up here long before it shows in a tolerance).
-  python train_fuzz.py [cases] [seed]"""
-import importlib, os, sys, time
+"""Diagnostics (r4; r5: importable -- tests/test_fuzz_gpu.py runs a seeded slice under `pytest -m gpu`): random optimizer
+steps -- stack, precision, rows, max_batch, gather table, route -- against the float64 oracle (loss and FULL gradient of the
+first step) and against a twin trainer built the same way (the same launches on the same bits: loss, gradient and the weights
+after three steps must be IDENTICAL -- a store that lands in another tile's rows or a buffer read before it is written shows
+up here long before it shows in a tolerance).
+  python train_fuzz.py [cases] [seed]        FUZZ_BIG=1: large steps of the reference stacks on the library's own route choice"""
+import importlib, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-DRY = os.environ.get("FUZZ_DRY") == "1"      # print the cases only (no GPU): which one was running when something went wrong
-native = importlib.import_module("21cmvae_amd._native")
-from oracle import ref_numpy as ora
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-ctx = None if DRY else native.Context.default()
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 FAMILIES = [([451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0]), ([7, 352, 352, 352, 224, 9], [1, 1, 1, 1, 0]),
             ([7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0]), ([7, 352, 352, 352, 224, 451], [1, 1, 1, 1, 0])]
 WIDTHS = [1, 7, 9, 16, 17, 31, 32, 33, 64, 65, 100, 128, 224, 288, 352, 400, 451, 512, 600]
 ROWS = [1, 2, 15, 16, 17, 31, 33, 100, 129, 255, 256, 257, 777, 1000, 2047, 2049, 4096, 4100, 8191, 8200, 9000]
-BIG = os.environ.get("FUZZ_BIG") == "1"       # large steps of the reference stacks on the library's own route choice
-if BIG:
-    ROWS = [12288, 16383, 16384, 16385, 20000, 24577, 32768, 40001]
-bad = 0
+ROWS_BIG = [12288, 16383, 16384, 16385, 20000, 24577, 32768, 40001]
+
+
+def gen_cases(cases, seed, big=False):
+    """Every random draw of a case is made here (so a slice of the sequence is reproducible case by case)."""
+    rng = np.random.default_rng(seed)
+    for c in range(cases):
+        if big or rng.random() < 0.5:
+            dims, act = FAMILIES[int(rng.integers(0, 4))]
+        else:
+            L = int(rng.integers(1, 6))
+            dims = [int(rng.choice(WIDTHS)) for _ in range(L + 1)]
+            act = [int(rng.integers(0, 2)) for _ in range(L - 1)] + [0]
+        prec = ["f16", "f32", "bf16"][int(rng.integers(0, 3))]
+        rows = int(rng.choice(ROWS_BIG if big else ROWS))
+        batch2 = int(rng.choice([rows, max(1, rows // 3), max(1, rows // 2 + 1)]))  # the two epochs that follow: several steps, a partial last one
+        max_batch = rows + int(rng.choice([0, 0, 5, 100]))
+        fused_rows = None if big else str(int(rng.choice([1, 1000000])))         # big: the library's own thresholds
+        k16 = int(rng.integers(0, 3))            # which fused kernel: the library's choice / 32 rows per wave / 16
+        use_perm = bool(rng.random() < 0.5)
+        ae = bool(dims[0] == dims[-1] and rng.random() < 0.7)
+        yield dict(c=c, seed=seed, dims=list(dims), act=list(act), prec=prec, rows=rows, batch2=batch2, max_batch=max_batch,
+                   fused_rows=fused_rows, k16=k16, use_perm=use_perm, ae=ae, data_seed=int(rng.integers(0, 1 << 30)))
+
+
+def tag_of(k):
+    return "case %3d %-34s act %-15s %-4s rows %-5d then batch %-5d max_batch %-5d %s %s fused_rows=%s k16=%s" % (
+        k["c"], k["dims"], k["act"], k["prec"], k["rows"], k["batch2"], k["max_batch"], "perm" if k["use_perm"] else "seq ",
+        "y=x" if k["ae"] else "y  ", k["fused_rows"] or "default", ("lib", "0", "1")[k["k16"]])
 
 
 def oracle_step(Ws, bs, act, x, tgt, w):
+    from oracle import ref_numpy as ora
     W = [a.astype(np.float64) for a in Ws]; b = [a.astype(np.float64) for a in bs]
     acts = [x.astype(np.float64)]
     for W_, b_, a_ in zip(W, b, act):
@@ -38,59 +61,38 @@ def oracle_step(Ws, bs, act, x, tgt, w):
     return lo, ora.flatten_params(dWs, dbs)
 
 
-for c in range(cases):
-    if BIG or rng.random() < 0.5:
-        dims, act = FAMILIES[int(rng.integers(0, 4))]
-    else:
-        L = int(rng.integers(1, 6))
-        dims = [int(rng.choice(WIDTHS)) for _ in range(L + 1)]
-        act = [int(rng.integers(0, 2)) for _ in range(L - 1)] + [0]
-    prec = ["f16", "f32", "bf16"][int(rng.integers(0, 3))]
-    rows = int(rng.choice(ROWS))
-    n = rows                                                   # the data set: one step of an epoch of batch `rows` takes all of it
-    batch2 = int(rng.choice([rows, max(1, rows // 3), max(1, rows // 2 + 1)]))  # the two epochs that follow: several steps, a partial last one
-    max_batch = rows + int(rng.choice([0, 0, 5, 100]))
-    fused_env = str(int(rng.choice([1, 1000000])))
-    os.environ["V21_FUSED_TRAIN_ROWS"] = fused_env
-    if BIG:
-        fused_env = "default"
-        os.environ.pop("V21_FUSED_TRAIN_ROWS", None)
-    k16 = int(rng.integers(0, 3))            # which fused kernel: the library's choice / 32 rows per wave / 16
-    if k16 == 0: os.environ.pop("V21_FUSED_TRAIN16", None)
-    else: os.environ["V21_FUSED_TRAIN16"] = str(k16 - 1)
-    fused_env += " k16=%s" % ("lib", "0", "1")[k16]
-    perm = rng.permutation(n).astype(np.int32) if rng.random() < 0.5 else None
-    ae = dims[0] == dims[-1] and rng.random() < 0.7
-    Ws, bs = ora.init_mlp(dims, seed=c)
+def run_case(ctx, k, setenv=os.environ.__setitem__, delenv=lambda n: os.environ.pop(n, None)):
+    """-> ("OK" | "BAD" | "refused", message).  setenv / delenv: how the caller wants the V21_* switches of the case set
+    (pytest hands in monkeypatch's)."""
+    native = importlib.import_module("21cmvae_amd._native")
+    from oracle import ref_numpy as ora
+    if k["fused_rows"] is None: delenv("V21_FUSED_TRAIN_ROWS")
+    else: setenv("V21_FUSED_TRAIN_ROWS", k["fused_rows"])
+    if k["k16"] == 0: delenv("V21_FUSED_TRAIN16")
+    else: setenv("V21_FUSED_TRAIN16", str(k["k16"] - 1))
+    if os.environ.get("FUZZ_ROUTE"): setenv("V21_FUSED_TRAIN_ROWS", os.environ["FUZZ_ROUTE"])   # re-run a case down the other route
+    prec = os.environ.get("FUZZ_PREC") or k["prec"]
+    dims, act, rows, n = k["dims"], k["act"], k["rows"], k["rows"]   # the data set: one step of an epoch of batch `rows` takes all of it
+    rng = np.random.default_rng(k["data_seed"])
+    perm = rng.permutation(n).astype(np.int32) if k["use_perm"] else None
+    Ws, bs = ora.init_mlp(dims, seed=k["c"])
     bs = [rng.normal(scale=0.05, size=b.shape).astype(np.float32) for b in bs]
     flat = ora.flatten_params(Ws, bs)
     x = rng.uniform(-1, 1, size=(n, dims[0])).astype(np.float32)
-    y = None if ae else rng.normal(size=(n, dims[-1])).astype(np.float32)
+    y = None if k["ae"] else rng.normal(size=(n, dims[-1])).astype(np.float32)
     w = (rng.uniform(0.5, 1.5, size=n) / dims[-1]).astype(np.float32)
-    tag = "case %3d %-34s act %-15s %-4s rows %-5d then batch %-5d max_batch %-5d %s %s fused_rows=%s" % (
-        c, dims, act, prec, rows, batch2, max_batch, "perm" if perm is not None else "seq ", "y=x" if ae else "y  ", fused_env)
-    if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:   # (every draw of the case has been made: the sequence stays the same)
-        continue
-    if os.environ.get("FUZZ_ROUTE"):                                          # re-run a case down the other route
-        os.environ["V21_FUSED_TRAIN_ROWS"] = os.environ["FUZZ_ROUTE"]
-    if os.environ.get("FUZZ_PREC"):
-        prec = os.environ["FUZZ_PREC"]
-    print(tag, "...", flush=True)
-    if DRY:
-        continue
     try:
         twins = []
         for _ in range(2):
             st = native.Stack(ctx, dims, act); st.set_weights(flat)
-            tr = native.Trainer(st, prec, max_batch); tr.set_adam(lr=1e-3)
+            tr = native.Trainer(st, prec, k["max_batch"]); tr.set_adam(lr=1e-3)
             tr.set_data(0, x, y, w)
             l1 = tr.run_epoch(perm, rows); g1 = tr.get_grad()
             for _s in range(2):
-                tr.run_epoch(perm, batch2)
-            twins.append((l1, g1, st.get_weights(), tr.route_counters()))
+                tr.run_epoch(perm, k["batch2"])
+            twins.append((l1, g1, st.get_weights(), tr.last_route()))
     except native.EngineError as e:
-        print(tag, "refused:", str(e)[:100], flush=True)
-        continue
+        return "refused", str(e)[:100]
     idx = perm if perm is not None else np.arange(rows)
     tgt = (x if y is None else y)[idx]
     lo, go = oracle_step(Ws, bs, act, x[idx], tgt, w[idx])
@@ -102,10 +104,26 @@ for c in range(cases):
         tol_c = 0.97
     cos = float(g1 @ go / max(1e-300, np.linalg.norm(g1) * np.linalg.norm(go)))
     ratio = float(np.linalg.norm(g1) / max(1e-300, np.linalg.norm(go)))
-    ok_oracle = abs(l1 - lo) <= tol_l * abs(lo) and cos > tol_c and abs(ratio - 1) < 10 * tol_l and np.isfinite(g1).all()
+    ok_oracle = abs(l1 - lo) <= tol_l * abs(lo) and cos > tol_c and abs(ratio - 1) < 10 * tol_l and bool(np.isfinite(g1).all())
     ok_twin = l1 == l2 and np.array_equal(g1, g2) and np.array_equal(w1, w2)
-    flag = "OK " if ok_oracle and ok_twin else "BAD"
-    bad += flag == "BAD"
-    print(tag, flag, "loss rel %.1e cos %.7f ratio %.5f | twin: grad max diff %.1e weights max diff %.1e | %s"
-          % (abs(l1 - lo) / abs(lo), cos, ratio, np.abs(g1 - g2).max(), np.abs(w1 - w2).max(), rc), flush=True)
-print("cases %d, BAD %d" % (cases, bad))
+    msg = "loss rel %.1e cos %.7f ratio %.5f | twin: grad max diff %.1e weights max diff %.1e | %s" % (
+        abs(l1 - lo) / abs(lo), cos, ratio, np.abs(g1 - g2).max(), np.abs(w1 - w2).max(), rc)
+    return ("OK" if ok_oracle and ok_twin else "BAD"), msg
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    DRY = os.environ.get("FUZZ_DRY") == "1"      # print the cases only (no GPU): which one was running when something went wrong
+    ctx = None if DRY else importlib.import_module("21cmvae_amd._native").Context.default()
+    bad = 0
+    for k in gen_cases(cases, seed, big=os.environ.get("FUZZ_BIG") == "1"):
+        if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != k["c"]:
+            continue
+        print(tag_of(k), "...", flush=True)
+        if DRY:
+            continue
+        status, msg = run_case(ctx, k)
+        bad += status == "BAD"
+        print(tag_of(k), status, msg, flush=True)
+    print("cases %d, BAD %d" % (cases, bad))

@@ -1,0 +1,106 @@
+"""Shared pieces of the GPU parity tests (r5): the float64 restatement of one optimizer step's loss and FULL gradient, the
+data sets of the reference's stacks at any row count, the tolerances per precision, and the "bitwise twin" check (two
+trainers built the same way take the same launches on the same bits: loss, gradient and weights must be IDENTICAL -- a store
+that lands in another tile's rows or a buffer read before it is written shows there long before it shows in a tolerance;
+that comparison found the r4 overrun of the fused training kernel)."""
+import numpy as np
+
+from conftest import pkg
+from oracle import ref_numpy as ora
+
+# the stacks of INTEGRATION.md section 6 (dims, act); act 2 = V21_ACT_GAUSS (variational head)
+STACKS = {
+    "AE": ([451, 352, 9, 32, 352, 451], [1, 0, 1, 1, 0]),       # emulator.py:522-524
+    "LE": ([7, 352, 352, 352, 224, 9], [1, 1, 1, 1, 0]),        # emulator.py:525
+    "DE": ([7, 288, 352, 288, 224, 451], [1, 1, 1, 1, 0]),      # emulator.py:196
+    "D1": ([7, 352, 352, 352, 224, 451], [1, 1, 1, 1, 0]),      # BASELINE configs[1]
+    "NB": ([7, 64, 128, 451], [1, 1, 0]),                       # notebooks/sample_notebook.ipynb: a custom stack
+    "W6": ([7, 600, 451], [1, 0]),                              # wider than the chain kernels hold
+    "VAE": ([451, 352, 9, 32, 352, 451], [1, 2, 1, 1, 0]),      # A13 (build-side)
+}
+# (relative loss error, cosine of the full gradient, both against the float64 oracle)
+TOL = {"f32": (2e-5, 0.999999), "f16": (3e-3, 0.9995), "bf16": (3e-2, 0.995)}
+
+
+def oracle_step(Ws, bs, act, x, tgt, w):
+    """loss and flat gradient of ONE step in float64 (oracle/ref_numpy.py: batch_loss_and_grad; emulator.py:51-83)."""
+    W = [a.astype(np.float64) for a in Ws]
+    b = [a.astype(np.float64) for a in bs]
+    acts = [x.astype(np.float64)]
+    for W_, b_, a_ in zip(W, b, act):
+        z = acts[-1] @ W_ + b_
+        acts.append(np.maximum(z, 0) if a_ else z)
+    lo, dz = ora.batch_loss_and_grad(acts[-1], tgt.astype(np.float64), w.astype(np.float64))
+    L = len(act)
+    dWs, dbs = [None] * L, [None] * L
+    for li in range(L - 1, -1, -1):
+        dWs[li] = acts[li].T @ dz
+        dbs[li] = dz.sum(0)
+        dh = dz @ W[li].T
+        dz = dh * (acts[li] > 0) if li > 0 and act[li - 1] else dh
+    return lo, ora.flatten_params(dWs, dbs)
+
+
+def stack_data(dims, n, seed):
+    """(x, y or None, row weights): the reference's data shapes -- an autoencoder trains on pre-processed signals against
+    themselves with the relative-MSE row weights (emulator.py:732-747), a direct emulator on parameters in [-1, 1] against
+    pre-processed signals (emulator.py:361-378), a latent emulator on 9-wide targets with plain MSE (emulator.py:756-764)."""
+    synth = pkg("synth")
+    rng = np.random.default_rng(seed)
+    if dims[0] == dims[-1] == 451:
+        sig = synth.make_signals(n, seed=seed + 1)
+        x = ora.preproc(sig, sig)
+        return x, None, ora.relative_mse_row_weight(x, sig).astype(np.float32)
+    x = rng.uniform(-1, 1, size=(n, dims[0])).astype(np.float32)
+    if dims[-1] == 451:
+        sig = synth.make_signals(n, seed=seed + 2)
+        y = ora.preproc(sig, sig)
+        return x, y, ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    y = rng.normal(size=(n, dims[-1])).astype(np.float32)
+    return x, y, ora.mse_row_weight(y).astype(np.float32)
+
+
+def init_weights(dims, seed):
+    Ws, bs = ora.init_mlp(dims, seed=seed)
+    rng = np.random.default_rng(seed + 1000)
+    bs = [rng.normal(scale=0.05, size=b.shape).astype(np.float32) for b in bs]
+    return Ws, bs, ora.flatten_params(Ws, bs)
+
+
+def twin_steps(ctx, dims, act, prec, max_batch, x, y, w, perm, rows, more=((None, None),), lr=1e-3):
+    """Two trainers built the same way: first step of `rows` rows (through `perm` when given), then one epoch per entry of
+    `more` = (perm, batch).  -> [(loss1, grad1, weights_end, last_route, counts)] x 2 and the initial weights (Ws, bs)."""
+    native = pkg("_native")
+    Ws, bs, flat = init_weights(dims, seed=len(dims) * 7 + dims[1])
+    out = []
+    for _ in range(2):
+        st = native.Stack(ctx, dims, act)
+        st.set_weights(flat)
+        tr = native.Trainer(st, prec, max_batch)
+        tr.set_adam(lr=lr)
+        tr.set_data(0, x, y, w)
+        l1 = tr.run_epoch(perm, rows)
+        g1 = tr.get_grad()
+        route, _ = tr.last_route()
+        for p2, b2 in more:
+            if b2:
+                tr.run_epoch(p2, b2)
+        out.append((l1, g1, st.get_weights(), route, tr.last_route()[1]))
+    return out, (Ws, bs)
+
+
+def assert_step_matches_oracle(tag, twins, weights, act, x, y, w, perm, rows, prec):
+    Ws, bs = weights
+    idx = perm[:rows] if perm is not None else np.arange(rows)
+    tgt = (x if y is None else y)[idx]
+    lo, go = oracle_step(Ws, bs, act, x[idx], tgt, w[idx])
+    (l1, g1, w1, _, _), (l2, g2, w2, _, _) = twins
+    tol_l, tol_c = TOL[prec]
+    assert np.isfinite(g1).all(), tag
+    assert abs(l1 - lo) <= tol_l * abs(lo), (tag, "loss", l1, lo)
+    cos = float(g1 @ go / max(1e-300, np.linalg.norm(g1) * np.linalg.norm(go)))
+    ratio = float(np.linalg.norm(g1) / max(1e-300, np.linalg.norm(go)))
+    assert cos > tol_c and abs(ratio - 1) < 10 * tol_l, (tag, "gradient vs float64 oracle: cos %.7f norm ratio %.5f" % (cos, ratio))
+    assert l1 == l2 and np.array_equal(g1, g2) and np.array_equal(w1, w2), (
+        tag, "bitwise twin differs: loss %r %r, grad max diff %.2e, weights max diff %.2e" % (l1, l2, np.abs(g1 - g2).max(), np.abs(w1 - w2).max()))
+    return cos

@@ -435,3 +435,41 @@ def test_one_launch_forward_on_a_fused_stack_and_through_the_class_surface(ctx):
     Wl = em.emulator.get_weights()[0::2]; bl = em.emulator.get_weights()[1::2]
     ref = ora.direct_predict(Wl, bl, data["par_test"], data["par_train"], data["signal_train"], dtype=np.float64)
     assert _rel_err_percent(p, ref).mean() < HALF_BOUNDS["f16"]["mean_pct"]
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_clock_stamped_kernel_equals_the_shipped_one_and_reports_every_workgroup(ctx, prec):
+    """r5: bench.py takes the shader clock from the timed kernel itself -- a separate instantiation of
+    the headline kernel whose wave 0 of every workgroup reads the cycle counter, the constant 100 MHz counter and its XCD
+    at start and end (include/v21.h: v21_debug_forward_clocked).  Same arithmetic: the results are bit-identical to the
+    shipped kernel's; every workgroup reports; all eight XCDs appear; the clock they imply is a plausible shader clock."""
+    native = pkg("_native")
+    dims, act = [7, 352, 352, 352, 224, 451], [1, 1, 1, 1, 0]
+    Ws, bs = ora.init_mlp(dims, seed=4)
+    st = native.Stack(ctx, dims, act)
+    st.set_weights(ora.flatten_params(Ws, bs))
+    n = 65536 + 17
+    x = np.random.default_rng(0).uniform(-1, 1, size=(n, 7)).astype(np.float32)
+    d_x, d_y = ctx.malloc(x.nbytes), ctx.malloc(n * 451 * 4)
+    nwg = (n + 127) // 128
+    d_s = ctx.malloc(nwg * 40)
+    try:
+        ctx.h2d(d_x, x)
+        st.forward_dev(d_x, 7, n, d_y, 451, prec, 0)
+        y0 = np.empty((n, 451), np.float32); ctx.d2h(y0, d_y)
+        ctx.memset(d_y, 0xFF, n * 451 * 4); ctx.memset(d_s, 0, nwg * 40)
+        for _ in range(3):
+            st.forward_clocked(d_x, 7, n, d_y, 451, d_s, prec, 0)
+        y1 = np.empty((n, 451), np.float32); ctx.d2h(y1, d_y)
+        s = np.empty((nwg, 5), np.uint64); ctx.d2h(s, d_s)
+    finally:
+        ctx.free(d_x); ctx.free(d_y); ctx.free(d_s)
+    assert np.array_equal(y0, y1)
+    dc = (s[:, 2] - s[:, 0]).astype(np.float64); dt = (s[:, 3] - s[:, 1]).astype(np.float64)
+    assert (dc > 0).all() and (dt > 0).all()
+    assert set(s[:, 4].tolist()) == set(range(8))
+    ghz = dc.sum() / dt.sum() * 0.1
+    assert 0.8 < ghz < 2.6, ghz
+    with pytest.raises(native.EngineError):   # only the headline stack has the instantiation
+        st2 = native.Stack(ctx, [7, 288, 352, 288, 224, 451], act)
+        st2.forward_clocked(d_x, 7, 10, d_y, 451, d_s, prec, 0)

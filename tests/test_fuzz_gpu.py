@@ -1,0 +1,100 @@
+"""A seeded slice of every fuzzer of scripts/diag/ under `pytest -m gpu` ("promote the fuzzers into
+-m gpu"; the r4 overrun of the fused training kernel was found by train_fuzz.py, not by pytest).  The scripts hold the
+case generators and the checks (gen_cases / run_case); here every case is one parametrised test with a fixed seed, so a
+failure names its case and `FUZZ_ONLY=<case> python scripts/diag/<name>_fuzz.py <cases> <seed>` reproduces it.
+
+train     loss + FULL gradient of a random step against the float64 oracle, and a bitwise twin
+train_big large steps of the reference stacks on the library's own route choice (FUZZ_BIG)
+forward   random forward calls (route, transforms, dtypes, host / strided device buffers) against the float64 oracle, twice
+joint     joint steps through two invariants that need no second implementation + a twin
+sweep     grouped steps against the members trained one by one + a twin
+surface   the class surface end to end (train, predict in float32 / float64, save -> load, test_error)
+dp        2-4 ranks on the ONE GPU (gloo + the host-staged transport) against one process; ranks bit-identical"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(name):
+    # (a regular import by module name: dp_fuzz starts its ranks with multiprocessing's spawn, which pickles the worker
+    #  function by module name and hands the children this process's sys.path)
+    d = os.path.join(ROOT, "scripts", "diag")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    return importlib.import_module(name + "_fuzz")
+
+
+train_fuzz, forward_fuzz, joint_fuzz, sweep_fuzz, surface_fuzz, dp_fuzz = (_load(n) for n in ("train", "forward", "joint", "sweep", "surface", "dp"))
+ROUTE_ENV = ["V21_TRAIN_CHAIN", "V21_FUSED_TRAIN", "V21_FUSED_TRAIN16", "V21_FUSED_TRAIN_ROWS", "V21_DW_SPLIT_ROWS", "V21_CHAIN32S", "V21_C32S_ROWS"]
+
+
+@pytest.fixture
+def clean_env(monkeypatch):
+    for k in ROUTE_ENV:
+        monkeypatch.delenv(k, raising=False)
+    return monkeypatch
+
+
+def _check(status, msg, tag):
+    assert status in ("OK", "refused"), "%s\n%s" % (tag, msg)
+
+
+@pytest.mark.parametrize("k", list(train_fuzz.gen_cases(12, seed=11)), ids=lambda k: "c%d-%s-rows%d" % (k["c"], k["prec"], k["rows"]))
+def test_train_fuzz_slice(ctx, k, clean_env):
+    _check(*train_fuzz.run_case(ctx, k, setenv=clean_env.setenv, delenv=lambda n: clean_env.delenv(n, raising=False)), train_fuzz.tag_of(k))
+
+
+@pytest.mark.parametrize("k", list(train_fuzz.gen_cases(6, seed=12, big=True)), ids=lambda k: "c%d-%s-rows%d" % (k["c"], k["prec"], k["rows"]))
+def test_train_fuzz_slice_of_large_steps_on_the_default_routes(ctx, k, clean_env):
+    _check(*train_fuzz.run_case(ctx, k, setenv=clean_env.setenv, delenv=lambda n: clean_env.delenv(n, raising=False)), train_fuzz.tag_of(k))
+
+
+@pytest.mark.parametrize("k", list(forward_fuzz.gen_cases(14, seed=13, families_only=True)), ids=lambda k: "c%d-%s-n%d-%s" % (k["c"], k["prec"], k["n"], k["rname"]))
+def test_forward_fuzz_slice(ctx, k, clean_env):
+    _check(*forward_fuzz.run_case(ctx, k), forward_fuzz.tag_of(k))
+
+
+@pytest.mark.parametrize("k", list(joint_fuzz.gen_cases(10, seed=14)), ids=lambda k: "c%d-%s-n%d-b%d" % (k["c"], k["prec"], k["n"], k["batch"]))
+def test_joint_fuzz_slice(ctx, k, clean_env):
+    _check(*joint_fuzz.run_case(ctx, k), joint_fuzz.tag_of(k))
+
+
+def test_f32_joint_drift_against_the_separate_trainer_grows_with_the_step_count(ctx, clean_env):
+    """joint_fuzz case 115 (f32, 1,500 single-row steps per epoch, rel 5.4e-5) was answered by widening
+    the tolerance to 1e-4 with the explanation asserted, not shown.  Shown here: the same models, the same rows, batch 1,
+    after 100 / 500 / 1,500 steps per epoch -- the joint launch forms the emulator's targets (the frozen encoder's latents)
+    in fp32 arithmetic, the separate trainer is fed float32 roundings of the float64 oracle's; the targets differ by ~1e-7
+    relative, every Adam step passes that difference through 1 / (sqrt(v) + eps), and the two weight trajectories
+    separate step by step.  Asserted: the relative difference of the epoch losses stays under 2e-5 at 100 steps, under
+    1e-4 at 1,500, and does not shrink as the steps grow (it is accumulated, not a per-step error)."""
+    base = dict(c=115, D=100, lat=9, enc=[64], dec=[32], em_hid=[64, 32], prec="f32", batch=1, use_perm=True, data_seed=115)
+    rel = {}
+    for n in (100, 500, 1500):
+        lj, l2, frozen_ok, _ = joint_fuzz.frozen_encoder_run(ctx, dict(base, n=n), epochs=2)
+        assert frozen_ok
+        rel[n] = max(abs(a - b) / abs(b) for a, b in zip(lj, l2))
+    print("f32 joint vs separate trainer, relative epoch-loss difference by steps per epoch:", rel)
+    assert rel[100] <= 2e-5 and rel[500] <= 1e-4 and rel[1500] <= 1e-4, rel
+    assert rel[1500] >= 0.3 * rel[100], rel
+
+
+@pytest.mark.parametrize("k", list(sweep_fuzz.gen_cases(10, seed=15, max_count=16)), ids=lambda k: "c%d-%s-m%d-b%d" % (k["c"], k["prec"], k["count"], k["batch"]))
+def test_sweep_fuzz_slice(ctx, k, clean_env):
+    _check(*sweep_fuzz.run_case(ctx, k), sweep_fuzz.tag_of(k))
+
+
+@pytest.mark.parametrize("k", list(surface_fuzz.gen_cases(8, seed=16)), ids=lambda k: "c%d-%s-%s-n%d-b%d" % (k["c"], k["kind"], k["prec"], k["n_train"], k["batch"]))
+def test_surface_fuzz_slice(ctx, k, clean_env):
+    _check(*surface_fuzz.run_case(k), surface_fuzz.tag_of(k))
+
+
+@pytest.mark.parametrize("cfg", list(dp_fuzz.gen_cases(4, seed=17)), ids=lambda c: "c%d-w%d-%s-%s" % (c["c"], c["world"], c["prec"], "sharded" if c["sharded"] else "allreduce"))
+def test_dp_fuzz_slice(ctx, cfg, clean_env):
+    _check(*dp_fuzz.run_case(cfg), dp_fuzz.tag_of(cfg))
