@@ -127,6 +127,10 @@ SIGNATURES = {
     "v21_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "v21_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(CommHostOps)]),
     "v21_comm_destroy": (C.c_int, [_P]),
+    "v21_comm_init_null": (C.c_int, [_P, C.c_int, C.c_int]),
+    "v21_comm_set_buckets": (C.c_int, [_P, C.c_int]),
+    "v21_trainer_phase_timing": (C.c_int, [_P, C.c_int]),
+    "v21_trainer_phase_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "v21_comm_set_sharded": (C.c_int, [_P, C.c_int]),
     "v21_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "v21_comm_allreduce_f32": (C.c_int, [_P, _P, C.c_size_t]),
@@ -406,11 +410,21 @@ class Context:
     def comm_set_sharded(self, on=True):
         check(self.lib.v21_comm_set_sharded(self.h, 1 if on else 0))
 
+    def comm_init_null(self, nranks, rank=0):
+        """A communicator without a transport (include/v21.h: v21_comm_init_null): the N > 1 step structure on one GPU,
+        nothing exchanged -- for timing the compute side of a data-parallel step, never for training."""
+        check(self.lib.v21_comm_init_null(self.h, int(nranks), int(rank)))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_set_buckets(self, buckets):
+        """1: one all-reduce per step (default); 2: two, the output-side half overlapping the second weight-gradient launch."""
+        check(self.lib.v21_comm_set_buckets(self.h, int(buckets)))
+
     def comm_info(self):
         """(nranks, rank, transport) as the attached communicator reports them; transport "none" / "rccl" / "host"."""
         n, r, t = C.c_int(0), C.c_int(0), C.c_int(0)
         check(self.lib.v21_comm_info(self.h, C.byref(n), C.byref(r), C.byref(t)))
-        return n.value, r.value, ("none", "rccl", "host")[t.value]
+        return n.value, r.value, ("none", "rccl", "host", "null")[t.value]
 
     def ranks_seen(self):
         """Sum of 1.0 over the communicator (one all-reduce through the library's transport): how many ranks really
@@ -659,6 +673,21 @@ class Trainer(_Owned):
         out = (C.c_longlong * 4)()
         check(self.lib.v21_debug_trainer_counters(self.h, out))
         return dict(zip(("chain", "fused", "stream_packs", "stream_adam"), (int(v) for v in out)))
+
+    def phase_timing(self, steps):
+        """Stamp the phases of the next `steps` eager steps with HIP events (include/v21.h: v21_trainer_phase_timing); 0 = off."""
+        check(self.lib.v21_trainer_phase_timing(self.h, int(steps)))
+
+    def phase_times(self):
+        """-> dict(steps=, forward_and_activation_gradients_us=, weight_gradients_us=, exchange_exposed_us=, adam_and_repack_us=,
+        step_us=): mean per stamped step since the last call."""
+        ms = (C.c_double * 5)()
+        n = C.c_int(0)
+        check(self.lib.v21_trainer_phase_times(self.h, ms, C.byref(n)))
+        keys = ("forward_and_activation_gradients_us", "weight_gradients_us", "exchange_exposed_us", "adam_and_repack_us", "step_us")
+        d = {k: 1e3 * float(v) for k, v in zip(keys, ms)}
+        d["steps"] = n.value
+        return d
 
     def last_route(self):
         """((forward route, update route) of the last eager step, {(fwd or upd) route name: steps since creation}) -- written

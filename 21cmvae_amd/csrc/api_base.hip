@@ -105,6 +105,8 @@ extern "C" int v21_ctx_destroy(v21_ctx* c) {
   hipSetDevice(c->device);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->comm_stream) { hipStreamSynchronize(c->comm_stream); hipStreamDestroy(c->comm_stream); }
+  for (hipEvent_t e : {c->ev_bucket[0], c->ev_bucket[1], c->ev_comm_done}) if (e) hipEventDestroy(e);
   if (c->own) { hipStreamSynchronize(c->own); hipStreamDestroy(c->own); }
   if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
   for (hipEvent_t e : c->slice_done) if (e) hipEventDestroy(e);
@@ -177,7 +179,7 @@ extern "C" int v21_comm_get_unique_id(v21_ctx* c, void* id) {
 extern "C" int v21_comm_init(v21_ctx* c, int nranks, int rank, const void* id) {
   CHK(use(c));
   if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(V21_ERR_ARG, "bad communicator arguments");
-  if (c->comm || c->host_comm) return fail(V21_ERR_STATE, "communicator already initialised");
+  if (c->comm || c->host_comm || c->null_comm) return fail(V21_ERR_STATE, "communicator already initialised");
   CHK(load_rccl());
   nccl_uid u;
   memcpy(&u, id, sizeof u);
@@ -192,26 +194,47 @@ extern "C" int v21_comm_init_host(v21_ctx* c, int nranks, int rank, const v21_co
   if (!ops || !ops->allreduce_sum_f32 || !ops->reduce_scatter_sum_f32 || !ops->allgather_f32 || nranks < 1 || rank < 0 ||
       rank >= nranks)
     return fail(V21_ERR_ARG, "bad communicator arguments");
-  if (c->comm || c->host_comm) return fail(V21_ERR_STATE, "communicator already initialised");
+  if (c->comm || c->host_comm || c->null_comm) return fail(V21_ERR_STATE, "communicator already initialised");
   c->host = *ops;
   c->host_comm = true;
   c->nranks = nranks;
   c->rank = rank;
   return V21_OK;
 }
+extern "C" int v21_comm_init_null(v21_ctx* c, int nranks, int rank) {
+  CHK(use(c));
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(V21_ERR_ARG, "bad communicator arguments");
+  if (c->comm || c->host_comm || c->null_comm) return fail(V21_ERR_STATE, "communicator already initialised");
+  c->null_comm = true;
+  c->nranks = nranks;
+  c->rank = rank;
+  return V21_OK;
+}
+extern "C" int v21_comm_set_buckets(v21_ctx* c, int buckets) {
+  if (!c) return fail(V21_ERR_ARG, "null context");
+  if (buckets != 1 && buckets != 2) return fail(V21_ERR_ARG, "buckets must be 1 or 2");
+  CHK(use(c));
+  if (buckets == 2 && !c->comm_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&c->ev_bucket[0], &c->ev_bucket[1], &c->ev_comm_done}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  c->buckets = buckets;
+  return V21_OK;
+}
 extern "C" int v21_comm_destroy(v21_ctx* c) {
   CHK(use(c));
+  if (c->comm_stream) HIPCHK(hipStreamSynchronize(c->comm_stream));
   if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
-  c->host_comm = false;
-  c->nranks = 1; c->rank = 0; c->sharded = 0;
+  c->host_comm = false; c->null_comm = false;
+  c->nranks = 1; c->rank = 0; c->sharded = 0; c->buckets = 1;
   return V21_OK;
 }
 // what the attached communicator itself says (RCCL: ncclCommCount / ncclCommUserRank; host transport: what the host
-// passed): transport 0 = none, 1 = RCCL inside the library, 2 = host-staged callbacks
+// passed): transport 0 = none, 1 = RCCL inside the library, 2 = host-staged callbacks, 3 = none on purpose (v21_comm_init_null)
 extern "C" int v21_comm_info(v21_ctx* c, int* nranks, int* rank, int* transport) {
   if (!c || !nranks || !rank || !transport) return fail(V21_ERR_ARG, "null argument");
   *nranks = c->nranks; *rank = c->rank;
-  *transport = c->comm ? 1 : (c->host_comm ? 2 : 0);
+  *transport = c->comm ? 1 : (c->host_comm ? 2 : (c->null_comm ? 3 : 0));
   if (c->comm && g_rccl.CommCount && g_rccl.CommUserRank) {
     int r = g_rccl.CommCount(c->comm, nranks);
     if (r == 0) r = g_rccl.CommUserRank(c->comm, rank);
@@ -234,29 +257,33 @@ static int host_stage(v21_ctx* c, size_t n) {
 // device buffer -> page-locked host copy -> callback -> back (the stream is drained on both sides: the callback
 // blocks in the host's transport)
 template <class F>
-static int host_collective(v21_ctx* c, float* d_buf, size_t n, F&& call, const char* what) {
+static int host_collective(v21_ctx* c, float* d_buf, size_t n, F&& call, const char* what, hipStream_t st = nullptr) {
+  if (!st) st = c->stream;
   CHK(host_stage(c, n));
-  HIPCHK(hipMemcpyAsync(c->h_stage, d_buf, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_stage, d_buf, n * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
   const int r = call(c->h_stage);
   if (r != 0) return fail(V21_ERR_COMM, "host %s callback returned %d", what, r);
-  HIPCHK(hipMemcpyAsync(d_buf, c->h_stage, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyAsync(d_buf, c->h_stage, n * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return V21_OK;
+}
+int comm_allreduce_on(v21_ctx* c, float* d_buf, size_t n, hipStream_t st) {
+  if (c->nranks <= 1 || c->null_comm || n == 0) return V21_OK;  // single rank / no transport: identity
+  if (c->host_comm)
+    return host_collective(c, d_buf, n, [&](float* h) { return c->host.allreduce_sum_f32(c->host.user, h, n); }, "all-reduce", st);
+  int r = g_rccl.AllReduce(d_buf, d_buf, n, kNcclFloat32, kNcclSum, c->comm, st);
+  if (r != 0) return fail(V21_ERR_COMM, "ncclAllReduce: %s", rccl_err(r));
   return V21_OK;
 }
 extern "C" int v21_comm_allreduce_f32(v21_ctx* c, float* d_buf, size_t n) {
   CHK(use(c));
-  if (c->nranks <= 1) return V21_OK;  // single rank: identity
-  if (c->host_comm)
-    return host_collective(c, d_buf, n, [&](float* h) { return c->host.allreduce_sum_f32(c->host.user, h, n); }, "all-reduce");
-  int r = g_rccl.AllReduce(d_buf, d_buf, n, kNcclFloat32, kNcclSum, c->comm, c->stream);
-  if (r != 0) return fail(V21_ERR_COMM, "ncclAllReduce: %s", rccl_err(r));
-  return V21_OK;
+  return comm_allreduce_on(c, d_buf, n, c->stream);
 }
 // in place over nranks * n_per floats: rank r ends up with the sums of elements [r n_per, (r+1) n_per) there
 extern "C" int v21_comm_reduce_scatter_f32(v21_ctx* c, float* d_buf, size_t n_per) {
   CHK(use(c));
-  if (c->nranks <= 1) return V21_OK;
+  if (c->nranks <= 1 || c->null_comm) return V21_OK;
   if (c->host_comm)
     return host_collective(c, d_buf, n_per * c->nranks,
                            [&](float* h) { return c->host.reduce_scatter_sum_f32(c->host.user, h, n_per); }, "reduce-scatter");
@@ -267,7 +294,7 @@ extern "C" int v21_comm_reduce_scatter_f32(v21_ctx* c, float* d_buf, size_t n_pe
 // in place over nranks * n_per floats: every rank contributes elements [r n_per, (r+1) n_per) and receives all
 extern "C" int v21_comm_allgather_f32(v21_ctx* c, float* d_buf, size_t n_per) {
   CHK(use(c));
-  if (c->nranks <= 1) return V21_OK;
+  if (c->nranks <= 1 || c->null_comm) return V21_OK;
   if (c->host_comm)
     return host_collective(c, d_buf, n_per * c->nranks, [&](float* h) { return c->host.allgather_f32(c->host.user, h, n_per); },
                            "all-gather");

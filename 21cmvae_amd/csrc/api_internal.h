@@ -76,6 +76,15 @@ struct v21_ctx {
   float* h_stage = nullptr;
   size_t h_stage_n = 0;
   int sharded = 0;  // 1: reduce-scatter -> Adam on this rank's shard -> all-gather (v21_comm_set_sharded)
+  // r5: a communicator WITHOUT a transport (v21_comm_init_null): this rank computes its share of every global batch and
+  // takes the N > 1 step structure (operands -> gradients -> [exchange: nothing] -> Adam), so that the compute side of a
+  // data-parallel step can be timed on one GPU (bench.py: dp_compute_only)
+  bool null_comm = false;
+  // r5: the gradient exchange in `buckets` messages (v21_comm_set_buckets; 1 = one message after all weight gradients,
+  // 2 = the upper layers' half leaves on comm_stream while the lower layers' gradients are still being formed)
+  int buckets = 1;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_bucket[2] = {nullptr, nullptr}, ev_comm_done = nullptr;
   // v21_mlp_forward on many rows: results leave over PCIe on a second stream, slice by slice, while the next slice
   // is being computed (created on first use)
   hipStream_t copy_stream = nullptr;
@@ -222,6 +231,12 @@ struct v21_trainer {
   int* d_cur = nullptr;       // index of the next step's descriptor
   long long desc_next = 0, desc_count = 0;  // host mirror of *d_cur, entries valid in the table
   long long desc_iter0 = -1; float desc_lr = -1.f; bool desc_epoch = false;  // what the table was built for
+  // r5: HIP-event stamps around the phases of an eager step (v21_trainer_phase_timing / v21_trainer_phase_times): five
+  // events per step -- start, after the chain launch, after the last weight-gradient launch, after the exchange has
+  // been joined, after Adam -- for up to phase_cap steps after they were switched on
+  bool phase_on = false;
+  std::vector<hipEvent_t> phase_ev;
+  int phase_steps = 0, phase_cap = 0, phase_seen = 0;
   struct StepGraph { int rows, brows; const void *x, *y, *rw, *idx; long long row0; hipGraph_t graph; hipGraphExec_t exec; };
   std::vector<StepGraph> graphs;
   int graph_misses = 0;
@@ -293,7 +308,10 @@ int launch_dw32_group(const std::vector<v21_trainer*>& trs, const Dw32Model* d_t
 int launch_dw_adam_group(const std::vector<v21_trainer*>& tr, const DwAdamModel* d_tab, const std::vector<DwAdamModel>& h_tab, int rows, int brows, long long slot, hipStream_t st);  // api_trainer.hip
 void launch_joint32_kernel(int rpw, bool gauss, dim3 grid, dim3 block, hipStream_t st, const ChainModel* tab, const ChainStep& sa, const ChainStep& sb);  // api_trainer.hip
 void launch_joint_kernel(int prec, bool gauss, dim3 grid, dim3 block, hipStream_t st, const ChainModel* tab, const ChainStep& sa, const ChainStep& sb);  // api_trainer.hip
-int reduce_and_update(v21_trainer* t, bool chain_copies, int fold);  // api_trainer.hip
+int reduce_and_update(v21_trainer* t, bool chain_copies, int fold, bool exchanged = false);  // api_trainer.hip
+// api_base.hip: the all-reduce of d_buf[0, n) on a stream of the caller's choice (RCCL: enqueued there; host-staged
+// transport: blocking, staged through that stream; null transport / one rank: nothing)
+int comm_allreduce_on(v21_ctx* c, float* d_buf, size_t n, hipStream_t st);
 int refresh_dw32_table(const std::vector<v21_trainer*>& trs, Dw32Model* d_tab, std::vector<Dw32Model>& h_tab, int* max_blocks, bool* ok, hipStream_t st);  // api_sweep.hip
 int refresh_dw_adam_table(const std::vector<v21_trainer*>& tr, DwAdamModel** d_tab, std::vector<DwAdamModel>& h_tab, hipStream_t st);  // api_trainer.hip
 int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw, const int* d_idx, long long first, int rows, int brows, float* loss_out, long long row0, bool chain_done = false /* the joint step: the chain of this model ran in the joint launch */);  // api_trainer.hip

@@ -196,16 +196,17 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long l
     CHK(chain_attr(t0->prec));
     ChainStep csp = cs;
     csp.ncons = ((rows + 31) / 32 + 7) / 8 * 8;
-    csp.npref = chain_prefetchers(csp.ncons, G);
-    const dim3 grid(csp.ncons + 8 * csp.npref, G), block(64 * kChainWaves);
+    csp.npref = 0;  // (no prefetcher workgroups in a sweep: measured slower in r2)
+    // one-dimensional grid: a model's row blocks share an XCD label (train_chain.h: train_chain_group_kernel)
+    const dim3 grid(8 * csp.ncons * ((G + 7) / 8)), block(64 * kChainWaves);
     bool gauss = false;  // (train_chain.h: FEAT)
     for (v21_trainer* t : s->tr) gauss = gauss || t->gl >= 0;
     if (t0->prec == V21_PREC_F16) {
-      if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, true>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
-      else hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, false>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
+      if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, true>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
+      else hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, false>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
     } else {
-      if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, true>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
-      else hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, false>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp);
+      if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, true>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
+      else hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, false>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
     }
     HIPCHK(hipGetLastError());
     if (s->ctx->nranks == 1)  // nothing to exchange: all gradients, all Adam updates, all packed copies in one launch

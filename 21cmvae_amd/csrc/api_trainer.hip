@@ -55,6 +55,58 @@ static void note_route(v21_trainer* t, const StepRoute& r) {
   if (t->capturing) return;
   t->last_route = r; t->fwd_count[r.fwd & 7] += 1; t->upd_count[r.upd & 7] += 1;
 }
+// r5: HIP-event stamps around the phases of an eager step (include/v21.h: v21_trainer_phase_timing)
+static void phase_mark(v21_trainer* t, int idx) {
+  if (!t->phase_on || t->capturing || t->phase_steps >= t->phase_cap) return;
+  if (idx == 0) t->phase_seen = 0;
+  (void)hipEventRecord(t->phase_ev[(size_t)t->phase_steps * 5 + idx], t->ctx->stream);
+  t->phase_seen |= 1 << idx;
+  if (idx == 4 && t->phase_seen == 31) t->phase_steps += 1;  // (a step that did not pass all five marks -- the joint step's members -- is not counted)
+}
+// r5: the gradient exchange of an all-reduce step in TWO messages (v21_comm_set_buckets(ctx, 2)): the arena is
+// [W0 b0 | W1 b1 | ... | W(L-1) b(L-1) | loss]; bucket 1 = the UPPER layers k .. L-1 and the loss slot (their weight
+// gradients are formed first, from the operands the chain launch left), bucket 2 = layers 0 .. k-1.  Bucket 1's all-reduce
+// is issued on the communicator stream as soon as its gradients exist and runs while the second weight-gradient launch
+// forms bucket 2.  Every rank takes the same decision from the same numbers (the split depends on the stack only), also
+// a rank whose share of a batch is empty.  k = the split with the most even parameter counts.
+static bool dp_bucketed(const v21_trainer* t) {
+  const v21_ctx* c = t->ctx;
+  return c->nranks > 1 && !c->sharded && c->buckets == 2 && t->mlp->L >= 2 && !t->capturing;
+}
+static int dp_split_layer(const v21_mlp* m) {
+  int best = 1;
+  long long bd = -1;
+  for (int k = 1; k < m->L; ++k) {
+    const long long lower = m->w_off[k], upper = (long long)m->nparams - lower;
+    const long long d = lower > upper ? lower - upper : upper - lower;
+    if (bd < 0 || d < bd) { bd = d; best = k; }
+  }
+  return best;
+}
+// bucket b (0: arena [lo, hi) just became final on the main stream): its all-reduce goes to the communicator stream
+static int dp_exchange_bucket(v21_trainer* t, int b, size_t lo, size_t hi) {
+  v21_ctx* c = t->ctx;
+  if (c->host_comm || c->null_comm) return comm_allreduce_on(c, t->d_g + lo, hi - lo, c->stream);  // (blocking / nothing: no second stream needed)
+  HIPCHK(hipEventRecord(c->ev_bucket[b], c->stream));
+  HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_bucket[b], 0));
+  return comm_allreduce_on(c, t->d_g + lo, hi - lo, c->comm_stream);
+}
+// the main stream continues once both buckets have been reduced
+static int dp_exchange_join(v21_trainer* t) {
+  v21_ctx* c = t->ctx;
+  if (c->host_comm || c->null_comm) return V21_OK;
+  HIPCHK(hipEventRecord(c->ev_comm_done, c->comm_stream));
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_comm_done, 0));
+  return V21_OK;
+}
+static int reduce_slabs_range(v21_trainer* t, int nslice, long long lo, long long hi) {
+  if (hi <= lo) return V21_OK;
+  const long long n4 = (hi - (lo & ~3ll) + 3) / 4;
+  hipLaunchKernelGGL(reduce_slabs_range_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, t->ctx->stream, t->d_g,
+                     (const float*)t->d_slab, nslice, (long long)t->P + 4, lo, hi);
+  HIPCHK(hipGetLastError());
+  return V21_OK;
+}
 
 static int build_chain32s_jobs(v21_trainer* t);
 extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_trainer** out) {
@@ -249,6 +301,7 @@ extern "C" int v21_trainer_destroy(v21_trainer* t) {
   hipFree(t->d_wt); hipFree(t->d_wp);
   hipFree(t->d_yb); hipFree(t->d_wb); hipFree(t->d_rowloss); hipFree(t->d_evalsum);
   destroy_graphs(t);
+  for (hipEvent_t e : t->phase_ev) hipEventDestroy(e);
   if (t->d_desc) hipFree(t->d_desc);
   if (t->h_desc) hipHostFree(t->h_desc);
   if (t->d_cur) hipFree(t->d_cur);
@@ -391,7 +444,7 @@ AdamArgs adam_args(v21_trainer* t, bool do_adam, float alpha, bool skip_nt) {
 //                rides in slot P: summed by the reduce-scatter, it is copied into the weight arena's first pad
 //                float by its owner, so that the all-gather hands it to everyone.
 // `fold` > 1 (single rank): Adam sums that many split-K slabs itself.
-int reduce_and_update(v21_trainer* t, bool chain_copies, int fold) {
+int reduce_and_update(v21_trainer* t, bool chain_copies, int fold, bool exchanged) {
   v21_ctx* c = t->ctx;
   hipStream_t st = c->stream;
   const size_t P = t->P;
@@ -412,13 +465,17 @@ int reduce_and_update(v21_trainer* t, bool chain_copies, int fold) {
     float* w = t->mlp->d_w;
     if (P / S == (size_t)c->rank) HIPCHK(hipMemcpyAsync(w + P, t->d_g + P, sizeof(float), hipMemcpyDeviceToDevice, st));
     CHK(v21_comm_allgather_f32(c, w, S));
+    phase_mark(t, 3);  // (sharded form: the slice's Adam pass sits between the two halves of the exchange and is counted with it)
     HIPCHK(hipMemcpyAsync(t->d_g + P, w + P, sizeof(float), hipMemcpyDeviceToDevice, st));  // the loss slot, on every rank
     CHK(adam_and_copies(t, false, 0.f, chain_copies));  // packed copies from the gathered arena
+    phase_mark(t, 4);
     return V21_OK;
   }
-  CHK(v21_comm_allreduce_f32(c, t->d_g, P + 1));
+  if (!exchanged) CHK(v21_comm_allreduce_f32(c, t->d_g, P + 1));  // (exchanged: the step reduced its two buckets itself)
+  phase_mark(t, 3);
   t->iter += 1;
   CHK(adam_and_copies(t, true, adam_alpha(t->adam, t->iter), chain_copies, fold));
+  phase_mark(t, 4);
   return V21_OK;
 }
 
@@ -485,6 +542,7 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
   // single rank, an epoch's per-step slot: the sum kernel writes it itself (a device-to-device copy per step is a launch)
   const bool in_table = t->ctx->nranks == 1 && rows > 0 && loss_out && t->d_steploss && loss_out >= t->d_steploss &&
                         loss_out < t->d_steploss + t->steploss_cap;
+  phase_mark(t, 0);
   if (rows > 0) {
     note_route(t, step_route(t, rows));
     CHK(ensure_copies(t));
@@ -549,6 +607,7 @@ static int trainer_step(v21_trainer* t, const float* yb, long long ldy, int rows
     CHK(adam_and_copies(t, true, 0.f));
     return V21_OK;
   }
+  phase_mark(t, 1); phase_mark(t, 2);  // (per-layer path: forward, loss and every backward launch are reported as the first phase)
   CHK(reduce_and_update(t, false, 1));
   if (loss_out && !in_table) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
   invalidate_streams(m);
@@ -1015,12 +1074,14 @@ int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, const f
     // larger steps and data-parallel ranks: sliced gradients, [slab sum, exchange], Adam (UP_NT_SLICED)
     const StepRoute route = step_route(t, rows);
     if (!chain_done) {
+      phase_mark(t, 0);
       CHK(ensure_copies(t, false));
       ChainArgs a{};
       static_cast<ChainModel&>(a) = chain_model32(t);
       static_cast<ChainStep&>(a) = chain_step(x, ldx, y, ldy, rw, d_idx, first, rows, brows, dout, t, row0);
       a.gs = 1.0f;  // fp32 operands: no scaling of the gradients
       CHK(launch_chain32_args(a, st, t->chain32s, route.fwd == TR_CHAIN32S_4 ? 4 : 8));
+      phase_mark(t, 1);
     }
     note_route(t, route);  // (the joint step ran this model's chain in its own launch: the update route is what is recorded)
     long long work = 0;
@@ -1072,10 +1133,12 @@ int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, const f
 #ifdef V21_CHAIN_FINE
       ad.dbg = t->stamps_on ? t->d_stamps + 1024 : nullptr;
 #endif
+      phase_mark(t, 2); phase_mark(t, 3);  // (gradients + Adam are ONE launch here: reported under the Adam phase)
       if (T == 2) hipLaunchKernelGGL(gemm_nt_dwadam_kernel<2>, dim3(blocks), dim3(256), 0, st, grp, ad);
       else if (route.upd == UP_DWADAM32) hipLaunchKernelGGL(dwadam32_kernel, dim3(blocks), dim3(256), 0, st, grp, ad);  // operands through LDS in whole rows (dw_adam32.h)
       else hipLaunchKernelGGL(gemm_nt_dwadam_kernel<1>, dim3(blocks), dim3(256), 0, st, grp, ad);
       HIPCHK(hipGetLastError());
+      phase_mark(t, 4);
       t->copies_ok = true;
       t->nt_ok = false;
       if (t->capturing) return V21_OK;
@@ -1096,8 +1159,10 @@ int train_on_rows_chain32(v21_trainer* t, const float* x, long long ldx, const f
       hipLaunchKernelGGL(chain32_loss_kernel, dim3(1), dim3(1), 0, st, (unsigned long long*)t->d_ticket, t->d_g + t->P);
       HIPCHK(hipGetLastError());
     }
+    phase_mark(t, 2);
   } else {
     HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
+    phase_mark(t, 0); phase_mark(t, 1); phase_mark(t, 2);
   }
   t->loss_slot_pending = (single && rows > 0) ? (in_table ? (int)(loss_out - t->d_steploss) : -1) : -2;
   int r;
@@ -1126,6 +1191,10 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   int fold = 1;
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   bool fused_step = false;
+  const bool bucketed = dp_bucketed(t);
+  const int ksplit = bucketed ? dp_split_layer(m) : 0;
+  const size_t lo1 = bucketed ? (size_t)m->w_off[ksplit] : 0;  // bucket 1 = arena [lo1, P + 1), bucket 2 = [0, lo1)
+  phase_mark(t, 0);
   if (rows > 0) {
     const bool ts_fresh = t->tstream_fresh && t->copies_ok && t->mlp->wpad_ok;  // (read before ensure_copies clears it)
     CHK(ensure_copies(t, false));
@@ -1142,6 +1211,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     fused_step = fused;
     if (fused) CHK(launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, ts_fresh));
     else { CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0)); if (!t->capturing) t->n_chain_steps += 1; }
+    phase_mark(t, 1);
     // Single rank, nothing to exchange: gradients, Adam and the packed copies in one launch (dw_adam.h) -- up to the
     // batch where its 32 x 32 tiles, each pulling its operands over the WHOLE batch through one CU, lose to the
     // 128 x 128 LDS-staged split-K kernel + an Adam launch that sums the slabs (V21_DW_SPLIT_ROWS overrides the
@@ -1150,8 +1220,10 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
       if (!t->capturing) t->iter += 1;
       // an epoch's per-step loss slot is written by the kernel itself (a device-to-device copy per step is a launch)
       const bool in_table = loss_out && t->d_steploss && loss_out >= t->d_steploss && loss_out < t->d_steploss + t->steploss_cap;
+      phase_mark(t, 2); phase_mark(t, 3);  // (gradients + Adam are ONE launch here: reported under the Adam phase)
       CHK(launch_dw_adam(t, rows, brows, t->capturing ? 0.f : adam_alpha(t->adam, t->iter),
                          in_table ? (int)(loss_out - t->d_steploss) : -1));
+      phase_mark(t, 4);
       if (t->capturing) return V21_OK;
       if (loss_out && !in_table) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
       invalidate_streams(m);
@@ -1161,23 +1233,48 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     int nslice = 1;
     std::vector<Dw16Args> probs;
     dw16_problems(t, rows, brows, &nslice, probs);  // every weight gradient in one launch: [dW; db] = [H^T; 1^T] dZ
-    CHK(launch_dw16(t->prec, probs, st));
-    fold = nslice > 1 && t->ctx->nranks == 1 ? nslice : 1;  // single rank: Adam sums the slabs itself
-    if (nslice > 1 && fold == 1) {
-      const long long n4 = ((long long)t->P + 3) / 4;
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
-                         (const float*)t->d_slab, nslice, (long long)t->P + 4, (long long)t->P);
-      HIPCHK(hipGetLastError());
+    if (bucketed) {
+      // two launches, the upper layers first (their bucket also carries the loss slot: the batch loss is published by
+      // whichever problem holds loss_acc -- the first of THIS launch); each problem's tiles are the same workgroups doing
+      // the same sums as in the one-launch form: bit-identical gradients
+      Dw16Args& p0 = probs[0]; Dw16Args& pk = probs[ksplit];
+      pk.loss_acc = p0.loss_acc; pk.loss_out = p0.loss_out; pk.loss_out2 = p0.loss_out2; pk.sc = p0.sc;
+      p0.loss_acc = nullptr; p0.loss_out = nullptr; p0.loss_out2 = nullptr;
+      const std::vector<Dw16Args> upper(probs.begin() + ksplit, probs.end()), lower(probs.begin(), probs.begin() + ksplit);
+      CHK(launch_dw16(t->prec, upper, st));
+      if (nslice > 1) CHK(reduce_slabs_range(t, nslice, (long long)lo1, (long long)t->P));
+      CHK(dp_exchange_bucket(t, 0, lo1, t->P + 1));
+      CHK(launch_dw16(t->prec, lower, st));
+      if (nslice > 1) CHK(reduce_slabs_range(t, nslice, 0, (long long)lo1));
+      phase_mark(t, 2);
+      CHK(dp_exchange_bucket(t, 1, 0, lo1));
+      CHK(dp_exchange_join(t));
+    } else {
+      CHK(launch_dw16(t->prec, probs, st));
+      fold = nslice > 1 && t->ctx->nranks == 1 ? nslice : 1;  // single rank: Adam sums the slabs itself
+      if (nslice > 1 && fold == 1) {
+        const long long n4 = ((long long)t->P + 3) / 4;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, t->d_g,
+                           (const float*)t->d_slab, nslice, (long long)t->P + 4, (long long)t->P);
+        HIPCHK(hipGetLastError());
+      }
+      phase_mark(t, 2);
     }
   } else {
     HIPCHK(hipMemsetAsync(t->d_g, 0, (t->P + 1) * sizeof(float), st));
+    phase_mark(t, 1); phase_mark(t, 2);
+    if (bucketed) {  // a rank without rows takes part in the same two messages
+      CHK(dp_exchange_bucket(t, 0, lo1, t->P + 1));
+      CHK(dp_exchange_bucket(t, 1, 0, lo1));
+      CHK(dp_exchange_join(t));
+    }
   }
   if (t->capturing) {
     CHK(adam_and_copies(t, true, 0.f, true, fold));
     return V21_OK;
   }
   t->ts_write = fused_step;  // the next step probably takes the fused kernel too: its stream comes out of this Adam pass
-  const int ru = reduce_and_update(t, true, fold);
+  const int ru = reduce_and_update(t, true, fold, bucketed);
   t->ts_write = false;
   CHK(ru);
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, t->d_g + t->P, sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1586,6 +1683,41 @@ extern "C" int v21_trainer_last_route(v21_trainer* t, int* fwd, int* upd, long l
   *fwd = t->last_route.fwd; *upd = t->last_route.upd;
   if (fwd_counts) for (int i = 0; i < 8; ++i) fwd_counts[i] = t->fwd_count[i];
   if (upd_counts) for (int i = 0; i < 8; ++i) upd_counts[i] = t->upd_count[i];
+  return V21_OK;
+}
+extern "C" int v21_trainer_phase_timing(v21_trainer* t, int steps) {
+  if (!t) return fail(V21_ERR_ARG, "null trainer");
+  if (steps < 0 || steps > 4096) return fail(V21_ERR_ARG, "steps %d not in [0, 4096]", steps);
+  CHK(use(t->ctx));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  while ((int)t->phase_ev.size() < 5 * steps) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    t->phase_ev.push_back(e);
+  }
+  t->phase_cap = steps; t->phase_steps = 0; t->phase_on = steps > 0;
+  return V21_OK;
+}
+extern "C" int v21_trainer_phase_times(v21_trainer* t, double ms[5], int* steps) {
+  if (!t || !ms || !steps) return fail(V21_ERR_ARG, "null argument");
+  CHK(use(t->ctx));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  for (int i = 0; i < 5; ++i) ms[i] = 0.0;
+  *steps = t->phase_steps;
+  for (int s = 0; s < t->phase_steps; ++s) {
+    hipEvent_t* e = &t->phase_ev[(size_t)s * 5];
+    for (int i = 0; i < 4; ++i) {
+      float f = 0.f;
+      HIPCHK(hipEventElapsedTime(&f, e[i], e[i + 1]));
+      ms[i] += f;
+    }
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, e[0], e[4]));
+    ms[4] += f;
+  }
+  if (t->phase_steps > 0)
+    for (int i = 0; i < 5; ++i) ms[i] /= t->phase_steps;
+  t->phase_steps = 0;
   return V21_OK;
 }
 extern "C" int v21_debug_trainer_counters(v21_trainer* t, long long out[4]) {

@@ -54,6 +54,7 @@ struct DwAdamStep {
   StepCtx sc;  // replayed step (single model): alpha and the loss slot come from the descriptor
 };
 constexpr int kDwAdamWaves = 8, kDwAdamInFlight = 8, kDwAdamPitch = 40;
+static_assert(sizeof(DwAdamModel) + sizeof(DwAdamStep) <= 4096, "dw16_adam_kernel takes both by value: kernel arguments are limited to 4 KiB");
 
 #ifdef V21_CHAIN_FINE
 #define DWFINE(i) do { if ((threadIdx.x & 63) == 0 && md.dbg && (blockIdx.x % 47) == 0 && blockIdx.x / 47 < 8) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); md.dbg[((blockIdx.x / 47) * 8 + (i)) * 8 + (threadIdx.x >> 6)] = t_; } } while (0)

@@ -167,7 +167,7 @@ __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
 // FEAT: which features of the general body an instantiation carries (see train_chain_body)
 constexpr int kChainGauss = 1, kChainJoint = 2, kChainOut = 4, kChainAll = 7, kChainFwd = 8;  // (kChainFwd REMOVES code: no backward pass)
 template <class P, int FEAT = kChainAll>
-__device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st);
+__device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st, int bid);
 
 // Every row-block workgroup streams the model's whole packed weight set, and the Adam kernel has just rewritten it:
 // the lines are in no L2.  All workgroups of an XCD ask for the same line at about the same time, so each of them
@@ -192,14 +192,21 @@ __device__ __forceinline__ void chain_prefetch(const ChainModel& a, const ChainS
 template <class P, int FEAT = kChainAll>
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_kernel(const ChainArgs a) {
   if ((int)blockIdx.x >= a.ncons) { chain_prefetch(a, a); return; }
-  train_chain_body<P, FEAT>(a, a);
+  train_chain_body<P, FEAT>(a, a, (int)blockIdx.x);
 }
-// a sweep: blockIdx.y = model, the per-model blocks in device memory
+// a sweep: G models, the per-model blocks in device memory.  r5: a one-dimensional grid of 8 * ncons * ceil(G / 8)
+// workgroups, dealt so that ALL row blocks of a model carry the same XCD label (workgroups b, b + 8, ... share an XCD:
+// observed round-robin dispatch; a wrong guess costs speed, never results): label x = b % 8 serves the models x, x + 8, ...,
+// slot j = b / 8 is row block j % ncons of that label's (j / ncons)-th model.  Until r4 the grid was (ncons, G) with
+// blockIdx.y = model: row block x of EVERY model sat on XCD x, every XCD pulled every member's packed weights through its
+// own L2 (32 members: 318 MB of HBM-side traffic per launch against ~40 MB of weights; profiles/r5/pmc_sweep_f16_m32.json).
 template <class P, bool GAUSS = true>  // GAUSS = false: no member of the sweep has a variational layer
 __global__ void __launch_bounds__(64 * kChainWaves) train_chain_group_kernel(const ChainModel* __restrict__ tab,
-                                                                             const ChainStep st) {
-  if ((int)blockIdx.x >= st.ncons) { chain_prefetch(tab[blockIdx.y], st); return; }
-  train_chain_body<P, GAUSS ? kChainGauss : 0>(tab[blockIdx.y], st);
+                                                                             const ChainStep st, const int G) {
+  const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+  const int model = x + 8 * (j / st.ncons);
+  if (model >= G) return;  // (G is not a multiple of 8: the last round of labels is partly empty)
+  train_chain_body<P, GAUSS ? kChainGauss : 0>(tab[model], st, j % st.ncons);
 }
 
 // joint step (BASELINE configs[2]): the autoencoder (signals -> signals) and the latent emulator (parameters -> latent)
@@ -223,12 +230,12 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_joint_kernel(con
     chain_prefetch(tab[0], sp); chain_prefetch(tab[1], sp);
     return;
   }
-  if ((int)blockIdx.x < sa.ncons) { train_chain_body<P, FA>(tab[0], sa); return; }
+  if ((int)blockIdx.x < sa.ncons) { train_chain_body<P, FA>(tab[0], sa, (int)blockIdx.x); return; }
   ChainStep se = sa;  // the encoder alone, for the emulator's rows
   se.fwd_only = 1; se.nfwd = tab[0].zcap_layer + 1; se.blk0 = sa.ncons;
-  train_chain_body<P, FA>(tab[0], se);
+  train_chain_body<P, FA>(tab[0], se, (int)blockIdx.x);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the encoder's last LDS accesses precede the emulator's gather
-  train_chain_body<P, kChainJoint>(tab[1], sb);
+  train_chain_body<P, kChainJoint>(tab[1], sb, (int)blockIdx.x);
 }
 
 // LDS-only rendezvous: own LDS writes retired, then the barrier.  Deliberately NOT __syncthreads():
@@ -253,7 +260,7 @@ __device__ __forceinline__ chain_s4 chain_tr_read(const void* p) {
 // them and 5 vector registers in scratch; FEAT = 0 -- what a trainer of the reference's stacks launches -- has 15 and 0,
 // and its step is 1.4 us shorter at every batch size (r3: 46.0 -> 44.6 us at 4,096 rows, 33.3 -> 31.9 at 256).
 template <class P, int FEAT>
-__device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st) {
+__device__ __forceinline__ void train_chain_body(const ChainModel& a, const ChainStep& st, const int bid /* the workgroup's block number: blockIdx.x, or the slot a grouped launch assigns */) {
 #define GG(cond) ((FEAT & kChainGauss) ? (bool)(cond) : false)
 #define GJ(cond) ((FEAT & kChainJoint) ? (bool)(cond) : false)
 #define GO(cond) ((FEAT & kChainOut) ? (bool)(cond) : false)
@@ -278,7 +285,7 @@ __device__ __forceinline__ void train_chain_body(const ChainModel& a, const Chai
   // XCD x carries the CONSECUTIVE row blocks x * ceil(nb / 8) ...: the batch slice whose weight-gradient tiles
   // gemm_dw16* then runs on the same XCD, so that it finds the operands this kernel wrote in its own L2.
   const int nrb = (st.rows + 31) >> 5;
-  const int bidx = (int)blockIdx.x - ((FEAT & kChainJoint) ? st.blk0 : 0);
+  const int bidx = bid - ((FEAT & kChainJoint) ? st.blk0 : 0);
   const int rb = (bidx & 7) * ((nrb + 7) >> 3) + (bidx >> 3);
   if (rb >= nrb) return;  // (the grid is rounded up to a multiple of 8)
   const int m0 = rb * 32;

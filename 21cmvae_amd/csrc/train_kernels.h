@@ -84,6 +84,27 @@ static __global__ void reduce_slabs_kernel(float* __restrict__ g, const float* _
   }
 }
 
+// ... over the arena elements [lo, hi) only (r5: a gradient bucket of a data-parallel step; element by element the same
+// sums in the same order as the whole-arena kernel)
+static __global__ void reduce_slabs_range_kernel(float* __restrict__ g, const float* __restrict__ slabs, int nslab,
+                                          long long stride, long long lo, long long hi) {
+  const long long i4 = (lo & ~3ll) + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= lo && i4 + 3 < hi) {
+    float4 s = *(const float4*)(slabs + i4);
+    for (int k = 1; k < nslab; ++k) {
+      const float4 t = *(const float4*)(slabs + k * stride + i4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *(float4*)(g + i4) = s;
+  } else {
+    for (long long i = i4 < lo ? lo : i4; i < i4 + 4 && i < hi; ++i) {
+      float s = slabs[i];
+      for (int k = 1; k < nslab; ++k) s += slabs[k * stride + i];
+      g[i] = s;
+    }
+  }
+}
+
 // ---- kernels of the NT training path (gemm_nt.h) ------------------------------------
 // K5: the Keras data adapter's shuffled batch (emulator.py:369-378 [K]); one wave per batch row: x[idx] -> H0 row and H0^T column, y[idx] -> Y row, w[idx]
 static __global__ void gather_batch_kernel(const float* __restrict__ x, int din, float* __restrict__ h0, long long ldh,
@@ -202,7 +223,7 @@ static __global__ void gauss_sample_bwd_kernel(const GaussArgs a) {
 }
 
 // ---- sweep forms (BASELINE configs[4]: many models, one batch): blockIdx.y = model ----------
-constexpr int kSweepMax = 16;
+constexpr int kSweepMax = 64;  // (r5: BASELINE configs[4] names 64 concurrent configs; 16 until r4.  The by-value argument blocks below stay under the 4-KiB kernel-argument segment: static_asserts)
 // train_chain.h walks the packed weight streams in chunks of kChainUnit 1-KiB fragments (k-steps of 16
 // features); a tile's k-steps are padded to whole chunks
 constexpr int kChainUnit = 4;
@@ -218,6 +239,7 @@ struct LossGroup {
   int n, d;
   float scale;
 };
+static_assert(sizeof(LossGroup) <= 4096, "kernel arguments are limited to 4 KiB");
 static __global__ void loss_grad_t_group_kernel(const LossGroup a) {
   const int k = blockIdx.y;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

@@ -54,13 +54,15 @@ def broadcast_bytes(payload, nbytes, src=0, device=None):
     return bytes(buf.cpu().tolist())
 
 
-def init_engine_comm(ctx, backend="auto", sharded=False):
+def init_engine_comm(ctx, backend="auto", sharded=False, buckets=1):
     """Attach a data-parallel communicator to `ctx` for the current torch.distributed process group.
 
     backend "rccl": the in-library RCCL communicator (unique id broadcast over the process group) -- what a
     one-process-per-GPU run uses.  "host": the library's host-staged transport driven by the process group's own
     collectives (gloo in the CPU/1-GPU tests; under an nccl group the buffer is staged through a device tensor).  "auto": RCCL when the process group is nccl, else host.
-    sharded: reduce-scatter -> Adam on this rank's slice -> all-gather instead of one all-reduce."""
+    sharded: reduce-scatter -> Adam on this rank's slice -> all-gather instead of one all-reduce.
+    buckets: 2 = the all-reduce form's exchange in two messages, the output-side layers' half overlapping the second
+    weight-gradient launch (include/v21.h: v21_comm_set_buckets; r5)."""
     from . import _native
     dist = _dist()
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -98,6 +100,7 @@ def init_engine_comm(ctx, backend="auto", sharded=False):
                 out[r * n_per:(r + 1) * n_per] = part.cpu() if on_gpu else part
         ctx.comm_init_host(world, rank, allreduce, reduce_scatter, allgather)
     ctx.comm_set_sharded(sharded)
+    ctx.comm_set_buckets(buckets)
 
 
 def broadcast_array(arr, src=0, device=None):

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _native, callbacks as cb_mod, engine
 
-MAX_GROUP = 16
+MAX_GROUP = 64  # include/v21.h: v21_sweep_create (r5: 64 = the whole of BASELINE configs[4] in one group; 16 until r4)
 
 
 def fit_models(models, x, y, batch_size=256, epochs=1, validation_data=None, callbacks=None, shuffle=True,

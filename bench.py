@@ -205,7 +205,7 @@ def cpu_baseline(weights_flat, x_f32, budget_s=6.0):
     return out
 
 
-PROFILE_TAG = "r4"  # profiles/<tag>/: the rocprofv3 summaries of this round (scripts/collect_profiles_r4.sh)
+PROFILE_TAG = "r5"  # profiles/<tag>/: the rocprofv3 summaries of this round (scripts/collect_profiles_r4.sh)
 
 
 def _profile_is_current():
@@ -323,7 +323,23 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
         wall = float(t.item())
     loss = tr.last_step_loss() / (batch * world)
     sps = steps / wall
-    return {"steps_per_s": sps, "samples_per_s": sps * batch * world, "ms_per_step": 1e3 / sps,
+    # r5: where the step's time goes -- an UNTIMED repeat of min(steps, 100) steps with HIP-event stamps
+    # around the phases (include/v21.h: v21_trainer_phase_timing); every rank takes part (the steps are collective)
+    phases = None
+    try:
+        np_steps = min(steps, 100)
+        tr.phase_timing(np_steps)
+        for _ in range(np_steps):
+            tr.step_dev(d_x, None, d_rw, batch, batch * world)
+        sync_all()
+        phases = tr.phase_times()
+        tr.phase_timing(0)
+        phases["note"] = ("mean microseconds per step by HIP events on the launch stream, an untimed repeat of the leg's steps; "
+                          "exchange_exposed = the part of the gradient exchange no weight-gradient launch covers; single-rank steps "
+                          "whose gradients and Adam are ONE launch report it under adam_and_repack")
+    except Exception as e:  # pragma: no cover
+        phases = {"error": "%s: %s" % (type(e).__name__, e)}
+    return {"steps_per_s": sps, "phases": phases, "samples_per_s": sps * batch * world, "ms_per_step": 1e3 / sps,
             "batch_per_gpu": batch, "global_batch": batch * world, "precision": precision,
             "model": ("variational " if variational else "") + "autoencoder 451-352-9-32-352-451, relative-MSE" +
                      (" + 1e-3 KL" if variational else "") + ", Adam", "steps": steps,
@@ -384,6 +400,69 @@ def sweep_leg(native, ctx, precision, batch=256, steps_per_epoch=48, epochs=3):
             "speedup": ts / tg, "ms_per_group_step": 1e3 * tg / nsteps,
             "max_rel_loss_diff_vs_one_by_one": float(max(abs(a - b) / b for a, b in zip(lg, ls))),
             "configs": "latent/enc/dec widths " + " ".join("%d/%d/%d-%d" % (c[0], c[1], c[2][0], c[2][1]) for c in SWEEP_CONFIGS)}
+
+
+def sweep_configs(count):
+    """`count` autoencoder configs of SURVEY 8d cfg 5 (latent in 4 .. 32, hidden widths multiples of 32 in [32, 512]): the
+    eight of SWEEP_CONFIGS first, the rest drawn with a fixed seed."""
+    cfgs = list(SWEEP_CONFIGS)
+    rng = np.random.default_rng(64)
+    while len(cfgs) < count:
+        he = int(rng.integers(1, 17)) * 32
+        cfgs.append((int(rng.integers(4, 33)), he, (int(rng.integers(1, 6)) * 32, he)))
+    return cfgs[:count]
+
+
+def sweep_scaling_leg(native, ctx, precision, counts=(8, 16, 32, 64), batch=256, steps_per_epoch=24, epochs=2):
+    """BASELINE configs[4] on ONE GPU: 8 / 16 / 32 / 64 autoencoder configs in ONE group (64 = the whole
+    config), model-steps/s and a roofline object per group size: algorithmic FLOP of the member stacks (per member and row
+    6 x MAC - 2 x (first layer's dX)) over the measured group-step time against the dense MFMA peak of the operand
+    type; the dominant kernels and HBM-side bytes from profiles/<tag>/kernel_stats_sweep_<precision>_m<count>.csv /
+    pmc_sweep_<precision>_m<count>.json when they were collected."""
+    synth = importlib.import_module("21cmvae_amd.synth")
+    pp = importlib.import_module("21cmvae_amd.preprocess")
+    losses = importlib.import_module("21cmvae_amd.losses")
+    n = batch * steps_per_epoch
+    sig = synth.make_signals(n, seed=77)
+    y = pp.preproc(sig, sig)
+    rw = losses.relative_mse_loss(sig)._v21_row_weight(y).astype(np.float32)
+    out = {"batch": batch, "precision": precision, "groups": []}
+    for G in counts:
+        cfgs = sweep_configs(G)
+        trs, flop, params = [], 0, 0
+        for i, (lat, he, hd) in enumerate(cfgs):
+            dims = [451, he, lat, hd[0], hd[1], 451]
+            st = native.Stack(ctx, dims, AE_ACT)
+            st.set_weights(glorot(dims, seed=50 + i))
+            tr = native.Trainer(st, precision, batch)
+            tr.set_adam(lr=1e-3)
+            trs.append(tr)
+            mac = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+            flop += (6 * mac - 2 * dims[0] * dims[1]) * batch
+            params += st.num_params
+        trs[0].set_data(0, y, None, rw)
+        sw = native.Sweep(trs)
+        sw.run_epoch(None, batch)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            lg = sw.run_epoch(None, batch)
+        ctx.sync()
+        tg = time.perf_counter() - t0
+        nsteps = epochs * steps_per_epoch
+        step_s = tg / nsteps
+        leg = {"batch_per_gpu": batch, "precision": precision, "ms_per_step": step_s * 1e3}
+        rf = train_roofline(leg, flop / batch, params, 451, 451, "kernel_stats_sweep_%s_m%d.csv" % (precision, G),
+                            "pmc_sweep_%s_m%d.json" % (precision, G))
+        # (the batch rows are read once per MEMBER by its row blocks: algorithmic bytes count them per member)
+        rf["algorithmic_bytes_per_step"] = G * batch * 4 * 451 + 7 * 4 * params + (2 if precision != "f32" else 4) * params
+        out["groups"].append({"models": G, "model_steps_per_s": G * nsteps / tg, "ms_per_group_step": step_s * 1e3,
+                              "parameters_of_the_group": params, "finite": bool(np.isfinite(lg).all()), "roofline": rf})
+        del sw, trs
+    base = out["groups"][0]["model_steps_per_s"]
+    for g in out["groups"]:
+        g["vs_8_models"] = g["model_steps_per_s"] / base
+    return out
 
 
 def accuracy_leg(native, ctx):
@@ -963,6 +1042,11 @@ def main():
             out["sweep"] = sweep_leg(native, ctx, args.precision)
         except Exception as e:
             out["sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:  # r5: configs[4] on one GPU -- 8 / 16 / 32 / 64 models in one group
+            out["sweep_scaling"] = {"f16": sweep_scaling_leg(native, ctx, args.precision if args.precision != "f32" else "f16"),
+                                    "f32": sweep_scaling_leg(native, ctx, "f32")}
+        except Exception as e:  # pragma: no cover
+            out["sweep_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if args.precision != "f32":  # the same sweep in the reference's arithmetic (grouped launches of train_chain32s.h / dw_adam32.h); every rank, like the leg above
             try:
                 out["sweep_f32"] = sweep_leg(native, ctx, "f32")
@@ -1009,6 +1093,15 @@ def main():
                                                 "kernel_stats_train_b%d_%s.csv" % (args.train_batch, args.precision),
                                                 "pmc_train_b%d_%s.json" % (args.train_batch, args.precision))
                 out["train"] = tl
+                if world > 1:  # r5: the all-reduce in two buckets, the output-side half overlapping the second weight-gradient launch
+                    ctx.comm_set_buckets(2)
+                    tb = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
+                                   args.train_batch, args.precision, args.train_steps, 20)
+                    tb["collective"] = "all-reduce in two buckets (output-side layers + loss slot first, on a second stream)"
+                    tb["transport"] = transport
+                    tb["n_ranks_seen"] = ctx.ranks_seen()
+                    out["train_two_buckets"] = tb
+                    ctx.comm_set_buckets(1)
                 if world > 1:  # the other exchange: reduce-scatter -> Adam on each rank's slice -> all-gather
                     ctx.comm_set_sharded(True)
                     ts = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
@@ -1019,6 +1112,25 @@ def main():
                     out["train_sharded_adam"] = ts
                     ctx.comm_set_sharded(False)
                 if world == 1 and not args.no_extras:
+                    # r5: the COMPUTE side of the data-parallel step on one GPU -- rank 0 of 8 on a communicator without a
+                    # transport (v21_comm_init_null): its 4,096-row share of a 32,768-row global batch through the N > 1
+                    # route (chain -> split-K weight gradients -> [exchange: nothing] -> Adam), one and two buckets.  A SCALE
+                    # curve minus this is wire + collective-launch time.
+                    try:
+                        cn = native.Context(local_rank)
+                        cn.comm_init_null(8, 0)
+                        dpc = {}
+                        for nb in (1, 2):
+                            cn.comm_set_buckets(nb)
+                            d = train_leg(native, cn, native.Stack, 8, 0, None, torch, lambda: None, lambda: cn.sync(),
+                                          args.train_batch, args.precision, args.train_steps, 20)
+                            dpc["buckets_%d" % nb] = {k: d[k] for k in ("ms_per_step", "steps_per_s", "phases", "batch_per_gpu", "global_batch")}
+                        dpc["note"] = ("rank 0 of 8, nothing exchanged (null transport): the three-launch data-parallel step without its "
+                                       "wire time; compare ms_per_step with `train` (single rank: gradients + Adam in one launch)")
+                        cn.comm_destroy()
+                        out["dp_compute_only"] = dpc
+                    except Exception as e:  # pragma: no cover
+                        out["dp_compute_only"] = {"error": "%s: %s" % (type(e).__name__, e)}
                     t32 = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier, sync_all, 256, "f32", 200, 10)
                     t32["roofline"] = train_roofline(t32, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
                                                      "kernel_stats_train_b256_f32.csv", "pmc_train_b256_f32.json")

@@ -276,6 +276,16 @@ int v21_route_train(int n_layers, const int* dims, const int* act, int precision
 int v21_mlp_last_route(v21_mlp* mlp, int* route, long long counts[8]);
 int v21_trainer_last_route(v21_trainer* tr, int* fwd, int* upd, long long fwd_counts[8], long long upd_counts[8]);
 const char* v21_route_name(int kind, int route);
+/* r5: where an eager optimizer step's time goes, by HIP events on the context's stream: v21_trainer_phase_timing(tr, n)
+ * stamps the next n steps (n = 0: off); v21_trainer_phase_times returns the mean milliseconds per step of
+ *   ms[0] forward + loss + activation gradients (the chain / fused training launch, its stream pack included),
+ *   ms[1] weight gradients (+ slab sums),  ms[2] the gradient exchange as far as it is EXPOSED (with two buckets: what is
+ *   left after the second weight-gradient launch),  ms[3] Adam + packed copies,  ms[4] the whole step,
+ * over the steps stamped since the last call (*steps).  Single-rank steps whose gradients and Adam are ONE launch report it
+ * under ms[3]; the per-layer path reports forward, loss and every backward launch under ms[0].  Steps of a joint object or a
+ * sweep are not stamped. */
+int v21_trainer_phase_timing(v21_trainer* tr, int steps);
+int v21_trainer_phase_times(v21_trainer* tr, double ms[5], int* steps);
 /* diagnostics: which route the eager 16-bit steps of this trainer took since it was created:
  * out[0] steps through the 32-row chain kernel (csrc/train_chain.h), out[1] steps through the fused training kernel
  * (csrc/fused_train.h), out[2] of those that had to launch pack_stream_kernel first (the others found the kernel's
@@ -306,7 +316,8 @@ int v21_trainer_set_vae(v21_trainer* tr, float kl_weight, int sample, uint64_t s
  * must share context, precision, max_batch, depth, activations and in/out width (hidden and
  * latent widths differ); trainer 0 holds the training set (v21_trainer_set_data).  Each
  * trainer keeps its own Adam settings, state and weights and can be used on its own
- * (eval, get_state, ...) between sweep epochs.  count <= 16. */
+ * (eval, get_state, ...) between sweep epochs.  count <= 64 (r5; 16 until r4: configs[4] names 64
+ * concurrent configs, and a group of 8 models x 8 row blocks leaves three quarters of the chip idle). */
 typedef struct v21_sweep v21_sweep;
 int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** out);
 int v21_sweep_destroy(v21_sweep* sw); /* the trainers stay alive */
@@ -338,6 +349,17 @@ typedef struct v21_comm_host_ops {
 int v21_comm_get_unique_id(v21_ctx* ctx, void* id /* V21_COMM_ID_BYTES */);
 int v21_comm_init(v21_ctx* ctx, int nranks, int rank, const void* id);
 int v21_comm_init_host(v21_ctx* ctx, int nranks, int rank, const v21_comm_host_ops* ops);
+/* r5: a communicator WITHOUT a transport: the context reports `nranks` ranks, a trainer on it computes this rank's share
+ * of every global batch and takes the N > 1 step structure (operands -> weight gradients -> [exchange: nothing] -> Adam),
+ * so the compute side of a data-parallel step can be timed on ONE GPU (bench.py: dp_compute_only).  The gradients are
+ * NOT summed over anything: results are those of a rank whose peers contributed zeros. */
+int v21_comm_init_null(v21_ctx* ctx, int nranks, int rank);
+/* r5: the all-reduce form's gradient exchange in 1 message (default: the whole arena + loss slot after all weight
+ * gradients) or 2: the weight gradients are formed in two launches, the output-side layers first; their half of the arena
+ * (and the loss slot) is all-reduced on a second stream while the input-side layers' gradients are still being formed.
+ * Same sums per element; with two ranks bit-identical to the one-message form.  Applies to 16-bit chain trainers in
+ * all-reduce mode; every rank of a communicator must set the same value. */
+int v21_comm_set_buckets(v21_ctx* ctx, int buckets);
 int v21_comm_destroy(v21_ctx* ctx);
 int v21_comm_set_sharded(v21_ctx* ctx, int on);
 /* what the attached communicator reports about itself (RCCL: ncclCommCount / ncclCommUserRank); transport: 0 none,

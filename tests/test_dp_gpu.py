@@ -35,7 +35,7 @@ def _data():
     return pp.preproc(sig, sig).astype(np.float32), pp.preproc(sv, sig).astype(np.float32), sig
 
 
-def _fit(prec, seed, world=1, rank=0, sharded=False, port=0, fused=False):
+def _fit(prec, seed, world=1, rank=0, sharded=False, port=0, fused=False, buckets=1, batch=128, rows=300):
     import importlib
     if fused:  # every step through a fused training kernel: the 16-rows-per-wave one (what a trainer of this size takes), or "32": the 128-row one
         os.environ["V21_FUSED_TRAIN_ROWS"] = "1"
@@ -50,16 +50,19 @@ def _fit(prec, seed, world=1, rank=0, sharded=False, port=0, fused=False):
     losses = importlib.import_module("21cmvae_amd.losses")
     optm = importlib.import_module("21cmvae_amd.optimizers")
     y, yv, sig = _data()
+    if rows != 300:   # (the bucket tests: steps of > 1,023 rows per rank take the split-K weight-gradient kernel and its slab sums)
+        sig = pkg("synth").make_signals(rows, seed=4)
+        y = pkg("preprocess").preproc(sig, sig).astype(np.float32)
     if world > 1:
         import torch.distributed as dist
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        importlib.import_module("21cmvae_amd.parallel").init_engine_comm(native.Context.default(), backend="host", sharded=sharded)
+        importlib.import_module("21cmvae_amd.parallel").init_engine_comm(native.Context.default(), backend="host", sharded=sharded, buckets=buckets)
     eng.set_random_seed(seed)  # different on every rank: rank 0's weights and shuffles must win
     m = eng.Sequential([eng.Input((451,))] + [eng.Dense(u, a) for u, a in zip(dims[1:], acts)])
     m.precision = prec
     m.compile(optimizer=optm.Adam(2e-3), loss=losses.relative_mse_loss(sig))
-    h = m.fit(y, y, batch_size=128, epochs=3, validation_data=(yv, yv), verbose=0)   # 128 + 128 + 44 rows per epoch
+    h = m.fit(y, y, batch_size=batch, epochs=3, validation_data=(yv, yv), verbose=0)   # (default: 128 + 128 + 44 rows per epoch)
     out = (np.concatenate([a.ravel() for a in m.get_weights()]), h.history["loss"], h.history["val_loss"],
            m._trainer.get_state())
     if world > 1:
@@ -71,9 +74,9 @@ def _fit(prec, seed, world=1, rank=0, sharded=False, port=0, fused=False):
     return out
 
 
-def _worker(rank, world, port, prec, sharded, q, fused=False):
+def _worker(rank, world, port, prec, sharded, q, fused=False, buckets=1, batch=128, rows=300):
     try:
-        q.put((rank, _fit(prec, seed=100 + rank, world=world, rank=rank, sharded=sharded, port=port, fused=fused)))
+        q.put((rank, _fit(prec, seed=100 + rank, world=world, rank=rank, sharded=sharded, port=port, fused=fused, buckets=buckets, batch=batch, rows=rows)))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
@@ -111,6 +114,72 @@ def test_two_ranks_on_one_gpu_equal_one_process(prec, sharded, fused):
     # (f16: the two halves of a batch meet other waves and other 16-bit roundings than the whole batch in one process;
     #  with the 16-rows-per-wave kernel 5 of 333,420 first moments came to 2.5e-3 of the largest)
     np.testing.assert_allclose(s0[1], ss[1], rtol=0, atol=(1e-5 if prec == "f32" else 4e-3) * np.abs(ss[1]).max())
+
+
+def _run_world(world, prec, fused, buckets, batch, rows):
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, prec, False, q, fused, buckets, batch, rows)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, out in res:
+        assert not isinstance(out, str), out
+    return [out for _, out in res]
+
+
+@pytest.mark.parametrize("case", ["chain_small_steps", "chain_split_k_slabs", "fused_train16"])
+def test_two_gradient_buckets_equal_one_message_bit_for_bit(case):
+    """r5: v21_comm_set_buckets(ctx, 2) forms the weight gradients in two launches, the output-side layers
+    first, and all-reduces their half of the arena (with the loss slot) while the input-side half is still being formed.
+    The same workgroups do the same sums; with two ranks a + b = b + a: weights, losses and Adam moments after three epochs
+    are BIT-IDENTICAL to the one-message form, on every rank -- small steps (gradients straight into the arena), steps whose
+    shares of 1,152 rows take the split-K kernel + the per-bucket slab sums, and shares through the fused training kernel."""
+    prec = "f16"
+    fused, batch, rows = {"chain_small_steps": (False, 128, 300), "chain_split_k_slabs": (False, 2304, 2304 + 700),
+                          "fused_train16": (True, 128, 300)}[case]
+    one = _run_world(2, prec, fused, 1, batch, rows)
+    two = _run_world(2, prec, fused, 2, batch, rows)
+    for (w1, l1, v1, s1), (w2, l2, v2, s2) in zip(one, two):
+        np.testing.assert_array_equal(w1, w2)
+        assert l1 == l2 and v1 == v2 and s1[0] == s2[0]
+        np.testing.assert_array_equal(s1[1], s2[1]); np.testing.assert_array_equal(s1[2], s2[2])
+    np.testing.assert_array_equal(two[0][0], two[1][0])        # and the two ranks agree with each other
+
+
+def test_null_transport_takes_the_multi_rank_step_structure_on_one_gpu(ctx):
+    """r5: v21_comm_init_null -- `nranks` ranks, nothing exchanged: this rank's share of the global batch through the N > 1
+    route (chain -> split-K weight gradients -> [no exchange] -> Adam), for bench.py's dp_compute_only leg.  The gradient is
+    this share's contribution to the global-batch mean: the single-rank gradient of the same rows times rows / global rows."""
+    native = pkg("_native")
+    from oracle import ref_numpy as ora
+    dims, act = DIMS_T1, [1, 0, 1, 1, 0]
+    y, _, sig = _data()
+    w = ora.relative_mse_row_weight(y, sig).astype(np.float32)
+    Ws, bs = ora.init_mlp(dims, seed=3)
+    flat = ora.flatten_params(Ws, bs)
+    c2 = native.Context(0)
+    c2.comm_init_null(4, 0)
+    assert c2.comm_info() == (4, 0, "null")
+    res = {}
+    for name, c, batch in (("null", c2, 300), ("single", ctx, 75)):
+        st = native.Stack(c, dims, act); st.set_weights(flat)
+        tr = native.Trainer(st, "f16", 300); tr.set_adam(lr=0.0)
+        tr.set_data(0, y[:300] if name == "null" else y[:75], None, w[:300] if name == "null" else w[:75])
+        tr.phase_timing(4)
+        tr.run_epoch(None, batch)          # null: rank 0 of 4 takes rows [0, 75) of the 300-row global batch
+        res[name] = (tr.get_grad(), tr.last_route()[0], tr.phase_times())
+    c2.comm_destroy()
+    assert res["null"][1] == ("chain16", "dw16_splitk") and res["single"][1] == ("chain16", "dw16_adam")
+    g0, g1 = res["null"][0], res["single"][0] * (75.0 / 300.0)
+    assert float(g0 @ g1 / (np.linalg.norm(g0) * np.linalg.norm(g1))) > 0.99999 and abs(np.linalg.norm(g0) / np.linalg.norm(g1) - 1) < 1e-3
+    ph = res["null"][2]
+    assert ph["steps"] == 1 and ph["step_us"] > 0 and ph["weight_gradients_us"] > 0 and ph["forward_and_activation_gradients_us"] > 0
+    assert res["single"][2]["weight_gradients_us"] == 0.0     # one launch for gradients + Adam: reported under the Adam phase
 
 
 def _fit_joint(seed, world=1, rank=0, port=0, prec="f16"):
