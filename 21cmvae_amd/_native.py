@@ -129,7 +129,7 @@ SIGNATURES = {
     "v21_comm_destroy": (C.c_int, [_P]),
     "v21_comm_init_null": (C.c_int, [_P, C.c_int, C.c_int]),
     "v21_comm_set_buckets": (C.c_int, [_P, C.c_int]),
-    "v21_trainer_phase_timing": (C.c_int, [_P, C.c_int]),
+    "v21_trainer_phase_timing": (C.c_int, [_P, C.c_int, C.c_int]),
     "v21_trainer_phase_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "v21_comm_set_sharded": (C.c_int, [_P, C.c_int]),
     "v21_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -674,20 +674,37 @@ class Trainer(_Owned):
         check(self.lib.v21_debug_trainer_counters(self.h, out))
         return dict(zip(("chain", "fused", "stream_packs", "stream_adam"), (int(v) for v in out)))
 
-    def phase_timing(self, steps):
-        """Stamp the phases of the next `steps` eager steps with HIP events (include/v21.h: v21_trainer_phase_timing); 0 = off."""
-        check(self.lib.v21_trainer_phase_timing(self.h, int(steps)))
+    def phase_timing(self, steps, cut=4):
+        """Stamp the next `steps` eager steps with two HIP events: the step's start and cut point `cut` (include/v21.h:
+        v21_trainer_phase_timing); steps = 0: off."""
+        check(self.lib.v21_trainer_phase_timing(self.h, int(steps), int(cut)))
 
     def phase_times(self):
-        """-> dict(steps=, forward_and_activation_gradients_us=, weight_gradients_us=, exchange_exposed_us=, adam_and_repack_us=,
-        step_us=): mean per stamped step since the last call."""
-        ms = (C.c_double * 5)()
-        n = C.c_int(0)
-        check(self.lib.v21_trainer_phase_times(self.h, ms, C.byref(n)))
-        keys = ("forward_and_activation_gradients_us", "weight_gradients_us", "exchange_exposed_us", "adam_and_repack_us", "step_us")
-        d = {k: 1e3 * float(v) for k, v in zip(keys, ms)}
-        d["steps"] = n.value
-        return d
+        """-> (mean microseconds from a step's start to the cut point, stamped steps) since the last call."""
+        ms, n = C.c_double(0.0), C.c_int(0)
+        check(self.lib.v21_trainer_phase_times(self.h, C.byref(ms), C.byref(n)))
+        return 1e3 * ms.value, n.value
+
+    def phase_profile(self, step, steps=50):
+        """Where a step's time goes: `step()` (a callable that takes ONE optimizer step on this trainer) is run `steps`
+        times per cut point with two HIP events per step, and the phases are the differences of the four cumulative times
+        (the marker's own cost -- an event is a packet in the stream, ~5 us when nothing separates two -- cancels in them;
+        the first phase still carries one marker: `marker_us` = the stamped whole step minus `unstamped_step_us` when the
+        caller supplies the latter says how much that is).  -> dict of microseconds."""
+        cum = []
+        for cut in (1, 2, 3, 4):
+            self.phase_timing(steps, cut)
+            for _ in range(steps):
+                step()
+            us, n = self.phase_times()
+            cum.append(us if n else float("nan"))
+        self.phase_timing(0)
+        return {"forward_and_activation_gradients_us": cum[0], "weight_gradients_us": cum[1] - cum[0], "exchange_exposed_us": cum[2] - cum[1],
+                "adam_and_repack_us": cum[3] - cum[2], "stamped_step_us": cum[3], "steps_per_cut": steps,
+                "note": "differences of cumulative start-to-cut times of four separate stamped runs (two HIP events per step); the first "
+                        "phase and stamped_step_us carry one marker's cost (stamped_step_us minus the leg's unstamped ms_per_step); "
+                        "exchange_exposed = the part of the gradient exchange no weight-gradient launch covers; single-rank steps whose "
+                        "gradients and Adam are ONE launch report it under adam_and_repack"}
 
     def last_route(self):
         """((forward route, update route) of the last eager step, {(fwd or upd) route name: steps since creation}) -- written

@@ -491,25 +491,19 @@ extern "C" int v21_mlp_forward(v21_mlp* m, const void* x, int x_dtype, int64_t n
   if ((flags & V21_FWD_IN_TRANSFORM) && !m->has_tin) return fail(V21_ERR_STATE, "input transform requested but not set");
   if ((flags & V21_FWD_OUT_TRANSFORM) && !m->has_tout) return fail(V21_ERR_STATE, "output transform requested but not set");
   const bool tin = (flags & V21_FWD_IN_TRANSFORM) != 0;
-  // par_transform of one value ON THE HOST, for the few-row route below: the same two branches as the device's
-  // (par_transform.h) with libm's log10 / log10f -- what numpy calls for float64 / float32 arrays
+  // par_transform of one value ON THE HOST, for the few-row route below: par_transform.h's two functions themselves
+  // (__host__ __device__; r5: until r4 the host used libm's log10f and the device the float64 log10 rounded to float32,
+  // so a float32 parameter vector could differ in its last bit depending on how many rows the call had -- ADVICE r4)
   auto host_value = [&](long long r, int j) -> float {
-    if (x_dtype == V21_DTYPE_F64) {
-      double t = ((const double*)x)[r * din + j];
-      if (!tin) return (float)t;  // Keras casts float64 inputs to float32 [K]
-      const v21_affine_in& a = m->tin;
-      if (a.zero_floor[j] > 0.0 && t == 0.0) t = a.zero_floor[j];
-      if (a.log_mask[j]) t = std::log10(t);
-      t -= a.lo[j]; t /= a.span[j]; t *= 2.0; t -= 1.0;  // preprocess.py:105-108, in this order
-      return (float)t;
-    }
-    float f = ((const float*)x)[r * din + j];
-    if (!tin) return f;
     const v21_affine_in& a = m->tin;
-    if (a.zero_floor[j] > 0.0 && f == 0.f) f = (float)a.zero_floor[j];
-    double t = a.log_mask[j] ? (double)std::log10(f) : (double)f;  // (log10f: np.log10 of a float32 array)
-    t -= a.lo[j]; t /= a.span[j]; t *= 2.0; t -= 1.0;
-    return (float)t;
+    if (x_dtype == V21_DTYPE_F64) {
+      const double t = ((const double*)x)[r * din + j];
+      if (!tin) return (float)t;  // Keras casts float64 inputs to float32 [K]
+      return par_transform_f64(t, a.log_mask[j], a.zero_floor[j], a.lo[j], a.span[j]);
+    }
+    const float f = ((const float*)x)[r * din + j];
+    if (!tin) return f;
+    return par_transform_f32(f, a.log_mask[j], a.zero_floor[j], a.lo[j], a.span[j]);
   };
   const FwdQuery hq{m->L, m->dims.data(), m->act.data(), m->fused_id >= 0, 0, precision, (long long)n, flags & ~V21_FWD_IN_TRANSFORM, (long long)dout};
   if (decide_forward(hq) == FWD_SMALL && (!tin || din <= 8)) {

@@ -231,12 +231,12 @@ struct v21_trainer {
   int* d_cur = nullptr;       // index of the next step's descriptor
   long long desc_next = 0, desc_count = 0;  // host mirror of *d_cur, entries valid in the table
   long long desc_iter0 = -1; float desc_lr = -1.f; bool desc_epoch = false;  // what the table was built for
-  // r5: HIP-event stamps around the phases of an eager step (v21_trainer_phase_timing / v21_trainer_phase_times): five
-  // events per step -- start, after the chain launch, after the last weight-gradient launch, after the exchange has
-  // been joined, after Adam -- for up to phase_cap steps after they were switched on
+  // r5: HIP-event stamps of an eager step (v21_trainer_phase_timing / v21_trainer_phase_times): two events per step -- its
+  // start and ONE cut point (1 after the chain launch, 2 after the last weight-gradient launch, 3 after the exchange has
+  // been joined, 4 after Adam) -- for up to phase_cap steps after they were switched on
   bool phase_on = false;
   std::vector<hipEvent_t> phase_ev;
-  int phase_steps = 0, phase_cap = 0, phase_seen = 0;
+  int phase_steps = 0, phase_cap = 0, phase_seen = 0, phase_cut = 4;
   struct StepGraph { int rows, brows; const void *x, *y, *rw, *idx; long long row0; hipGraph_t graph; hipGraphExec_t exec; };
   std::vector<StepGraph> graphs;
   int graph_misses = 0;

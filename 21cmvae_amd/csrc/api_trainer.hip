@@ -57,11 +57,15 @@ static void note_route(v21_trainer* t, const StepRoute& r) {
 }
 // r5: HIP-event stamps around the phases of an eager step (include/v21.h: v21_trainer_phase_timing)
 static void phase_mark(v21_trainer* t, int idx) {
-  if (!t->phase_on || t->capturing || t->phase_steps >= t->phase_cap) return;
+  // TWO markers per stamped step -- its start and ONE cut point (v21_trainer_phase_timing: `cut`) -- because a HIP event is
+  // a barrier packet of its own: five per step (r5's first form) cost 13 us of a 44-us step, an empty interval between two
+  // of them read 4.6-5.2 us.  The phases come out as differences of the cumulative times of separate runs, in which the
+  // one marker's cost cancels.
+  if (!t->phase_on || t->capturing || t->phase_steps >= t->phase_cap || (idx != 0 && idx != t->phase_cut)) return;
   if (idx == 0) t->phase_seen = 0;
-  (void)hipEventRecord(t->phase_ev[(size_t)t->phase_steps * 5 + idx], t->ctx->stream);
-  t->phase_seen |= 1 << idx;
-  if (idx == 4 && t->phase_seen == 31) t->phase_steps += 1;  // (a step that did not pass all five marks -- the joint step's members -- is not counted)
+  (void)hipEventRecord(t->phase_ev[(size_t)t->phase_steps * 2 + (idx ? 1 : 0)], t->ctx->stream);
+  t->phase_seen |= idx ? 2 : 1;
+  if (idx && t->phase_seen == 3) t->phase_steps += 1;  // (a step that did not pass both marks -- the joint step's members -- is not counted)
 }
 // r5: the gradient exchange of an all-reduce step in TWO messages (v21_comm_set_buckets(ctx, 2)): the arena is
 // [W0 b0 | W1 b1 | ... | W(L-1) b(L-1) | loss]; bucket 1 = the UPPER layers k .. L-1 and the loss slot (their weight
@@ -1685,38 +1689,32 @@ extern "C" int v21_trainer_last_route(v21_trainer* t, int* fwd, int* upd, long l
   if (upd_counts) for (int i = 0; i < 8; ++i) upd_counts[i] = t->upd_count[i];
   return V21_OK;
 }
-extern "C" int v21_trainer_phase_timing(v21_trainer* t, int steps) {
+extern "C" int v21_trainer_phase_timing(v21_trainer* t, int steps, int cut) {
   if (!t) return fail(V21_ERR_ARG, "null trainer");
   if (steps < 0 || steps > 4096) return fail(V21_ERR_ARG, "steps %d not in [0, 4096]", steps);
+  if (steps > 0 && (cut < 1 || cut > 4)) return fail(V21_ERR_ARG, "cut %d not in [1, 4]", cut);
   CHK(use(t->ctx));
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
-  while ((int)t->phase_ev.size() < 5 * steps) {
+  while ((int)t->phase_ev.size() < 2 * steps) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
     t->phase_ev.push_back(e);
   }
-  t->phase_cap = steps; t->phase_steps = 0; t->phase_on = steps > 0;
+  t->phase_cap = steps; t->phase_steps = 0; t->phase_on = steps > 0; t->phase_cut = cut;
   return V21_OK;
 }
-extern "C" int v21_trainer_phase_times(v21_trainer* t, double ms[5], int* steps) {
+extern "C" int v21_trainer_phase_times(v21_trainer* t, double* ms, int* steps) {
   if (!t || !ms || !steps) return fail(V21_ERR_ARG, "null argument");
   CHK(use(t->ctx));
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
-  for (int i = 0; i < 5; ++i) ms[i] = 0.0;
+  *ms = 0.0;
   *steps = t->phase_steps;
   for (int s = 0; s < t->phase_steps; ++s) {
-    hipEvent_t* e = &t->phase_ev[(size_t)s * 5];
-    for (int i = 0; i < 4; ++i) {
-      float f = 0.f;
-      HIPCHK(hipEventElapsedTime(&f, e[i], e[i + 1]));
-      ms[i] += f;
-    }
     float f = 0.f;
-    HIPCHK(hipEventElapsedTime(&f, e[0], e[4]));
-    ms[4] += f;
+    HIPCHK(hipEventElapsedTime(&f, t->phase_ev[(size_t)s * 2], t->phase_ev[(size_t)s * 2 + 1]));
+    *ms += f;
   }
-  if (t->phase_steps > 0)
-    for (int i = 0; i < 5; ++i) ms[i] /= t->phase_steps;
+  if (t->phase_steps > 0) *ms /= t->phase_steps;
   t->phase_steps = 0;
   return V21_OK;
 }

@@ -123,9 +123,9 @@ std::string lib_dir() {
   }
   return ".";
 }
-void mkdirs(const std::string& d) {
+void mkdirs(const std::string& d, mode_t leaf = 0755) {
   for (size_t i = 1; i <= d.size(); ++i)
-    if (i == d.size() || d[i] == '/') mkdir(d.substr(0, i).c_str(), 0755);
+    if (i == d.size() || d[i] == '/') mkdir(d.substr(0, i).c_str(), i == d.size() ? leaf : 0755);
 }
 // A directory whose code objects this process will LOAD AND RUN must be the user's own and closed to others: a
 // world-writable or foreign directory (somebody else created /tmp/21cmvae_amd_kernels_<uid> first) would let another
@@ -135,15 +135,28 @@ bool private_dir(const std::string& d) {
   if (lstat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) return false;
   return sb.st_uid == getuid() && (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0 && access(d.c_str(), W_OK | X_OK) == 0;
 }
-// $V21_KERNEL_CACHE (the caller's word is taken for it), else ~/.cache/21cmvae_amd/kernels, else (no home directory, or one
+// A directory this process only READS code objects from (kernel_cache/ next to the library, written by the build): it and
+// the file must belong to this user or to root and be closed to group and others -- the objects are loaded onto the GPU
+// and run (only the per-user cache directory was checked until r4).
+bool trusted_owner(const struct stat& sb) {
+  return (sb.st_uid == getuid() || sb.st_uid == 0) && (sb.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+bool trusted_dir(const std::string& d) {
+  struct stat sb;
+  return lstat(d.c_str(), &sb) == 0 && S_ISDIR(sb.st_mode) && trusted_owner(sb);
+}
+// $V21_KERNEL_CACHE (it must pass the same test as the default: the user's own, closed to others), else ~/.cache/21cmvae_amd/kernels, else (no home directory, or one
 // that cannot be written: a container running as another user) a per-user directory under /tmp created 0700; "" when
 // neither is the user's own private directory -- kernels are then compiled per process and nothing is cached on disk
 std::string user_cache_dir() {
-  if (const char* e = getenv("V21_KERNEL_CACHE")) return e;
+  if (const char* e = getenv("V21_KERNEL_CACHE")) {
+    mkdirs(e, 0700);
+    return private_dir(e) ? std::string(e) : std::string();
+  }
   const char* home = getenv("HOME");
   if (home && *home) {
     const std::string d = std::string(home) + "/.cache/21cmvae_amd/kernels";
-    mkdirs(d);
+    mkdirs(d, 0700);  // (the leaf holds code objects this process loads and runs: the user's alone)
     if (private_dir(d)) return d;
   }
   const std::string t = "/tmp/21cmvae_amd_kernels_" + std::to_string((long)getuid());
@@ -155,6 +168,8 @@ constexpr char kMagic[8] = {'V', '2', '1', 'K', 'O', 'B', 'J', '1'};
 bool read_cache(const std::string& path, std::string& sym, std::vector<char>& code) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return false;
+  struct stat sb;  // (the open file itself, not the name: nobody can swap it between the check and the read)
+  if (fstat(fileno(f), &sb) != 0 || !S_ISREG(sb.st_mode) || !trusted_owner(sb)) { fclose(f); return false; }
   char magic[8];
   unsigned n = 0;
   bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kMagic, 8) == 0 && fread(&n, 4, 1, f) == 1 && n > 0 && n < 4096;
@@ -206,7 +221,8 @@ struct JitKernel {
   struct Loaded { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; };
   std::map<int, Loaded> loaded;  // per device
   std::thread th;               // waits for the compiler process (v21_jitc)
-  std::atomic<int> child{0};    // its pid while it runs
+  std::atomic<int> child{0};    // its pid while it runs (written under `mu`, together with the spawn)
+  bool cancel = false;          // the process is ending (Registry::~Registry, under `mu`): do not start a compiler any more
 };
 
 namespace {
@@ -215,6 +231,11 @@ struct Registry {
   std::map<std::string, JitKernel*> all;
   ~Registry() {  // the process ends: a compiler process still running is of no use to anybody
     for (auto& kv : all) {
+      // under the kernel's mutex: its thread spawns and publishes the pid under the same mutex, so either the child is
+      // seen here and killed, or it is never started (a child spawned but not yet published made exit() wait
+      // for the whole compilation)
+      std::lock_guard<std::mutex> lk(kv.second->mu);
+      kv.second->cancel = true;
       const int pid = kv.second->child.load();
       if (pid > 0) kill(pid, SIGKILL);
     }
@@ -243,10 +264,23 @@ std::string make_source(const JitKernel& k) {
   src += "};\n};\n}  // namespace v21\n";
   return src;
 }
+// What a cached code object depends on besides the sources, the options and the stack: the format of the cache file and of
+// the host-side launch contract (kCacheFormat: bump it when FusedArgs, the launch geometry or the file layout change), and
+// the toolchain that compiled it -- the version of the HIP runtime this library runs with (hiprtc ships with it; the
+// compiler library itself is only ever loaded in the child process: csrc/jitc_main.cpp says why).  A stale object from
+// before a ROCm upgrade is then never loaded.
+constexpr int kCacheFormat = 2;
+int toolchain_version() {
+  int v = 0;
+  if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; }
+  return v;
+}
 std::string file_name(const JitKernel& k) {
   unsigned long long h = fnv1a(kFusedSrc, sizeof(kFusedSrc));
   for (int i = 0; i < kNumOptions; ++i) h = fnv1a(kOptions[i], strlen(kOptions[i]), h);
   h = fnv1a(k.spec.data(), k.spec.size(), h);
+  const int meta[3] = {kCacheFormat, toolchain_version(), HIP_VERSION};
+  h = fnv1a(meta, sizeof meta, h);
   char buf[32];
   snprintf(buf, sizeof buf, "%016llx", h);
   return "fused_" + k.spec + "_" + buf + ".v21k";
@@ -325,7 +359,8 @@ JitKernel* jit_request(int L, const int* dims, const int* act, int prec) {
   if (it != g_reg.all.end()) return it->second;
   JitKernel* k = new JitKernel();
   fill(k, L, dims, act, prec);
-  const std::string dirs[2] = {lib_dir() + "/kernel_cache", user_cache_dir()};
+  const std::string built = lib_dir() + "/kernel_cache";
+  const std::string dirs[2] = {trusted_dir(built) ? built : std::string(), user_cache_dir()};
   for (const std::string& d : dirs)
     if (!d.empty() && read_cache(d + "/" + k->file, k->sym, k->code)) {
       k->state.store(JIT_READY);
@@ -352,10 +387,29 @@ JitKernel* jit_request(int L, const int* dims, const int* act, int prec) {
     std::vector<char*> argv;
     for (auto& a : av) argv.push_back(a.data());
     argv.push_back(nullptr);
+    // The child gets a SCRUBBED environment: a parent under rocprofv3 or any LD_PRELOAD tool would otherwise hand the pure
+    // compile job its tool libraries (the profiler then initialises the GPU in the compiler process and writes its own
+    // output into the profile directory: ADVICE r4).  Everything else -- PATH, HOME, ROCM_PATH, V21_* -- is kept.
+    std::vector<std::string> envs;
+    for (char** e = environ; e && *e; ++e) {
+      const char* drop[] = {"LD_PRELOAD=", "HSA_TOOLS_LIB=", "HSA_TOOLS_REPORT_LOAD_FAILURE=", "ROCP_", "ROCPROFILER_", "ROCPROF_", "ROCTRACER_",
+                            "ROCTX_", "HIP_TOOLS_LIB=", "OMPT_TOOL_LIBRARIES="};
+      bool keep = true;
+      for (const char* d : drop) keep = keep && strncmp(*e, d, strlen(d)) != 0;
+      if (keep) envs.push_back(*e);
+    }
+    std::vector<char*> envp;
+    for (auto& e : envs) envp.push_back(e.data());
+    envp.push_back(nullptr);
     pid_t pid = 0;
-    const int rc = posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ);
+    int rc = 0;
+    {
+      std::lock_guard<std::mutex> lk(k->mu);
+      if (k->cancel) rc = ECANCELED;
+      else rc = posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), envp.data());
+      if (rc == 0) k->child.store((int)pid);
+    }
     if (rc != 0) { finish(k, JIT_FAILED, "cannot start the compiler process " + helper + ": " + strerror(rc)); return; }
-    k->child.store((int)pid);
     int status = 0;
     while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
     k->child.store(0);

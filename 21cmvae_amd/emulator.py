@@ -150,22 +150,30 @@ def _grid(redshifts_, frequencies):
 class _EmulatorBase:
     par_labels = ["fstar", "Vc", "fx", "tau", "alpha", "nu_min", "Rmfp"]
 
-    def _set_data(self, par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data=True):
-        """``freeze_data`` (default True; not in the reference): ``self.par_train`` and ``self.signal_train`` -- the two
-        arrays whose statistics every ``predict`` needs -- are PRIVATE READ-ONLY COPIES of what the caller passed.  The
-        reference keeps the caller's arrays and recomputes mean / std / min / max of the ~44 MB training set on every
-        call (preprocess.py:22-23, 44-45, 89-101); caching those numbers is exact only while the buffer cannot change,
-        and a read-only copy nobody else holds cannot: a call costs no checksum (r3's default re-hashed the 44 MB per
-        call to stay exact: 1.24 ms for one parameter vector), and an attempt to edit ``em.signal_train`` in place
-        raises numpy's "assignment destination is read-only" instead of being silently ignored.  To change the
-        training set, ASSIGN a new array (``em.signal_train = new``: a new identity, new statistics) or build a new
-        emulator.  ``freeze_data=False`` keeps the reference's by-reference semantics -- the caller's own writable
-        arrays, edits in place honoured -- at the price of a whole-buffer hash per call (``preprocess._cached``)."""
+    def _set_data(self, par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data="auto"):
+        """``freeze_data`` (not in the reference) says how ``self.par_train`` / ``self.signal_train`` -- the two arrays
+        whose statistics every ``predict`` needs -- are held.  The reference keeps the caller's arrays and recomputes mean /
+        std / min / max of the ~44 MB training set on every call (preprocess.py:22-23, 44-45, 89-101); caching those
+        numbers is exact only while the buffer cannot change.
+
+        ``"auto"`` (default since r5): THE CALLER'S OWN ARRAYS, as in the reference -- ``em.signal_train is
+        signal_train``, nothing is held twice -- with their ``writeable`` flag switched off when they own their buffer:
+        nobody can then edit them in place (numpy raises "assignment destination is read-only" instead of the edit being
+        silently ignored), so the statistics are cached on identity alone and a call costs no checksum (~70 us for one
+        parameter vector).  To change the training set, ASSIGN a new array (``em.signal_train = new``) -- or switch the
+        flag back on (``arr.setflags(write=True)``): a writable array is re-hashed on every call, see ``False``.  Arrays that
+        do not own their buffer (views: the base could still be written) are treated as ``False``.
+        ``True`` (r4's default): private read-only COPIES; the caller's arrays are not touched, the training set is held twice.
+        ``False``: the reference's semantics to the letter -- the caller's writable arrays, edits in place honoured -- at
+        the price of a whole-buffer hash per call (``preprocess._cached``: ~1.2 ms on the 44 MB set)."""
         d = _resolve_data(dict(par_train=par_train, par_val=par_val, par_test=par_test,
                                signal_train=signal_train, signal_val=signal_val, signal_test=signal_test))
         for k, v in d.items():
-            if freeze_data and k in ("par_train", "signal_train") and not pp._is_frozen(v):
-                v = pp.freeze(v)
+            if k in ("par_train", "signal_train") and not pp._is_frozen(v):
+                if freeze_data is True:
+                    v = pp.freeze(v)
+                elif freeze_data == "auto" and isinstance(v, np.ndarray) and v.base is None and v.flags.owndata:
+                    v.flags.writeable = False   # (the caller's object, locked: pp._is_frozen(v) holds from here on)
             setattr(self, k, v)
         self.par_labels = list(_EmulatorBase.par_labels)
 
@@ -208,7 +216,7 @@ class DirectEmulator(_EmulatorBase):
 
     def __init__(self, par_train=None, par_val=None, par_test=None, signal_train=None, signal_val=None,
                  signal_test=None, hidden_dims=hidden_dims, activation_func="relu", redshifts=redshifts,
-                 frequencies=None, precision="f32", freeze_data=True):
+                 frequencies=None, precision="f32", freeze_data="auto"):
         self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data)
         self.emulator = _gen_model(self.par_train.shape[-1], hidden_dims, self.signal_train.shape[-1],
                                    activation_func, name="emulator")
@@ -291,7 +299,7 @@ class AutoEncoderEmulator(_EmulatorBase):
                  signal_test=None, latent_dim=latent_dim, enc_hidden_dims=enc_hidden_dims,
                  dec_hidden_dims=dec_hidden_dims, em_hidden_dims=em_hidden_dims, activation_func="relu",
                  redshifts=redshifts, frequencies=None, precision="f32", variational=False, kl_weight=0.0,
-                 freeze_data=True):
+                 freeze_data="auto"):
         self._set_data(par_train, par_val, par_test, signal_train, signal_val, signal_test, freeze_data)
         self.redshifts, self.frequencies = _grid(redshifts, frequencies)
         autoencoder = AutoEncoder(self.signal_train, enc_hidden_dims, dec_hidden_dims, latent_dim, activation_func,

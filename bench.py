@@ -327,16 +327,9 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
     # around the phases (include/v21.h: v21_trainer_phase_timing); every rank takes part (the steps are collective)
     phases = None
     try:
-        np_steps = min(steps, 100)
-        tr.phase_timing(np_steps)
-        for _ in range(np_steps):
-            tr.step_dev(d_x, None, d_rw, batch, batch * world)
+        phases = tr.phase_profile(lambda: tr.step_dev(d_x, None, d_rw, batch, batch * world), steps=min(steps, 50))
         sync_all()
-        phases = tr.phase_times()
-        tr.phase_timing(0)
-        phases["note"] = ("mean microseconds per step by HIP events on the launch stream, an untimed repeat of the leg's steps; "
-                          "exchange_exposed = the part of the gradient exchange no weight-gradient launch covers; single-rank steps "
-                          "whose gradients and Adam are ONE launch report it under adam_and_repack")
+        phases["marker_us"] = phases["stamped_step_us"] - 1e3 / sps
     except Exception as e:  # pragma: no cover
         phases = {"error": "%s: %s" % (type(e).__name__, e)}
     return {"steps_per_s": sps, "phases": phases, "samples_per_s": sps * batch * world, "ms_per_step": 1e3 / sps,
@@ -529,8 +522,9 @@ def latency_leg():
     """Auxiliary metric: what a sampler sees -- DirectEmulator.predict() on ONE parameter vector through
     the class surface (numpy in, numpy out; transforms, PCIe both ways, synchronisation included), with a
     training set of the reference's size (24,562 rows).  The reference quotes 40 ms per call (README.rst:11) and
-    recomputes the training-set statistics on every call.  `f32_default` / `f16_default`: the constructor's default since
-    r4 (`freeze_data=True`: private read-only copies of the training arrays, statistics cached on identity, no checksum);
+    recomputes the training-set statistics on every call.  `f32_default` / `f16_default`: the constructor's default
+    (r5: `freeze_data="auto"` -- the caller's own arrays with their writeable flag off, statistics cached on identity, no checksum;
+    r4: private read-only copies);
     `f32_freeze_data_false_rehash`: the reference's by-reference arrays, re-hashed on every call (r3's default, then
     called `f32_default_rehash`).  An emulator built without explicit data -- the reference's default use -- takes
     read-only arrays from the data set file (`f32_no_argument_constructor`: a synthetic dataset_21cmVAE.h5 of the
@@ -539,8 +533,11 @@ def latency_leg():
     emu = importlib.import_module("21cmvae_amd.emulator")
     data = synth.make_dataset(synth.N_TRAIN, 400, 400)
     res = {}
-    for key, prec, freeze, reps in (("f32_default", "f32", True, 200), ("f16_default", "f16", True, 200),
+    for key, prec, freeze, reps in (("f32_default", "f32", "auto", 200), ("f16_default", "f16", "auto", 200),
                                     ("f32_freeze_data_false_rehash", "f32", False, 10)):
+        if freeze is False:   # (the default locked the caller's arrays above: the reference's semantics need them writable)
+            for k in ("par_train", "signal_train"):
+                data[k].setflags(write=True)
         em = emu.DirectEmulator(hidden_dims=DIMS[1:-1], precision=prec, freeze_data=freeze, **data)
         p1 = data["par_test"][0]
         for _ in range(5):

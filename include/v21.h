@@ -276,16 +276,18 @@ int v21_route_train(int n_layers, const int* dims, const int* act, int precision
 int v21_mlp_last_route(v21_mlp* mlp, int* route, long long counts[8]);
 int v21_trainer_last_route(v21_trainer* tr, int* fwd, int* upd, long long fwd_counts[8], long long upd_counts[8]);
 const char* v21_route_name(int kind, int route);
-/* r5: where an eager optimizer step's time goes, by HIP events on the context's stream: v21_trainer_phase_timing(tr, n)
- * stamps the next n steps (n = 0: off); v21_trainer_phase_times returns the mean milliseconds per step of
- *   ms[0] forward + loss + activation gradients (the chain / fused training launch, its stream pack included),
- *   ms[1] weight gradients (+ slab sums),  ms[2] the gradient exchange as far as it is EXPOSED (with two buckets: what is
- *   left after the second weight-gradient launch),  ms[3] Adam + packed copies,  ms[4] the whole step,
- * over the steps stamped since the last call (*steps).  Single-rank steps whose gradients and Adam are ONE launch report it
- * under ms[3]; the per-layer path reports forward, loss and every backward launch under ms[0].  Steps of a joint object or a
- * sweep are not stamped. */
-int v21_trainer_phase_timing(v21_trainer* tr, int steps);
-int v21_trainer_phase_times(v21_trainer* tr, double ms[5], int* steps);
+/* r5: where an eager optimizer step's time goes, by HIP events on the context's stream.  v21_trainer_phase_timing(tr, n,
+ * cut) stamps the next n steps (n = 0: off) with TWO events each -- the step's start and one cut point:
+ *   cut 1 after forward + loss + activation gradients (the chain / fused training launch, its stream pack included),
+ *   cut 2 after the weight gradients (+ slab sums),  cut 3 after the gradient exchange has been joined,  cut 4 after Adam +
+ *   packed copies (the whole step);
+ * v21_trainer_phase_times returns the mean milliseconds from start to cut over the steps stamped since the last call.
+ * A HIP event is a packet of its own (an empty interval between two reads ~5 us): the phases are DIFFERENCES of the
+ * cumulative times of separate runs, in which the marker's cost cancels (21cmvae_amd/_native.py: Trainer.phase_profile).
+ * Single-rank steps whose gradients and Adam are ONE launch have cut 2 = cut 3 = cut 1; the per-layer path has cut 1 = cut 2
+ * = everything before the exchange.  Steps of a joint object or a sweep are not stamped. */
+int v21_trainer_phase_timing(v21_trainer* tr, int steps, int cut);
+int v21_trainer_phase_times(v21_trainer* tr, double* ms, int* steps);
 /* diagnostics: which route the eager 16-bit steps of this trainer took since it was created:
  * out[0] steps through the 32-row chain kernel (csrc/train_chain.h), out[1] steps through the fused training kernel
  * (csrc/fused_train.h), out[2] of those that had to launch pack_stream_kernel first (the others found the kernel's

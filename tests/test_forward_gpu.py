@@ -473,3 +473,17 @@ def test_clock_stamped_kernel_equals_the_shipped_one_and_reports_every_workgroup
     with pytest.raises(native.EngineError):   # only the headline stack has the instantiation
         st2 = native.Stack(ctx, [7, 288, 352, 288, 224, 451], act)
         st2.forward_clocked(d_x, 7, 10, d_y, 451, d_s, prec, 0)
+
+
+def test_prebuilt_run_time_kernels_are_found_without_a_compiler(ctx, monkeypatch):
+    """__graft_entry__.build() leaves the run-time kernels of the notebook stacks in 21cmvae_amd/kernel_cache/; with
+    compilation switched off (V21_JIT=0) they must still be there for the taking -- i.e. the directory and its files pass
+    the ownership test the loader applies since r5 (this user's or root's, closed to group and others: csrc/jit.hip), and
+    the cache key (sources, options, stack, format, HIP runtime version) is the one the build computed."""
+    native = pkg("_native")
+    monkeypatch.setenv("V21_JIT", "0")
+    st = native.Stack(ctx, [7, 64, 128, 451], [1, 1, 0])
+    Ws, bs = ora.init_mlp([7, 64, 128, 451], seed=8)
+    st.set_weights(ora.flatten_params(Ws, bs))
+    for prec in ("f16", "bf16", "f32"):
+        assert st.jit(prec, wait_ms=0) == "ready"

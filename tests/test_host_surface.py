@@ -57,36 +57,56 @@ def test_frozen_copies_are_cached_on_identity_and_cannot_change():
     assert pp.SignalStats.of(v) is not a
 
 
-def test_emulators_snapshot_their_training_set_by_default(monkeypatch):
-    """r4 contract of the class surface: an emulator keeps private read-only copies of
-    par_train / signal_train (freeze_data=True), so its statistics cache is exact WITHOUT a per-call checksum -- an
-    in-place edit of the emulator's array raises, an edit of the caller's array no longer reaches the emulator, and
-    assigning a new array is seen; freeze_data=False keeps the reference's by-reference arrays and the whole-buffer
-    hash of every call (r3's default)."""
+def test_emulators_hold_the_callers_training_arrays_locked_by_default(monkeypatch):
+    """r5 contract of the class surface (INTEGRATION.md sections 1 and 7): an emulator holds THE CALLER'S OWN
+    par_train / signal_train, as the reference does (`em.signal_train is signal_train`, nothing held twice), with their
+    writeable flag switched off -- so the statistics cache is exact WITHOUT a per-call checksum: an in-place edit raises,
+    assigning a new array is seen, and an array the user unlocks again is re-hashed on every call.  freeze_data=True:
+    private read-only copies (r4's default); freeze_data=False: the caller's writable arrays and the whole-buffer hash."""
     emu, pp, synth = pkg("emulator"), pkg("preprocess"), pkg("synth")
     data = synth.make_dataset(n_train=400, n_val=20, n_test=20, seed=2)
     em = emu.DirectEmulator(hidden_dims=[8], **data)
     for k in ("par_train", "signal_train"):
         a = getattr(em, k)
-        assert a is not data[k] and not a.flags.writeable and np.array_equal(a, data[k])
-    assert em.par_val is data["par_val"]                      # (only the two arrays with cached statistics are copied)
+        assert a is data[k] and not a.flags.writeable          # the caller's object, locked
+    assert em.par_val is data["par_val"] and data["par_val"].flags.writeable   # (only the two arrays with cached statistics)
     s0, p0 = pp.SignalStats.of(em.signal_train), pp.ParamStats.of(em.par_train)
     calls = []
     monkeypatch.setattr(pp, "_digest", lambda buf: calls.append(1) or b"x")
     assert pp.SignalStats.of(em.signal_train) is s0 and pp.ParamStats.of(em.par_train) is p0 and not calls   # no hash
     with pytest.raises(ValueError, match="read-only"):
         em.signal_train[0, 0] = 1.0
-    data["signal_train"][0, 0] += 50.0                        # the caller's buffer is not the emulator's any more
-    assert pp.SignalStats.of(em.signal_train) is s0
+    with pytest.raises(ValueError, match="read-only"):
+        data["signal_train"][0, 0] += 50.0                    # ... through the caller's name as well: it IS that array
     monkeypatch.undo()
-    em.signal_train = data["signal_train"]                    # assignment: a new identity, new statistics
+    # the user unlocks the array: from then on it is re-hashed per call, and an edit in place is seen
+    data["signal_train"].setflags(write=True)
+    data["signal_train"][0, 0] += 50.0
+    s_edit = pp.SignalStats.of(em.signal_train)
+    assert s_edit is not s0 and s_edit.mean[0] == np.mean(data["signal_train"], axis=0)[0]
+    new = data["signal_train"].copy()
+    new[1, 1] -= 7.0
+    em.signal_train = new                                     # assignment: a new identity, new statistics
     s1 = pp.SignalStats.of(em.signal_train)
-    assert s1 is not s0 and s1.mean[0] == np.mean(data["signal_train"], axis=0)[0]
-    # the reference's by-reference semantics on request
-    em2 = emu.AutoEncoderEmulator(freeze_data=False, enc_hidden_dims=[8], dec_hidden_dims=[8], em_hidden_dims=[8], **data)
-    assert em2.signal_train is data["signal_train"] and em2.par_train is data["par_train"]
+    assert s1 is not s_edit and s1.mean[1] == np.mean(new, axis=0)[1]
+    # a view does not own its buffer (the base could still be written): held by reference, hashed per call
+    base = synth.make_dataset(n_train=420, n_val=20, n_test=20, seed=3)
+    view = base["signal_train"][:400]
+    em_v = emu.DirectEmulator(hidden_dims=[8], **dict(data, signal_train=view, par_train=base["par_train"][:400]))
+    assert em_v.signal_train is view and view.flags.writeable
+    a = pp.SignalStats.of(em_v.signal_train)
+    base["signal_train"][3, 3] += 1.0
+    assert pp.SignalStats.of(em_v.signal_train) is not a
+    # r4's default on request: private read-only copies, the caller's arrays untouched
+    data2 = synth.make_dataset(n_train=400, n_val=20, n_test=20, seed=4)
+    em_c = emu.DirectEmulator(hidden_dims=[8], freeze_data=True, **data2)
+    assert em_c.signal_train is not data2["signal_train"] and not em_c.signal_train.flags.writeable and data2["signal_train"].flags.writeable
+    # the reference's by-reference semantics to the letter
+    data3 = synth.make_dataset(n_train=400, n_val=20, n_test=20, seed=5)
+    em2 = emu.AutoEncoderEmulator(freeze_data=False, enc_hidden_dims=[8], dec_hidden_dims=[8], em_hidden_dims=[8], **data3)
+    assert em2.signal_train is data3["signal_train"] and em2.par_train is data3["par_train"] and data3["signal_train"].flags.writeable
     a = pp.SignalStats.of(em2.signal_train)
-    data["signal_train"][3, 3] += 1.0
+    data3["signal_train"][3, 3] += 1.0
     assert pp.SignalStats.of(em2.signal_train) is not a       # the in-place edit is seen (whole-buffer hash)
 
 
