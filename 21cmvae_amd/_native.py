@@ -102,8 +102,9 @@ SIGNATURES = {
     "v21_debug_check_chain_jobs": (C.c_int, [_P, C.c_longlong, C.c_longlong]),
     "v21_debug_trainer_counters": (C.c_int, [_P, C.POINTER(C.c_longlong)]),
     "v21_route_forward": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int)]),
-    "v21_route_train": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+    "v21_route_train": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "v21_trainer_jit": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     "v21_mlp_last_route": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "v21_trainer_last_route": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "v21_route_name": (C.c_char_p, [C.c_int, C.c_int]),
@@ -153,13 +154,14 @@ def route_forward(dims, act, precision, n, flags=0, rt_ready=False):
     return FWD_ROUTES[r.value]
 
 
-def route_train(dims, act, precision, max_batch, rows, nranks=1):
+def route_train(dims, act, precision, max_batch, rows, nranks=1, rt_ready=False):
     """The kernels one optimizer step of `rows` rows takes for a trainer created with max_batch on nranks ranks (pure host
-    logic: no GPU).  -> (name of TRAIN_FWD_ROUTES, name of TRAIN_UPD_ROUTES)."""
+    logic: no GPU; rt_ready: the run-time instantiated fused training kernel of a stack outside archs.h has arrived).
+    -> (name of TRAIN_FWD_ROUTES, name of TRAIN_UPD_ROUTES)."""
     L = len(act)
     f, u = C.c_int(0), C.c_int(0)
     check(load_library().v21_route_train(L, (C.c_int * (L + 1))(*[int(d) for d in dims]), (C.c_int * L)(*[int(a) for a in act]),
-                                         precision_id(precision), int(max_batch), int(rows), int(nranks), C.byref(f), C.byref(u)))
+                                         precision_id(precision), int(max_batch), int(rows), int(nranks), 1 if rt_ready else 0, C.byref(f), C.byref(u)))
     return TRAIN_FWD_ROUTES[f.value], TRAIN_UPD_ROUTES[u.value]
 
 
@@ -549,6 +551,14 @@ class Stack(_Owned):
         check(self.lib.v21_mlp_forward_dev(self.h, _P(d_x), ldx, n, _P(d_y), ldy, precision_id(precision), flags))
 
 
+def jit_prebuild_train(dims, act, precision, directory=None):
+    """jit_prebuild for the fused TRAINING kernel of (dims, act, f16 | bf16) (include/v21.h: v21_trainer_jit)."""
+    lib = load_library()
+    L = len(act)
+    check(lib.v21_jit_prebuild(L, (C.c_int * (L + 1))(*[int(d) for d in dims]), (C.c_int * L)(*[int(a) for a in act]),
+                               precision_id(precision) | 16, directory.encode() if directory else None))
+
+
 def jit_prebuild(dims, act, precision, directory=None):
     """Compile the fused kernel of (dims, act, precision) into `directory` (None: kernel_cache/ next to libv21.so).
     Needs hiprtc but no GPU.  Call it from a process that has not loaded ANOTHER LLVM (importing torch does: hiprtc then
@@ -673,6 +683,13 @@ class Trainer(_Owned):
         out = (C.c_longlong * 4)()
         check(self.lib.v21_debug_trainer_counters(self.h, out))
         return dict(zip(("chain", "fused", "stream_packs", "stream_adam"), (int(v) for v in out)))
+
+    def jit(self, wait_ms=-1):
+        """The fused training kernel of THIS trainer's stack (include/v21.h: v21_trainer_jit): wait up to `wait_ms` (< 0: until
+        compiled) for its run-time instantiation.  -> "ready" / "compiling"; raises EngineError when the trainer cannot have one."""
+        s = C.c_int(0)
+        check(self.lib.v21_trainer_jit(self.h, int(wait_ms), C.byref(s)))
+        return "ready" if s.value == 1 else "compiling"
 
     def phase_timing(self, steps, cut=4):
         """Stamp the next `steps` eager steps with two HIP events: the step's start and cut point `cut` (include/v21.h:

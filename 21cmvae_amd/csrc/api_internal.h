@@ -204,6 +204,7 @@ struct v21_trainer {
   // large steps of f16 / bf16 trainers whose stack has a compiled fused training kernel (fused_train.h; archs.h: T1 ..):
   // index into the registry of api_trainer.hip or -1, and that kernel's packed stream (rebuilt before every launch)
   int train_arch = -1;
+  v21::JitKernel* train_jit = nullptr;  // r5: ... or its run-time instantiation for a stack outside archs.h (jit.hip; asked for at creation)
   bool train16 = false;  // the fused training kernel on 16 rows per wave (fused_train16.h): the stream below is in ITS format
   unsigned char* d_tstream = nullptr;
   int tstream_total = 0, tstream_padded = 0;

@@ -28,7 +28,7 @@ int v21::fused_train_arch_of(int L, const int* dims, const int* act) {
   }
   return -1;
 }
-bool v21::fused_train_rt_eligible(int, const int*, const int*) { return false; }
+bool v21::fused_train_rt_eligible(int L, const int* dims, const int* act) { return v21::jit_train_eligible(L, dims, act, nullptr); }
 
 // ---------------------------------------------------------------------------------
 // trainer (NT path: gemm_nt.h).  Every contraction of a step reads operands whose
@@ -47,9 +47,13 @@ void destroy_graphs(v21_trainer* t) {
 }
 
 // routes.h: the route of a step of `rows` rows of this trainer now, and the record of the step that takes it
+// a fused training kernel can be launched now: compiled in (archs.h), or instantiated at run time and arrived (jit.hip)
+static bool fused_train_ready(const v21_trainer* t) {
+  return t->train_arch >= 0 || (t->train_jit && v21::jit_state(t->train_jit) == v21::JIT_READY);
+}
 static StepRoute step_route(const v21_trainer* t, int rows) {
   const v21_mlp* m = t->mlp;
-  return decide_step(t->kind, m->L, m->dims.data(), m->act.data(), rows, t->ctx->nranks, t->capturing, t->train_arch >= 0, RouteEnv::read());
+  return decide_step(t->kind, m->L, m->dims.data(), m->act.data(), rows, t->ctx->nranks, t->capturing, fused_train_ready(t), RouteEnv::read());
 }
 static void note_route(v21_trainer* t, const StepRoute& r) {
   if (t->capturing) return;
@@ -209,7 +213,16 @@ extern "C" int v21_trainer_create(v21_mlp* m, int precision, int max_batch, v21_
       // a compiled fused training kernel for this stack (large steps; no variational head), and which of the two: the
       // packed weight stream is in the kernel's own format, so the choice is fixed here (routes.h: decide_trainer_kind)
       t->train_arch = t->kind.train_arch;
-      if (t->train_arch >= 0) {
+      if (t->kind.train_rt) {
+        // r5: no compiled kernel, but the template can be instantiated for this stack at run time (jit.hip: fused_train16 only).
+        // Asked for here when the trainer is large enough to ever take it; until the code object arrives -- and if it never
+        // does (no libhiprtc, a stack that spills) -- the steps stay on the chain kernel.  v21_trainer_jit waits for it.
+        const RouteEnv e = RouteEnv::read();
+        const int fused_rows = e.fused_train_rows >= 0 ? e.fused_train_rows : 8193;
+        if (max_batch >= fused_rows) t->train_jit = v21::jit_request(L, m->dims.data(), m->act.data(), precision | v21::kJitTrain16);
+        if (!t->train_jit) t->kind.train_rt = false;
+      }
+      if (t->train_arch >= 0 || t->kind.train_rt) {
         t->train16 = t->kind.train16;
         int total = 0;
         for (int v = 0; v < 2 * L - 1; ++v) {
@@ -352,7 +365,7 @@ extern "C" int v21_trainer_set_data(v21_trainer* t, int which, const float* x, c
   HIPCHK(hipMemcpyAsync(t->d_x[which], x, (size_t)n * din * sizeof(float), hipMemcpyHostToDevice, st));
   if (which == 0) {  // the fused training kernels gather the training rows as 16-bit elements (ChainStep::x16)
     if (t->d_x16) { HIPCHK(hipFree(t->d_x16)); t->d_x16 = nullptr; }
-    if (t->train_arch >= 0 && !(getenv("V21_TRAIN_X16") && getenv("V21_TRAIN_X16")[0] == '0')) {
+    if ((t->train_arch >= 0 || t->kind.train_rt) && !(getenv("V21_TRAIN_X16") && getenv("V21_TRAIN_X16")[0] == '0')) {
       t->ldx16 = (din + 31) / 32 * 32;
       const long long tot = (long long)n * t->ldx16;
       HIPCHK(hipMalloc((void**)&t->d_x16, (size_t)tot * 2));
@@ -781,6 +794,17 @@ static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, con
   // rows of the resident training set: the kernels gather their 16-bit copy
   if (t->d_x16 && ldx == m->dims[0] && x >= t->d_x[0] && x < t->d_x[0] + (size_t)t->n[0] * ldx && (x - t->d_x[0]) % ldx == 0) {
     a.x16 = t->d_x16 + (size_t)((x - t->d_x[0]) / ldx) * t->ldx16; a.ldx16 = t->ldx16;
+  }
+  if (t->train_arch < 0) {  // instantiated at run time (jit.hip)
+    const hipError_t e = v21::jit_launch_train(t->train_jit, t->ctx->device, a, st);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      std::string why;
+      v21::jit_state(t->train_jit, &why);
+      t->n_fused_steps -= 1;
+      return fail(V21_ERR_UNSUPPORTED, "run-time fused training kernel: %s (%s)", why.c_str(), hipGetErrorString(e));
+    }
+    return V21_OK;
   }
   if (t->train16) HIPCHK(g_train[t->train_arch].fn16[t->prec == V21_PREC_F16 ? 0 : 1](a, st));
   else HIPCHK(g_train[t->train_arch].fn[t->prec == V21_PREC_F16 ? 0 : 1](a, st));
@@ -1213,8 +1237,18 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     const bool fused = route.fwd == TR_FUSED64 || route.fwd == TR_FUSED128;
     note_route(t, route);
     fused_step = fused;
-    if (fused) CHK(launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, ts_fresh));
-    else { CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0)); if (!t->capturing) t->n_chain_steps += 1; }
+    bool fused_done = false;
+    if (fused) {
+      const int fr = launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, ts_fresh);
+      if (fr == V21_OK) fused_done = true;
+      else if (t->train_arch >= 0) return fr;
+      else {  // the run-time kernel could not be loaded (it spills: marked failed): this step and every later one take the chain
+        t->kind.train_rt = false; t->train_jit = nullptr;
+        fused_step = false;
+        t->last_route.fwd = TR_CHAIN16; t->fwd_count[TR_CHAIN16] += 1; t->fwd_count[route.fwd & 7] -= 1;
+      }
+    }
+    if (!fused_done) { CHK(launch_chain(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0)); if (!t->capturing) t->n_chain_steps += 1; }
     phase_mark(t, 1);
     // Single rank, nothing to exchange: gradients, Adam and the packed copies in one launch (dw_adam.h) -- up to the
     // batch where its 32 x 32 tiles, each pulling its operands over the WHOLE batch through one CU, lose to the
@@ -1670,15 +1704,36 @@ extern "C" int v21_debug_check_chain_jobs(v21_trainer* t, long long fw_bytes, lo
     return fail(V21_ERR_STATE, "%s", why);
   return V21_OK;
 }
+extern "C" int v21_trainer_jit(v21_trainer* t, int wait_ms, int* status) {
+  if (!t || !status) return fail(V21_ERR_ARG, "null argument");
+  *status = -1;
+  if (t->train_arch >= 0) { *status = 1; return V21_OK; }  // compiled into the library (archs.h)
+  if (!t->train_jit) {
+    std::string why = "the trainer was created with fewer rows per step than the kernel's threshold, or run-time compilation is switched off (V21_JIT=0)";
+    if (t->prec == V21_PREC_F32) why = "f32 trainers have no fused training kernel";
+    else if (!t->chain) why = "the trainer is not on the chain path";
+    else v21::jit_train_eligible(t->mlp->L, t->mlp->dims.data(), t->mlp->act.data(), &why);
+    return fail(V21_ERR_UNSUPPORTED, "no fused training kernel for this trainer: %s", why.c_str());
+  }
+  int s = v21::jit_state(t->train_jit);
+  if (s == v21::JIT_COMPILING && wait_ms != 0) s = v21::jit_wait(t->train_jit, wait_ms);
+  *status = s;
+  if (s == v21::JIT_FAILED) {
+    std::string why;
+    v21::jit_state(t->train_jit, &why);
+    return fail(V21_ERR_UNSUPPORTED, "fused training kernel of this stack: %s", why.c_str());
+  }
+  return V21_OK;
+}
 extern "C" int v21_route_train(int n_layers, const int* dims, const int* act, int precision, int max_batch, int rows, int nranks,
-                               int* fwd, int* upd) {
+                               int rt_ready, int* fwd, int* upd) {
   if (!dims || !act || !fwd || !upd) return fail(V21_ERR_ARG, "null argument");
   if (n_layers < 1 || n_layers > 16) return fail(V21_ERR_ARG, "n_layers %d out of range", n_layers);
   if (precision < 0 || precision > 2) return fail(V21_ERR_ARG, "precision %d unknown", precision);
   if (max_batch < 1 || rows < 1 || rows > max_batch || nranks < 1) return fail(V21_ERR_ARG, "need 1 <= rows <= max_batch and nranks >= 1");
   const RouteEnv e = RouteEnv::read();
   const TrainerKind k = decide_trainer_kind(n_layers, dims, act, precision, max_batch, e);
-  const StepRoute r = decide_step(k, n_layers, dims, act, rows, nranks, false, k.train_arch >= 0, e);
+  const StepRoute r = decide_step(k, n_layers, dims, act, rows, nranks, false, k.train_arch >= 0 || (k.train_rt && rt_ready), e);
   *fwd = r.fwd; *upd = r.upd;
   return V21_OK;
 }

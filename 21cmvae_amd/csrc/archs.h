@@ -22,7 +22,6 @@ namespace v21 {
 struct ArchT1 { static constexpr int L = 5; static constexpr int dims[6] = {451, 352, 9, 32, 352, 451}; static constexpr int act[5] = {1, 0, 1, 1, 0}; };
 struct ArchT2 { static constexpr int L = 5; static constexpr int dims[6] = {7, 352, 352, 352, 224, 9}; static constexpr int act[5] = {1, 1, 1, 1, 0}; };
 struct ArchT3 { static constexpr int L = 5; static constexpr int dims[6] = {7, 288, 352, 288, 224, 451}; static constexpr int act[5] = {1, 1, 1, 1, 0}; };
-constexpr int kTrainRowsPerWg = 128;  // batch rows per workgroup of the fused training kernel (fused_train.h; the host sizes the operand buffers for whole blocks)
 struct ArchT4 { static constexpr int L = 5; static constexpr int dims[6] = {7, 352, 352, 352, 224, 451}; static constexpr int act[5] = {1, 1, 1, 1, 0}; };
 }  // namespace v21
 #define V21_TRAIN_ARCH_LIST(X) X(T1) X(T2) X(T3) X(T4)

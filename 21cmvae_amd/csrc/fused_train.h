@@ -22,9 +22,7 @@
 // Same ChainArgs as train_chain_kernel (a.fw = THIS kernel's packed stream: fused_train_pack in api_trainer.hip).
 #pragma once
 #include "fused_fwd.h"
-#include "gemm_nt.h"
-#include "train_chain.h"
-#include "archs.h"
+#include "chain_types.h"   // (ChainArgs, chain_tr_read, kTrainRowsPerWg -- and nothing else of the chain kernels: csrc/jit.hip compiles this file at run time)
 
 namespace v21 {
 
@@ -48,7 +46,7 @@ constexpr int kTrainStageBytes = 4 * 32 * kTrainStagePitch * 2;         // four 
 constexpr int kTrainMaskTiles = 48;                                     // ReLU mask tiles of a stack (16 bits per lane and tile, kept in LDS)
 constexpr int kTrainMaskBytes = 4 * kTrainMaskTiles * 64 * 2;
 template <class P> constexpr int fused_train_lds() { return fused_lds<P>() + kTrainStageBytes + kTrainMaskBytes; }
-// (kTrainRowsPerWg = 128 rows per workgroup: archs.h)
+// (kTrainRowsPerWg = 128 rows per workgroup: chain_types.h)
 #ifndef V21_TRAIN_WPS
 #define V21_TRAIN_WPS 1
 #endif

@@ -15,10 +15,16 @@
 #include <string>
 
 #include "fused_fwd.h"
+#include "chain_types.h"
 
 namespace v21 {
 struct JitKernel;  // one (stack, precision); lives until the library is unloaded
 enum { JIT_COMPILING = 0, JIT_READY = 1, JIT_FAILED = -1 };
+// r5: `prec | kJitTrain16` asks for the fused TRAINING kernel of the stack (fused_train16<Arch, Prec>, f16 / bf16) instead
+// of the forward kernel: same registry, same caches, same compiler process
+constexpr int kJitTrain16 = 16;
+bool jit_train_eligible(int L, const int* dims, const int* act, std::string* why);
+hipError_t jit_launch_train(JitKernel* k, int device, const ChainArgs& a, hipStream_t st);
 
 // false (with a reason) for stacks fused_fwd cannot express: a non-linear output layer, a variational head, > 16 layers
 bool jit_eligible(int L, const int* dims, const int* act, std::string* why);

@@ -1,5 +1,9 @@
-// jit.hip -- run-time instantiation of fused_fwd<Arch, Prec> through hiprtc (see jit.h).
+// jit.hip -- run-time instantiation of fused_fwd<Arch, Prec> -- and, r5, of the fused training kernel
+// fused_train16<Arch, Prec> -- through hiprtc (see jit.h).  A kernel's KIND rides in bit 4 of the precision argument of
+// the internal interface (kJitTrain16 | V21_PREC_F16 ...), so that the registry, the cache and the compiler process
+// (v21_jitc -> v21_jit_prebuild) serve both with the same code.
 #include "jit.h"
+#include "fused_train16.h"
 
 #include <dlfcn.h>
 #include <signal.h>
@@ -27,6 +31,12 @@ namespace {
 const unsigned char kFusedSrc[] = {
 #include "fused_src.inc"
     0};
+// ... + chain_types.h + fused_train.h + fused_train16.h (Makefile: fused_train_src.inc)
+const unsigned char kTrainSrc[] = {
+#include "fused_train_src.inc"
+    0};
+inline bool is_train(int prec) { return (prec & kJitTrain16) != 0; }
+inline int base_prec(int prec) { return prec & 15; }
 
 // ---- hiprtc, loaded at run time (a user who never predicts on a custom stack needs no libhiprtc)
 typedef void* rtc_prog;
@@ -95,11 +105,24 @@ bool jit_wide() { const char* e = getenv("V21_JIT_WIDE"); return e && e[0] == '1
 bool jit_wide() { return false; }
 #endif
 const char* prec_type(int prec, bool wide) {
+  if (is_train(prec)) return base_prec(prec) == 1 ? "PrecF16t16" : "PrecBF16t16";
   return prec == 0 ? "PrecF32" : (prec == 1 ? (wide ? "PrecF16" : "PrecF16x2sp") : (wide ? "PrecBF16" : "PrecBF16x2sp"));
+}
+// LDS read-ahead (fragments) of a run-time training kernel: the template's default (V21_TRAIN16_DEPTH = 4) unless the loss
+// layer has several tiles and too few k-steps per tile for it (fused_train16.h: the target double buffer needs
+// ks_of(L - 1) > depth) -- the sample notebook's 7 -> [64, 128] -> 451 has four: depth 3.  Passed to hiprtc as
+// -DV21_TRAIN16_DEPTH and part of the kernel's name in the cache.
+int train_depth(int L, const int* dims) {
+  if (dims[L] <= 16) return V21_TRAIN16_DEPTH;
+  const int ks = (dims[L - 1] + 31) / 32;
+  return ks - 1 < V21_TRAIN16_DEPTH ? ks - 1 : V21_TRAIN16_DEPTH;
 }
 struct Launch { int rows_per_wg, threads, lds; };
 template <class P> constexpr Launch launch_of() { return Launch{P::WAVES * P::CT * 32, 64 * P::WAVES, fused_lds_alloc<P>()}; }
 Launch launch_geometry(int prec, bool wide) {
+  if (is_train(prec))
+    return base_prec(prec) == 1 ? Launch{kTrain16RowsPerWg, 64 * PrecF16t16::WAVES, fused_train16_lds<PrecF16t16>()}
+                                : Launch{kTrain16RowsPerWg, 64 * PrecBF16t16::WAVES, fused_train16_lds<PrecBF16t16>()};
   if (prec == 0) return launch_of<PrecF32>();
   if (prec == 1) return wide ? launch_of<PrecF16>() : launch_of<PrecF16x2sp>();
   return wide ? launch_of<PrecBF16>() : launch_of<PrecBF16x2sp>();
@@ -246,7 +269,8 @@ struct Registry {
 Registry g_reg;
 
 std::string make_spec(int L, const int* dims, const int* act, int prec, bool wide) {
-  std::string s;
+  std::string s = is_train(prec) ? "train16_" : "";
+  if (is_train(prec) && train_depth(L, dims) != V21_TRAIN16_DEPTH) s += "d" + std::to_string(train_depth(L, dims)) + "_";
   for (int l = 0; l <= L; ++l) s += (l ? "x" : "") + std::to_string(dims[l]);
   s += "_a";
   for (int l = 0; l < L; ++l) s += act[l] ? "1" : "0";
@@ -255,7 +279,7 @@ std::string make_spec(int L, const int* dims, const int* act, int prec, bool wid
   return s;
 }
 std::string make_source(const JitKernel& k) {
-  std::string src((const char*)kFusedSrc);
+  std::string src((const char*)(is_train(k.prec) ? kTrainSrc : kFusedSrc));
   src += "\nnamespace v21 {\nstruct ArchRT {\n  static constexpr int L = " + std::to_string(k.L) + ";\n  static constexpr int dims[" +
          std::to_string(k.L + 1) + "] = {";
   for (int l = 0; l <= k.L; ++l) src += (l ? ", " : "") + std::to_string(k.dims[l]);
@@ -271,12 +295,19 @@ std::string make_source(const JitKernel& k) {
 // before a ROCm upgrade is then never loaded.
 constexpr int kCacheFormat = 2;
 int toolchain_version() {
-  int v = 0;
-  if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; }
-  return v;
+  // (the compiler process is told by its parent -- V21_JIT_TOOLCHAIN in the environment it is spawned with: asking the HIP
+  //  runtime initialises it, and a process that has the GPU open counts against the box's limit of six -- a test run with
+  //  ten compilations in flight was killed for it, r5)
+  if (const char* e = getenv("V21_JIT_TOOLCHAIN")) return atoi(e);
+  static const int cached = [] {
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; }
+    return v;
+  }();
+  return cached;
 }
 std::string file_name(const JitKernel& k) {
-  unsigned long long h = fnv1a(kFusedSrc, sizeof(kFusedSrc));
+  unsigned long long h = is_train(k.prec) ? fnv1a(kTrainSrc, sizeof(kTrainSrc)) : fnv1a(kFusedSrc, sizeof(kFusedSrc));
   for (int i = 0; i < kNumOptions; ++i) h = fnv1a(kOptions[i], strlen(kOptions[i]), h);
   h = fnv1a(k.spec.data(), k.spec.size(), h);
   const int meta[3] = {kCacheFormat, toolchain_version(), HIP_VERSION};
@@ -289,12 +320,19 @@ std::string file_name(const JitKernel& k) {
 int compile(const JitKernel& k, std::string& sym, std::vector<char>& code, std::string& why) {
   if (!load_rtc(&why)) return -1;
   const std::string src = make_source(k);
-  const std::string expr = std::string("v21::fused_fwd<v21::ArchRT, v21::") + prec_type(k.prec, k.wide) + ">";
+  const std::string expr = std::string(is_train(k.prec) ? "v21::fused_train16<v21::ArchRT, v21::" : "v21::fused_fwd<v21::ArchRT, v21::") +
+                           prec_type(k.prec, k.wide) + ">";
   rtc_prog prog = nullptr;
   int r = g_rtc.CreateProgram(&prog, src.c_str(), "v21_fused_rt.hip", 0, nullptr, nullptr);
   if (r != 0) { why = "hiprtcCreateProgram failed"; return -1; }
   r = g_rtc.AddNameExpression(prog, expr.c_str());
-  if (r == 0) r = g_rtc.CompileProgram(prog, kNumOptions, kOptions);
+  std::vector<const char*> opts(kOptions, kOptions + kNumOptions);
+  std::string depth_opt;
+  if (is_train(k.prec) && train_depth(k.L, k.dims) != V21_TRAIN16_DEPTH) {
+    depth_opt = "-DV21_TRAIN16_DEPTH=" + std::to_string(train_depth(k.L, k.dims));
+    opts.push_back(depth_opt.c_str());
+  }
+  if (r == 0) r = g_rtc.CompileProgram(prog, (int)opts.size(), opts.data());
   if (r != 0) {
     size_t n = 0;
     g_rtc.GetProgramLogSize(prog, &n);
@@ -351,8 +389,31 @@ bool jit_eligible(int L, const int* dims, const int* act, std::string* why) {
   return true;
 }
 
+// The fused training kernel on 16 rows per wave (fused_train16.h) for a stack outside archs.h.  What the template's own
+// static_asserts and its register budget allow: a linear output layer, ReLU / linear hidden layers, no variational head,
+// 2 .. 8 layers up to 512 wide (the chain kernel's limit: the trainer falls back to it), at most 44 ReLU mask tile pairs,
+// a loss layer of one 16-wide tile or fed by more than 32 x (read-ahead) features.  A kernel that spills anyway is
+// rejected when it is loaded (scratch memory), as the forward kernels are.
+bool jit_train_eligible(int L, const int* dims, const int* act, std::string* why) {
+  auto no = [&](const char* w) { if (why) *why = w; return false; };
+  if (L < 2 || L > 8) return no("layer count not in [2, 8]");
+  if (act[L - 1] != 0) return no("the loss is taken on a linear output layer");
+  int pairs = 0;
+  for (int l = 0; l < L; ++l) {
+    if (act[l] != 0 && act[l] != 1) return no("the fused training kernel has no variational head");
+    if (l + 1 < L && act[l]) pairs += ((dims[l + 1] + 15) / 16 + 1) / 2;
+  }
+  for (int l = 0; l <= L; ++l)
+    if (dims[l] < 1 || dims[l] > 512) return no("layer width not in [1, 512]");
+  if (pairs > kTrain16MaskPairs) return no("too many ReLU mask tiles for the kernel's LDS area");
+  if (train_depth(L, dims) < 1) return no("the loss layer's input is too narrow for the target double buffer");
+  return true;
+}
+
 JitKernel* jit_request(int L, const int* dims, const int* act, int prec) {
-  if (prec < 0 || prec > 2 || !jit_eligible(L, dims, act, nullptr)) return nullptr;
+  if (is_train(prec)) {
+    if ((base_prec(prec) != 1 && base_prec(prec) != 2) || !jit_train_eligible(L, dims, act, nullptr)) return nullptr;
+  } else if (prec < 0 || prec > 2 || !jit_eligible(L, dims, act, nullptr)) return nullptr;
   const std::string spec = make_spec(L, dims, act, prec, jit_wide());
   std::lock_guard<std::mutex> lk(g_reg.mu);
   auto it = g_reg.all.find(spec);
@@ -392,12 +453,13 @@ JitKernel* jit_request(int L, const int* dims, const int* act, int prec) {
     // output into the profile directory: ADVICE r4).  Everything else -- PATH, HOME, ROCM_PATH, V21_* -- is kept.
     std::vector<std::string> envs;
     for (char** e = environ; e && *e; ++e) {
-      const char* drop[] = {"LD_PRELOAD=", "HSA_TOOLS_LIB=", "HSA_TOOLS_REPORT_LOAD_FAILURE=", "ROCP_", "ROCPROFILER_", "ROCPROF_", "ROCTRACER_",
+      const char* drop[] = {"V21_JIT_TOOLCHAIN=", "LD_PRELOAD=", "HSA_TOOLS_LIB=", "HSA_TOOLS_REPORT_LOAD_FAILURE=", "ROCP_", "ROCPROFILER_", "ROCPROF_", "ROCTRACER_",
                             "ROCTX_", "HIP_TOOLS_LIB=", "OMPT_TOOL_LIBRARIES="};
       bool keep = true;
       for (const char* d : drop) keep = keep && strncmp(*e, d, strlen(d)) != 0;
       if (keep) envs.push_back(*e);
     }
+    envs.push_back("V21_JIT_TOOLCHAIN=" + std::to_string(toolchain_version()));
     std::vector<char*> envp;
     for (auto& e : envs) envp.push_back(e.data());
     envp.push_back(nullptr);
@@ -453,7 +515,16 @@ int jit_wait(JitKernel* k, int timeout_ms) {
   return k->state.load(std::memory_order_acquire);
 }
 
+static hipError_t jit_launch_any(JitKernel* k, int device, void* arg_block, long long rows, hipStream_t st);
 hipError_t jit_launch(JitKernel* k, int device, const FusedArgs& a, hipStream_t st) {
+  FusedArgs copy = a;
+  return jit_launch_any(k, device, &copy, a.n_rows, st);
+}
+hipError_t jit_launch_train(JitKernel* k, int device, const ChainArgs& a, hipStream_t st) {
+  ChainArgs copy = a;
+  return jit_launch_any(k, device, &copy, a.rows, st);
+}
+static hipError_t jit_launch_any(JitKernel* k, int device, void* arg_block, long long rows, hipStream_t st) {
   if (!k) return hipErrorInvalidValue;
   const int s = k->state.load(std::memory_order_acquire);
   if (s == JIT_COMPILING) return hipErrorNotReady;
@@ -490,16 +561,18 @@ hipError_t jit_launch(JitKernel* k, int device, const FusedArgs& a, hipStream_t 
     }
     ld = it->second;
   }
-  const long long nwg = (a.n_rows + g.rows_per_wg - 1) / g.rows_per_wg;
+  long long nwg = (rows + g.rows_per_wg - 1) / g.rows_per_wg;
   if (nwg <= 0) return hipSuccess;
-  FusedArgs copy = a;
-  void* args[] = {(void*)&copy};
+  if (is_train(k->prec)) nwg = (nwg + 7) / 8 * 8;  // (whole rounds of the 8 XCDs: the kernel maps block numbers XCD-major and the surplus leaves)
+  void* args[] = {arg_block};
   return hipModuleLaunchKernel(ld.fn, (unsigned)nwg, 1, 1, (unsigned)g.threads, 1, 1, (unsigned)g.lds, st, args, nullptr);
 }
 
 int jit_prebuild(int L, const int* dims, const int* act, int prec, const char* dir, std::string* why) {
   std::string w;
-  if (prec < 0 || prec > 2 || !jit_eligible(L, dims, act, &w)) { if (why) *why = w.empty() ? "bad precision" : w; return -1; }
+  const bool ok = is_train(prec) ? ((base_prec(prec) == 1 || base_prec(prec) == 2) && jit_train_eligible(L, dims, act, &w))
+                                 : (prec >= 0 && prec <= 2 && jit_eligible(L, dims, act, &w));
+  if (!ok) { if (why) *why = w.empty() ? "bad precision" : w; return -1; }
   JitKernel k;
   fill(&k, L, dims, act, prec);
   const std::string d = dir && *dir ? dir : lib_dir() + "/kernel_cache";

@@ -109,11 +109,13 @@ inline TrainerKind decide_trainer_kind(int L, const int* dims, const int* act, i
     k.chain = ok && mask_tiles <= kChainMaskTiles;
     if (k.chain && k.gl < 0 && e.fused_train) {
       k.train_arch = fused_train_arch_of(L, dims, act);
-      k.train_rt = k.train_arch < 0 && e.jit && fused_train_rt_eligible(L, dims, act);
+      // (only the 16-rows-per-wave kernel is instantiated at run time: a stack outside archs.h takes it whatever max_batch is)
+      k.train_rt = k.train_arch < 0 && e.fused_train16 != 0 && fused_train_rt_eligible(L, dims, act);
       // 16 rows per wave (64-row workgroups, two per CU) for trainers of fewer than 24,576 rows per step: a step of
       // 8,193 .. 24,575 rows does not fill the chip with 128-row workgroups; above, both take the same time and the
       // 128-row form has the evener workgroups
-      if (k.train_arch >= 0 || k.train_rt) k.train16 = e.fused_train16 >= 0 ? e.fused_train16 == 1 : max_batch < 24576;
+      if (k.train_arch >= 0) k.train16 = e.fused_train16 >= 0 ? e.fused_train16 == 1 : max_batch < 24576;
+      if (k.train_rt) k.train16 = true;
     }
   } else {
     bool ok = e.train_chain && narrow;

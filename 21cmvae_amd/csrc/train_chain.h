@@ -52,83 +52,7 @@ constexpr int kChainZPitch = 2 * kChainMaxLatent + 4;
 constexpr int kChainZBytes = 32 * kChainZPitch * 4 + 32 * 4;  // fp32 (mu | lv) rows + kl_weight * KL per row
 constexpr int kChainLdsBytes = kChainBufBytes + kChainMaskBytes + kChainSmallBytes + 32 * kChainYPitch * 4 + kChainZBytes;
 
-struct ChainLayer {
-  int K, N;            // Dense input / output width
-  int KS, NT;          // forward: k-steps of 16 (padded to whole chunks: chain_steps), 32-wide output tiles
-  int NS, KT;          // backward: n-steps of 16 (padded likewise), 32-wide input tiles
-  int relu;            // ReLU on this layer's output
-  int gauss;           // variational head (V21_ACT_GAUSS): N = 2*latent Dense outputs [z_mean | z_log_var]; the
-                       // next layer sees z = z_mean + exp(z_log_var/2) eps (latent wide)
-  int mask_tile;       // first tile of this layer's output mask in LDS (-1: none)
-  long long fw_off, bw_off;  // fragment offsets (units of 8 elements) into the packed streams
-  long long b_off;     // bias offset in the arena
-  // operands of the weight gradient (gemm_dw16_kernel below), written here in MFMA-fragment order:
-  // element (feature f, batch row b) at ((f/32 * BS + b/16) * 64 + 32*((b%16)/8) + f%32) * 8 + b%8
-  void* ht16;          // input of this layer (K features; feature K is a constant row of ones)
-  void* dzt16;         // gs * gradient w.r.t. this layer's output (N features)
-};
-// what stays the same from step to step: one per model (a sweep keeps a table of them in HBM)
-struct ChainModel {
-  int L;
-  ChainLayer lt[16];
-  const void* fw; const void* bw;  // packed weight streams
-  long long fw_bytes, bw_bytes;    // their sizes (the prefetcher workgroups touch every line once)
-  const float* w;                  // arena (biases)
-  long long BS;                    // batch steps of 16 per feature tile of the transposed buffers
-  // batch loss: every workgroup adds its rows' losses as 2^-32 fixed point (an integer sum does not
-  // depend on the order of arrival); gemm_dw16_kernel turns it into the float slot and clears it
-  unsigned long long* loss_acc;
-  unsigned long long* stamps;      // diagnostics: s_memtime of workgroup 0 at every phase boundary
-  // variational head (per model, so the members of a sweep may differ): loss_i += kl_weight * KL_i;
-  // eps keyed on (seed, step, row0 + row, d) as in train_kernels.h
-  float kl_weight;
-  int sample;
-  unsigned long long seed, step;
-  // joint step (train_chain_joint_kernel): the fp32 outputs of this (linear) layer stay in LDS as the NEXT
-  // model's targets (-1: none) -- the autoencoder's latent layer, emulator.py:753-754 without the host round trip
-  int zcap_layer;
-  // train_chain32s.h: what every wave does in every layer, worked out by the host (C32sJob rows, read with scalar loads)
-  const int* jobs;
-};
-// the batch of this step (shared by every model of a sweep)
-struct ChainStep {
-  const float* x; long long ldx;   // source rows
-  // the same rows as 16-bit operand elements (f16 / bf16 as the trainer's precision), row pitch ldx16 halves, zero-padded to
-  // a multiple of 32 features: what the fused training kernels gather instead of x when the step reads the trainer's
-  // resident training set (api_trainer.hip: v21_trainer_set_data) -- large steps are bound by HBM traffic, and the input
-  // rows are rounded to 16 bits on their way into the first MFMA either way; nullptr: none
-  const unsigned short* x16; long long ldx16;
-  const float* y; long long ldy;   // targets (nullptr: y == x, the autoencoder)
-  const float* rw;                 // row weights w_i
-  const int* idx; long long first; // row m of the batch = source row idx[first + m] (or first + m)
-  int rows;                        // rows of this rank's batch
-  float scale;                     // 2 / B_global
-  float gs;                        // gradient operand scale (power of two)
-  float inv_b;                     // 1 / B_global (the KL term's own gradient)
-  unsigned long long row0;         // position of this rank's first row in the global batch (noise key)
-  unsigned long long step_off;     // steps since the per-model `step` was stored (a sweep stores it once per epoch)
-  StepCtx sc;                      // replayed step (hipGraph): `first` comes from the step descriptor
-  int y_from_lds;                  // joint step: the targets are the rows the previous model left in LDS (zcap_layer)
-  // workgroups [0, ncons) carry row blocks; workgroups ncons + 8 p + x (p < npref) are PREFETCHERS of XCD x: they
-  // touch every 128-byte line of the model's weight streams once and leave (see chain_prefetch)
-  int ncons, npref;
-  // validation pass: gather, forward and loss only -- nothing is written but the loss accumulator, so the launch may
-  // cover ANY number of rows (the weight-gradient operands, sized for max_batch, are not touched)
-  int fwd_only;
-  // joint step: the emulator's workgroups first run the ENCODER alone (forward layers [0, nfwd) of the autoencoder,
-  // nothing written but the captured latents) -- nfwd = 0: the whole stack
-  int nfwd;
-  int blk0;  // physical block blk0 is logical block 0 of this body (the joint kernel runs two families of row blocks)
-  // FORWARD mode (Model.predict of any stack up to 512 wide, emulator.py:402 / :789-790; with fwd_only): the last layer's
-  // outputs leave as fp32 rows out[row * ldo + n] = z * out_std + out_mean[n] (preprocess.unpreproc, preprocess.py:27-46;
-  // out_mean == nullptr: plain outputs) instead of entering a loss; tin != nullptr: preprocess.par_transform
-  // (preprocess.py:49-110, statistics cached in *tin, device memory) is applied to the <= 8 input columns as they
-  // are gathered.  out == nullptr: training / validation.
-  float* out; long long ldo;
-  float out_std; const float* out_mean;
-  const v21_affine_in* tin;
-};
-struct ChainArgs : ChainModel, ChainStep {};
+// (ChainLayer / ChainModel / ChainStep / ChainArgs: chain_types.h)
 __device__ __forceinline__ void chain_stamp(const ChainModel& a, int i) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.stamps) {  // (physical block 0 is row block 0)
     unsigned long long t;
@@ -242,14 +166,7 @@ __global__ void __launch_bounds__(64 * kChainWaves) train_chain_joint_kernel(con
 // its fence would also drain the weight loads that are in flight across the barrier (vmcnt(0)).
 __device__ __forceinline__ void chain_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-typedef short chain_s4 __attribute__((ext_vector_type(4)));
-typedef short chain_s8 __attribute__((ext_vector_type(8)));
-// hardware transpose read (ds_read_b64_tr_b16): per 16-lane group a 4-row x 16-column block of 16-bit
-// elements; lane 4q+p supplies the address of row q, columns 4p..4p+3 and lane i receives column i of
-// the four rows.  EXEC must be all ones.
-__device__ __forceinline__ chain_s4 chain_tr_read(const void* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((chain_s4 __attribute__((address_space(3)))*)p);
-}
+// (chain_s4 / chain_s8 / chain_tr_read: chain_types.h)
 
 // FEAT: the features this instantiation carries -- kChainGauss: a variational layer (sampling, KL, its backward);
 // kChainJoint: the joint step's captured latents, targets from LDS, encoder-only passes, shifted block numbers;

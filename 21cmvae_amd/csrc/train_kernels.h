@@ -6,15 +6,11 @@
 
 #include "../../include/v21.h"
 #include "par_transform.h"
+#include "chain_types.h"
 
 namespace v21 {
 
-// What differs between two optimizer steps of one epoch when a captured step is replayed (hipGraph):
-// where the batch starts, Adam's bias-corrected step size, and the slot of the step's loss.  The host
-// writes one descriptor per step of the epoch; the kernels read descriptor number *cur; the last
-// node of the captured step increments *cur.  desc == nullptr: the values in the kernel arguments.
-struct StepDesc { long long first; float alpha; int slot; };
-struct StepCtx { const StepDesc* desc; const int* cur; };
+// (StepDesc / StepCtx: chain_types.h)
 static __global__ void step_tick_kernel(int* cur) { *cur += 1; }
 
 // K2: loss_i = w_i sum_j (p - y)^2 (relative_mse_loss, emulator.py:68-81, with

@@ -340,6 +340,49 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
             "collective": "all-reduce of the flat gradient arena (%d floats)" % (st.num_params + 1) if world > 1 else "none"}
 
 
+def custom_train_leg(native, ctx, precision, batch=16384, steps=60):
+    """r5: a stack WITHOUT a compiled fused training kernel -- the sample notebook's 7 -> [64, 128] -> 451
+    -- at 16,384 rows per step: the fused training kernel instantiated at run time (csrc/jit.hip: fused_train16<ArchRT, Prec>,
+    prebuilt by build(), else compiled in a child process while the chain kernel serves) against the chain route."""
+    synth = importlib.import_module("21cmvae_amd.synth")
+    pp = importlib.import_module("21cmvae_amd.preprocess")
+    losses = importlib.import_module("21cmvae_amd.losses")
+    dims, act = [7, 64, 128, 451], [1, 1, 0]
+    sig = synth.make_signals(batch, seed=91)
+    y = pp.preproc(sig, sig)
+    rw = losses.relative_mse_loss(sig)._v21_row_weight(y).astype(np.float32)
+    x = np.random.default_rng(5).uniform(-1, 1, size=(batch, 7)).astype(np.float32)
+    out = {"stack": "7-64-128-451", "batch": batch, "precision": precision}
+    for name in ("fused_run_time_kernel", "chain"):
+        if name == "chain":
+            os.environ["V21_FUSED_TRAIN"] = "0"
+        try:
+            st = native.Stack(ctx, dims, act)
+            st.set_weights(glorot(dims, seed=9))
+            tr = native.Trainer(st, precision, batch)
+            tr.set_adam(lr=1e-3)
+            if name != "chain":
+                out["kernel_status"] = tr.jit(-1)
+            tr.set_data(0, x, y, rw)
+            d_x, d_y, d_rw, _ = tr.data_dev(0)
+            for _ in range(5):
+                tr.step_dev(d_x, d_y, d_rw, batch, batch)
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.step_dev(d_x, d_y, d_rw, batch, batch)
+            ctx.sync()
+            out[name] = {"us_per_step": 1e6 * (time.perf_counter() - t0) / steps, "route": list(tr.last_route()[0]),
+                         "loss": tr.last_step_loss() / batch}
+        except Exception as e:  # pragma: no cover
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            os.environ.pop("V21_FUSED_TRAIN", None)
+    if "us_per_step" in out.get("chain", {}) and "us_per_step" in out.get("fused_run_time_kernel", {}):
+        out["speedup_vs_chain"] = out["chain"]["us_per_step"] / out["fused_run_time_kernel"]["us_per_step"]
+    return out
+
+
 SWEEP_CONFIGS = [  # (latent, encoder hidden, decoder hidden): widths multiples of 32 in [32, 512] (SURVEY 8d cfg 5)
     (4, 128, (32, 128)), (8, 256, (32, 256)), (9, 352, (32, 352)), (12, 384, (64, 384)),
     (16, 448, (64, 448)), (20, 512, (96, 512)), (24, 320, (128, 320)), (32, 480, (160, 480))]
@@ -1128,6 +1171,8 @@ def main():
                         out["dp_compute_only"] = dpc
                     except Exception as e:  # pragma: no cover
                         out["dp_compute_only"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    if args.precision in ("f16", "bf16"):
+                        out["train_custom_b16384"] = custom_train_leg(native, ctx, args.precision)
                     t32 = train_leg(native, ctx, native.Stack, 1, 0, None, torch, barrier, sync_all, 256, "f32", 200, 10)
                     t32["roofline"] = train_roofline(t32, AE_FLOP_PER_SAMPLE, ae_params, 451, 451,
                                                      "kernel_stats_train_b256_f32.csv", "pmc_train_b256_f32.json")

@@ -150,6 +150,15 @@ int v21_mlp_forward_dev(v21_mlp* mlp, const float* d_x, int64_t ldx, int64_t n,
  * v21_jit_prebuild: compile (stack, precision) into `dir` (NULL: kernel_cache/ next to the library) without touching a
  *   GPU -- a build step for deployments that know their stacks. */
 int v21_mlp_jit(v21_mlp* mlp, int precision, int wait_ms, int* status);
+/* r5: the same for the fused TRAINING kernel (csrc/fused_train16.h: forward + loss + activation gradients of steps of
+ * >= 8,193 rows in one launch, 64-row workgroups).  `_gen_model` takes any hidden_dims (emulator.py:12-48); four stacks
+ * have the kernel compiled in (archs.h T1-T4), every other f16 / bf16 trainer of >= 8,193 rows per step whose stack the
+ * template can express (linear output, no variational head, 2-8 layers up to 512 wide) has it instantiated at run time:
+ * asked for when the trainer is created, taken once the code object is there (until then, and if it never comes, the
+ * chain kernel serves).  v21_trainer_jit waits up to wait_ms (< 0: until compiled): *status 1 ready, 0 compiling;
+ * V21_ERR_UNSUPPORTED (status -1) when this trainer cannot have one.  v21_jit_prebuild(..., precision | 16, dir) compiles
+ * it ahead of time. */
+int v21_trainer_jit(v21_trainer* tr, int wait_ms, int* status);
 int v21_jit_prebuild(int n_layers, const int* dims, const int* act, int precision, const char* dir);
 #define V21_FWD_IN_TRANSFORM 1
 #define V21_FWD_OUT_TRANSFORM 2
@@ -263,7 +272,8 @@ int v21_debug_check_chain_jobs(v21_trainer* tr, long long fw_bytes, long long bw
  *                      instantiated kernel of a stack outside archs.h has arrived); route: 1 small (one NT launch per
  *                      layer), 2 fused_fwd compiled in, 3 fused_fwd instantiated at run time, 4 table-driven chain
  *                      kernel in FORWARD mode, 5 generic per-layer GEMM.
- *   v21_route_train    one optimizer step of `rows` rows of a trainer created with max_batch, on `nranks` ranks:
+ *   v21_route_train    one optimizer step of `rows` rows of a trainer created with max_batch, on `nranks` ranks
+ *                      (rt_ready: assume the run-time instantiated fused TRAINING kernel of a stack outside archs.h has arrived):
  *                      fwd: 1 per-layer NT, 2 train_chain_kernel (16-bit), 3 fused_train (128-row workgroups),
  *                      4 fused_train16 (64-row workgroups), 5 train_chain32_kernel, 6 / 7 train_chain32s_kernel<8> / <4>;
  *                      upd: 1 per-layer NT + adam_repack, 2 dw16_adam_kernel, 3 gemm_dw16[_lds] split-K + adam_repack,
@@ -272,7 +282,7 @@ int v21_debug_check_chain_jobs(v21_trainer* tr, long long fw_bytes, long long bw
  * how many calls / steps took each route since creation (counts[route]; nullable).  v21_route_name: kind 0 forward,
  * 1 training forward, 2 update. */
 int v21_route_forward(int n_layers, const int* dims, const int* act, int precision, int64_t n, int flags, int rt_ready, int* route);
-int v21_route_train(int n_layers, const int* dims, const int* act, int precision, int max_batch, int rows, int nranks, int* fwd, int* upd);
+int v21_route_train(int n_layers, const int* dims, const int* act, int precision, int max_batch, int rows, int nranks, int rt_ready, int* fwd, int* upd);
 int v21_mlp_last_route(v21_mlp* mlp, int* route, long long counts[8]);
 int v21_trainer_last_route(v21_trainer* tr, int* fwd, int* upd, long long fwd_counts[8], long long upd_counts[8]);
 const char* v21_route_name(int kind, int route);

@@ -67,7 +67,7 @@ def init_weights(dims, seed):
     return Ws, bs, ora.flatten_params(Ws, bs)
 
 
-def twin_steps(ctx, dims, act, prec, max_batch, x, y, w, perm, rows, more=((None, None),), lr=1e-3):
+def twin_steps(ctx, dims, act, prec, max_batch, x, y, w, perm, rows, more=((None, None),), lr=1e-3, wait_jit=False):
     """Two trainers built the same way: first step of `rows` rows (through `perm` when given), then one epoch per entry of
     `more` = (perm, batch).  -> [(loss1, grad1, weights_end, last_route, counts)] x 2 and the initial weights (Ws, bs)."""
     native = pkg("_native")
@@ -78,6 +78,8 @@ def twin_steps(ctx, dims, act, prec, max_batch, x, y, w, perm, rows, more=((None
         st.set_weights(flat)
         tr = native.Trainer(st, prec, max_batch)
         tr.set_adam(lr=lr)
+        if wait_jit:   # the run-time instantiated fused training kernel of this stack (build() prebuilt it; else this compiles)
+            assert tr.jit(-1) == "ready"
         tr.set_data(0, x, y, w)
         l1 = tr.run_epoch(perm, rows)
         g1 = tr.get_grad()

@@ -28,15 +28,15 @@ def _tables():
     train, fwd = [], []
     for line in sec.splitlines():
         c = [x.strip() for x in line.strip().strip("|").split("|")]
-        if len(c) == 8 and c[0] in STACKS:
-            train.append(dict(stack=c[0], prec=c[1], max_batch=int(c[2]), rows=int(c[3]), ranks=int(c[4]), fwd=c[5], upd=c[6], where=c[7]))
+        if len(c) == 9 and c[0] in STACKS:
+            train.append(dict(stack=c[0], prec=c[1], max_batch=int(c[2]), rows=int(c[3]), ranks=int(c[4]), rt=c[5] == "yes", fwd=c[6], upd=c[7], where=c[8]))
         elif len(c) == 6 and c[0] in STACKS:
             fwd.append(dict(stack=c[0], prec=c[1], rows=int(c[2]), rt=c[3] == "yes", route=c[4], where=c[5]))
     return train, fwd
 
 
 TRAIN_ROWS, FWD_ROWS = _tables()
-_tid = lambda r: "%s-%s-mb%d-rows%d-r%d" % (r["stack"], r["prec"], r["max_batch"], r["rows"], r["ranks"])
+_tid = lambda r: "%s-%s-mb%d-rows%d-r%d%s" % (r["stack"], r["prec"], r["max_batch"], r["rows"], r["ranks"], "-rt" if r["rt"] else "")
 _fid = lambda r: "%s-%s-rows%d-%s" % (r["stack"], r["prec"], r["rows"], "rt" if r["rt"] else "nort")
 ROUTE_ENV = ["V21_TRAIN_CHAIN", "V21_FUSED_TRAIN", "V21_FUSED_TRAIN16", "V21_FUSED_TRAIN_ROWS", "V21_DW_SPLIT_ROWS", "V21_CHAIN32S",
              "V21_C32S_ROWS", "V21_DW32_LDS", "V21_DW32_ADAM", "V21_JIT", "V21_TRAIN_X16", "V21_SWEEP32_GROUP", "V21_CHAIN_PLAIN",
@@ -62,7 +62,7 @@ def test_the_table_is_there():
 def test_training_route_decision_equals_the_documented_table(row, no_switches):
     native = pkg("_native")
     dims, act = STACKS[row["stack"]]
-    assert native.route_train(dims, act, row["prec"], row["max_batch"], row["rows"], row["ranks"]) == (row["fwd"], row["upd"])
+    assert native.route_train(dims, act, row["prec"], row["max_batch"], row["rows"], row["ranks"], rt_ready=row["rt"]) == (row["fwd"], row["upd"])
 
 
 @pytest.mark.parametrize("row", FWD_ROWS, ids=_fid)
@@ -163,13 +163,13 @@ def test_default_training_routes_at_natural_size_match_table_oracle_and_twin(ctx
     # first step at the row's size; then an epoch of two steps (the second partial) -- the fused kernels read a weight
     # stream written by the previous step's Adam pass from their second consecutive step on
     b2 = rows // 2 + 3 if rows > 1000 else None
-    twins, weights = twin_steps(ctx, dims, act, prec, n, x, y, w, perm, rows, more=((perm, b2),))
+    twins, weights = twin_steps(ctx, dims, act, prec, n, x, y, w, perm, rows, more=((perm, b2),), wait_jit=row["rt"])
     route = twins[0][3]
     assert route == (row["fwd"], row["upd"]), (row, route)
     assert_step_matches_oracle(_tid(row), twins, weights, act, x, y, w, perm, rows, prec)
     # ... and the decision the table test checks on the CPU is the one the launch sites followed
     native = pkg("_native")
-    assert native.route_train(dims, act, prec, n, rows, 1) == route
+    assert native.route_train(dims, act, prec, n, rows, 1, rt_ready=row["rt"]) == route
 
 
 @pytest.mark.gpu

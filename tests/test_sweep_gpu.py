@@ -91,7 +91,10 @@ def test_sweep_argument_errors(ctx):
 
 
 def test_sweep_group_sizes(ctx):
-    """One model is a valid group; 16 is the most one launch group holds; 17 is refused."""
+    """One model is a valid group; 64 is the most one group holds (r5: the whole of BASELINE configs[4]; 16 until r4) -- in
+    f16 (grouped chain launch with a model's row blocks on one XCD label + grouped gradient / Adam launch) and in f32
+    (train_chain32s_group_kernel + dwadam32_group_kernel): model 0 and model 63 of the big group train as they do alone; 65
+    are refused."""
     native = pkg("_native")
     rng = np.random.default_rng(0)
     x = rng.normal(size=(64, 12)).astype(np.float32)
@@ -110,14 +113,21 @@ def test_sweep_group_sizes(ctx):
     sw1 = native.Sweep([one])
     got = [sw1.run_epoch(None, 32)[0] for _ in range(2)]
     np.testing.assert_allclose(got, ref, rtol=1e-6)
-    many = [make(k) for k in range(16)]
-    many[0].set_data(0, x, None, w)
-    sw16 = native.Sweep(many)
-    l16 = sw16.run_epoch(None, 32)
-    assert len(l16) == 16 and np.all(np.isfinite(l16))
-    np.testing.assert_allclose(l16[0], ref[0], rtol=1e-3)  # model 0 of the big group = the solo model's first epoch
+    for prec in ("f16", "f32"):
+        solo0 = make(0, prec); solo0.set_data(0, x, None, w)
+        solo63 = make(63, prec); solo63.set_data(0, x, None, w)
+        r0, r63 = solo0.run_epoch(None, 32), solo63.run_epoch(None, 32)
+        many = [make(k, prec) for k in range(64)]
+        many[0].set_data(0, x, None, w)
+        sw64 = native.Sweep(many)
+        l64 = sw64.run_epoch(None, 32)
+        assert len(l64) == 64 and np.all(np.isfinite(l64))
+        tol = 1e-3 if prec == "f16" else 2e-5
+        np.testing.assert_allclose(l64[0], r0, rtol=tol)    # members of the big group = the same models alone
+        np.testing.assert_allclose(l64[63], r63, rtol=tol)
+        np.testing.assert_allclose(many[63].stack.get_weights(), solo63.stack.get_weights(), atol=3e-3 if prec == "f16" else 5e-6)
     with pytest.raises(native.EngineError):
-        native.Sweep(many + [make(16)])
+        native.Sweep(many + [make(64, "f32")])
 
 
 @pytest.mark.parametrize("precision", ["f16", "f32"])
