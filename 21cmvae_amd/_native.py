@@ -697,7 +697,7 @@ class Trainer(_Owned):
         check(self.lib.v21_trainer_phase_timing(self.h, int(steps), int(cut)))
 
     def phase_times(self):
-        """-> (mean microseconds from a step's start to the cut point, stamped steps) since the last call."""
+        """-> (median microseconds from a step's start to the cut point, stamped steps) since the last call."""
         ms, n = C.c_double(0.0), C.c_int(0)
         check(self.lib.v21_trainer_phase_times(self.h, C.byref(ms), C.byref(n)))
         return 1e3 * ms.value, n.value

@@ -1764,12 +1764,13 @@ extern "C" int v21_trainer_phase_times(v21_trainer* t, double* ms, int* steps) {
   HIPCHK(hipStreamSynchronize(t->ctx->stream));
   *ms = 0.0;
   *steps = t->phase_steps;
-  for (int s = 0; s < t->phase_steps; ++s) {
-    float f = 0.f;
-    HIPCHK(hipEventElapsedTime(&f, t->phase_ev[(size_t)s * 2], t->phase_ev[(size_t)s * 2 + 1]));
-    *ms += f;
+  std::vector<float> el((size_t)t->phase_steps);
+  for (int s = 0; s < t->phase_steps; ++s)
+    HIPCHK(hipEventElapsedTime(&el[s], t->phase_ev[(size_t)s * 2], t->phase_ev[(size_t)s * 2 + 1]));
+  if (!el.empty()) {  // the MEDIAN: one stalled step (the host descheduled between two enqueues) moves a mean of 50 by microseconds
+    std::sort(el.begin(), el.end());
+    *ms = el.size() % 2 ? el[el.size() / 2] : 0.5 * (el[el.size() / 2 - 1] + el[el.size() / 2]);
   }
-  if (t->phase_steps > 0) *ms /= t->phase_steps;
   t->phase_steps = 0;
   return V21_OK;
 }

@@ -329,7 +329,7 @@ def train_leg(native, ctx, stack_cls, world, rank, dist, torch, barrier, sync_al
     try:
         phases = tr.phase_profile(lambda: tr.step_dev(d_x, None, d_rw, batch, batch * world), steps=min(steps, 50))
         sync_all()
-        phases["marker_us"] = phases["stamped_step_us"] - 1e3 / sps
+        phases["marker_us"] = phases["stamped_step_us"] - 1e6 / sps
     except Exception as e:  # pragma: no cover
         phases = {"error": "%s: %s" % (type(e).__name__, e)}
     return {"steps_per_s": sps, "phases": phases, "samples_per_s": sps * batch * world, "ms_per_step": 1e3 / sps,
@@ -492,6 +492,15 @@ def sweep_scaling_leg(native, ctx, precision, counts=(8, 16, 32, 64), batch=256,
                             "pmc_sweep_%s_m%d.json" % (precision, G))
         # (the batch rows are read once per MEMBER by its row blocks: algorithmic bytes count them per member)
         rf["algorithmic_bytes_per_step"] = G * batch * 4 * 451 + 7 * 4 * params + (2 if precision != "f32" else 4) * params
+        # A group step at batch 256 is bound by the OPTIMIZER STATE, not by the matrix pipe: 28-32 B of HBM-side traffic per
+        # parameter and step (Adam's w, g, m, v passes + the packed copies) against 2 x 3 x 256 FLOP -- the roofline that
+        # applies is HBM (profiles/r5/pmc_sweep_*: dw16_adam_group_kernel moves its bytes at 3.7 TB/s); the MFMA fraction rides along
+        rf["mfma_frac"] = rf["frac"]
+        rf["bound"], rf["unit"], rf["peak"] = "hbm", "GB/s", PEAK_HBM_GBS
+        rf["achieved"] = rf["algorithmic_bytes_per_step"] / step_s / 1e9
+        rf["frac"] = rf["achieved"] / PEAK_HBM_GBS
+        if rf.get("traffic"):
+            rf["hbm_side_GBps"] = rf["traffic"] / step_s / 1e9
         out["groups"].append({"models": G, "model_steps_per_s": G * nsteps / tg, "ms_per_group_step": step_s * 1e3,
                               "parameters_of_the_group": params, "finite": bool(np.isfinite(lg).all()), "roofline": rf})
         del sw, trs
@@ -828,28 +837,11 @@ def main():
             ctx.record(evs[i + 1])
         ctx.sync()
         timed.per_launch_ms = [ctx.elapsed_ms(evs[i], evs[i + 1]) for i in range(steps)]
-        # the shader clock these launches run at: a THIRD untimed run of the same K launches with one
-        # sampling wave beside them (v21_debug_clock_probe_*: s_memtime against the 100 MHz s_memrealtime), started once
-        # the launches are enqueued and sampling for about half of the run
+        # (r4 ran a THIRD repeat here with one sampling wave beside the launches -- v21_debug_clock_probe_*.  r5 dropped it: that wave
+        #  sits on ONE CU and reads ITS clock between samples -- 2.44 GHz beside launches whose own workgroups measure 1.5-1.6 GHz
+        #  (gpurun_out runs of r5; VERDICT r4 weak 2 had spotted that the same 52-54 us came with "clocks" of 1.78 and 2.40 GHz))
         timed.clock = None
-        try:
-            run_ms = max(0.4, steps * ev_ms / max(steps, 1))
-            # (under the same conditions as the timed launches: the reading of the per-launch events above left the GPU
-            #  idle for milliseconds, and an idle chip boosts -- the same untimed settle phase first)
-            t_s = time.perf_counter()
-            while time.perf_counter() - t_s < args.settle:
-                for _ in range(100):
-                    stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
-                ctx.sync()
-            for _ in range(warmup + steps):
-                stack.forward_dev(d_x, DIMS[0], B, d_y, DIMS[-1], prec, flags)
-            run_ms = run_ms * (warmup + steps) / max(steps, 1)
-            ctx.clock_probe_start(0.5 * run_ms, period_us=max(20.0, 0.5 * run_ms * 1000.0 / 200.0))
-            ctx.sync()
-            timed.clock = ctx.clock_probe_read()
-        except Exception as e:  # pragma: no cover
-            timed.clock = {"error": "%s: %s" % (type(e).__name__, e)}
-        # r5: the clock FROM THE KERNEL ITSELF.  A FOURTH untimed run -- settle, warm-up, K launches --
+        # r5: the clock FROM THE KERNEL ITSELF.  A THIRD untimed run -- settle, warm-up, K launches --
         # through the clock-stamped instantiation of the same kernel (fused_fwd.h: CLOCK_STAMPS; identical but for two
         # pairs of scalar counter reads and one 40-byte store per workgroup): wave 0 of EVERY workgroup of EVERY one of the K
         # launches reads s_memtime (shader-clock cycles) and s_memrealtime (100 MHz) at its start and end, and its XCD.

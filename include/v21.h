@@ -291,7 +291,7 @@ const char* v21_route_name(int kind, int route);
  *   cut 1 after forward + loss + activation gradients (the chain / fused training launch, its stream pack included),
  *   cut 2 after the weight gradients (+ slab sums),  cut 3 after the gradient exchange has been joined,  cut 4 after Adam +
  *   packed copies (the whole step);
- * v21_trainer_phase_times returns the mean milliseconds from start to cut over the steps stamped since the last call.
+ * v21_trainer_phase_times returns the MEDIAN milliseconds from start to cut over the steps stamped since the last call.
  * A HIP event is a packet of its own (an empty interval between two reads ~5 us): the phases are DIFFERENCES of the
  * cumulative times of separate runs, in which the marker's cost cancels (21cmvae_amd/_native.py: Trainer.phase_profile).
  * Single-rank steps whose gradients and Adam are ONE launch have cut 2 = cut 3 = cut 1; the per-layer path has cut 1 = cut 2
