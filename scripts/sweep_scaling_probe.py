@@ -12,6 +12,6 @@ ctx = native.Context.default()
 out = bench.sweep_scaling_leg(native, ctx, prec, counts=counts)
 for g in out["groups"]:
     rf = g["roofline"]
-    print("%s models %2d: %8.0f model-steps/s  %7.1f us per group step  %.2fx the 8-model rate  %.1f TFLOP/s = %.4f of peak  params %d"
-          % (prec, g["models"], g["model_steps_per_s"], g["ms_per_group_step"] * 1e3, g["vs_8_models"], rf["achieved"], rf["frac"], g["parameters_of_the_group"]))
+    print("%s models %2d: %8.0f model-steps/s  %7.1f us per group step  %.2fx the first group's rate  algorithmic %.0f GB/s = %.3f of 8 TB/s (MFMA: %.4f of peak)  params %d"
+          % (prec, g["models"], g["model_steps_per_s"], g["ms_per_group_step"] * 1e3, g["vs_8_models"], rf["achieved"], rf["frac"], rf["mfma_frac"], g["parameters_of_the_group"]))
 print(json.dumps(out))
