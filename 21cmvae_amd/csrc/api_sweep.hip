@@ -24,6 +24,14 @@ struct v21_sweep {
   bool chain32s = false;
   Dw32Model* d_dw32 = nullptr;
   std::vector<Dw32Model> h_dw32;
+  // r5: TWO half-groups on two streams (one rank, grouped chain launches).  A group step is two launches of complementary
+  // character -- every member's chain (latency-bound per workgroup, little HBM traffic) and every member's gradients + Adam
+  // (bound by the optimizer state's bytes: 390 MB per step of 32 members at 3.85 TB/s) -- and the members are independent
+  // models: half B's chain runs while half A's Adam launch waits for HBM.  Same kernels on the same data per member:
+  // bit-identical results.  32 members, f16: 172 -> 148 us per group step (scripts/diag/sweep_two_streams_probe.py).
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_off = nullptr, ev_join = nullptr;
+  bool two_streams = false;  // this epoch
 };
 
 extern "C" int v21_sweep_create(v21_trainer** trainers, int count, v21_sweep** out) {
@@ -71,6 +79,8 @@ extern "C" int v21_sweep_destroy(v21_sweep* s) {
   if (s->d_chain) hipFree(s->d_chain);
   if (s->d_dwadam) hipFree(s->d_dwadam);
   if (s->d_dw32) hipFree(s->d_dw32);
+  if (s->s2) { hipStreamSynchronize(s->s2); hipStreamDestroy(s->s2); }
+  for (hipEvent_t e : {s->ev_fork, s->ev_off, s->ev_join}) if (e) hipEventDestroy(e);
   delete s;
   return V21_OK;
 }
@@ -186,6 +196,30 @@ static int sweep_step(v21_sweep* s, const float* yb, long long ldy, int rows, in
 
 // chain form of a sweep step: ONE launch carries every model's rows through forward, loss and the
 // activation-gradient chain (blockIdx.y = model); then all weight gradients, then all Adam updates
+// members [g0, g1) of the group on stream `st`: the chain of each, and (one rank) their gradients + Adam
+static int sweep_chain_launch(v21_sweep* s, const ChainStep& csp, int g0, int g1, hipStream_t st) {
+  v21_trainer* t0 = s->tr[0];
+  const int G = g1 - g0;
+  // one-dimensional grid: a model's row blocks share an XCD label (train_chain.h: train_chain_group_kernel)
+  const dim3 grid(8 * csp.ncons * ((G + 7) / 8)), block(64 * kChainWaves);
+  bool gauss = false;  // (train_chain.h: FEAT)
+  for (int k = g0; k < g1; ++k) gauss = gauss || s->tr[k]->gl >= 0;
+  const ChainModel* tab = (const ChainModel*)s->d_chain + g0;
+  if (t0->prec == V21_PREC_F16) {
+    if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, true>), grid, block, kChainLdsBytes, st, tab, csp, G);
+    else hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, false>), grid, block, kChainLdsBytes, st, tab, csp, G);
+  } else {
+    if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, true>), grid, block, kChainLdsBytes, st, tab, csp, G);
+    else hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, false>), grid, block, kChainLdsBytes, st, tab, csp, G);
+  }
+  HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+static int sweep_dwadam_launch(v21_sweep* s, int g0, int g1, int rows, int brows, long long step_index, hipStream_t st) {
+  const std::vector<v21_trainer*> part(s->tr.begin() + g0, s->tr.begin() + g1);
+  const std::vector<DwAdamModel> hpart(s->h_dwadam.begin() + g0, s->h_dwadam.begin() + g1);
+  return launch_dw_adam_group(part, s->d_dwadam + g0, hpart, rows, brows, step_index, st);
+}
 static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long long step_index) {
   v21_trainer* t0 = s->tr[0];
   hipStream_t st = s->ctx->stream;
@@ -197,18 +231,18 @@ static int sweep_step_chain(v21_sweep* s, const ChainStep& cs, int brows, long l
     ChainStep csp = cs;
     csp.ncons = ((rows + 31) / 32 + 7) / 8 * 8;
     csp.npref = 0;  // (no prefetcher workgroups in a sweep: measured slower in r2)
-    // one-dimensional grid: a model's row blocks share an XCD label (train_chain.h: train_chain_group_kernel)
-    const dim3 grid(8 * csp.ncons * ((G + 7) / 8)), block(64 * kChainWaves);
-    bool gauss = false;  // (train_chain.h: FEAT)
-    for (v21_trainer* t : s->tr) gauss = gauss || t->gl >= 0;
-    if (t0->prec == V21_PREC_F16) {
-      if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, true>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
-      else hipLaunchKernelGGL((train_chain_group_kernel<PrecF16, false>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
-    } else {
-      if (gauss) hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, true>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
-      else hipLaunchKernelGGL((train_chain_group_kernel<PrecBF16, false>), grid, block, kChainLdsBytes, st, (const ChainModel*)s->d_chain, csp, G);
+    if (s->two_streams) {  // one rank: half A on the context's stream, half B on the second one, B one launch behind A
+      const int GA = (G + 1) / 2;
+      CHK(sweep_chain_launch(s, csp, 0, GA, st));
+      if (step_index == 0) {  // (the offset that makes B's chain meet A's Adam launch, not A's chain)
+        HIPCHK(hipEventRecord(s->ev_off, st));
+        HIPCHK(hipStreamWaitEvent(s->s2, s->ev_off, 0));
+      }
+      CHK(sweep_chain_launch(s, csp, GA, G, s->s2));
+      CHK(sweep_dwadam_launch(s, 0, GA, rows, brows, step_index, st));
+      return sweep_dwadam_launch(s, GA, G, rows, brows, step_index, s->s2);
     }
-    HIPCHK(hipGetLastError());
+    CHK(sweep_chain_launch(s, csp, 0, G, st));
     if (s->ctx->nranks == 1)  // nothing to exchange: all gradients, all Adam updates, all packed copies in one launch
       return launch_dw_adam_group(s->tr, s->d_dwadam, s->h_dwadam, rows, brows, step_index, st);
     int nslice = 1;
@@ -326,22 +360,12 @@ int refresh_dw32_table(const std::vector<v21_trainer*>& trs, Dw32Model* d_tab, s
 }
 // one optimizer step of every f32 member in TWO launches: the chain of every model (blockIdx.y = model), then every
 // weight gradient + Adam + packed streams + batch loss
-static int sweep_step_chain32(v21_sweep* s, const ChainStep& cs, long long step_index, int max_blocks) {
-  hipStream_t st = s->ctx->stream;
-  const int G = (int)s->tr.size(), rows = cs.rows;
-  for (v21_trainer* t : s->tr) CHK(ensure_copies(t, false));
-  CHK(chain_attr(V21_PREC_F32));
-  // 4 rows per workgroup while every model's row blocks fit the chip in one round (train_chain32s.h)
-  const char* er = getenv("V21_C32S_ROWS");
-  const int force_rows = er ? atoi(er) : 0;
-  const int rpw = force_rows == 4 || force_rows == 8 ? force_rows : ((long long)G * ((rows + 3) / 4) <= 256 ? 4 : 8);
-  ChainStep csp = cs;
-  csp.ncons = ((rows + rpw - 1) / rpw + 7) / 8 * 8;
-  csp.npref = 0;
+static int sweep_chain32_launch(v21_sweep* s, const ChainStep& csp, int rpw, int g0, int g1, hipStream_t st) {
+  const int G = g1 - g0;
   const dim3 grid(csp.ncons * G), block(64 * kC32sWaves);
   bool gauss = false;
-  for (v21_trainer* t : s->tr) gauss = gauss || t->gl >= 0;
-  const ChainModel* tab = (const ChainModel*)s->d_chain;
+  for (int k = g0; k < g1; ++k) gauss = gauss || s->tr[k]->gl >= 0;
+  const ChainModel* tab = (const ChainModel*)s->d_chain + g0;
   if (rpw == 4) {
     if (gauss) hipLaunchKernelGGL((train_chain32s_group_kernel<4, true>), grid, block, kC32sLdsBytes, st, tab, csp, G);
     else hipLaunchKernelGGL((train_chain32s_group_kernel<4, false>), grid, block, kC32sLdsBytes, st, tab, csp, G);
@@ -350,6 +374,32 @@ static int sweep_step_chain32(v21_sweep* s, const ChainStep& cs, long long step_
     else hipLaunchKernelGGL((train_chain32s_group_kernel<8, false>), grid, block, kC32sLdsBytes, st, tab, csp, G);
   }
   HIPCHK(hipGetLastError());
+  return V21_OK;
+}
+static int sweep_step_chain32(v21_sweep* s, const ChainStep& cs, long long step_index, int max_blocks) {
+  hipStream_t st = s->ctx->stream;
+  const int G = (int)s->tr.size(), rows = cs.rows;
+  for (v21_trainer* t : s->tr) CHK(ensure_copies(t, false));
+  CHK(chain_attr(V21_PREC_F32));
+  // 4 rows per workgroup while every model's row blocks fit the chip in one round (train_chain32s.h)
+  const int force_rows = RouteEnv::read().c32s_rows;
+  const int rpw = force_rows == 4 || force_rows == 8 ? force_rows : ((long long)G * ((rows + 3) / 4) <= 256 ? 4 : 8);
+  ChainStep csp = cs;
+  csp.ncons = ((rows + rpw - 1) / rpw + 7) / 8 * 8;
+  csp.npref = 0;
+  if (s->two_streams) {  // (as sweep_step_chain: half B one launch behind half A)
+    const int GA = (G + 1) / 2;
+    const std::vector<v21_trainer*> pa(s->tr.begin(), s->tr.begin() + GA), pb(s->tr.begin() + GA, s->tr.end());
+    CHK(sweep_chain32_launch(s, csp, rpw, 0, GA, st));
+    if (step_index == 0) {
+      HIPCHK(hipEventRecord(s->ev_off, st));
+      HIPCHK(hipStreamWaitEvent(s->s2, s->ev_off, 0));
+    }
+    CHK(sweep_chain32_launch(s, csp, rpw, GA, G, s->s2));
+    CHK(launch_dw32_group(pa, s->d_dw32, rows, step_index, max_blocks, st));
+    return launch_dw32_group(pb, s->d_dw32 + GA, rows, step_index, max_blocks, s->s2);
+  }
+  CHK(sweep_chain32_launch(s, csp, rpw, 0, G, st));
   return launch_dw32_group(s->tr, s->d_dw32, rows, step_index, max_blocks, st);
 }
 
@@ -424,6 +474,17 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
       HIPCHK(hipStreamSynchronize(st));
     }
   }
+  // r5: two half-groups on two streams (v21_sweep: s2) for the grouped chain launches of one rank; V21_SWEEP_STREAMS=1: one stream
+  s->two_streams = R == 1 && (s->chain || group32) && s->tr.size() >= 4 && RouteEnv::read().sweep_streams == 2;
+  if (s->two_streams) {
+    if (!s->s2) {
+      HIPCHK(hipStreamCreateWithFlags(&s->s2, hipStreamNonBlocking));
+      for (hipEvent_t* e : {&s->ev_fork, &s->ev_off, &s->ev_join}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    for (v21_trainer* t : s->tr) CHK(ensure_copies(t, false));  // (a stale member's refresh runs on the context's stream: before the fork)
+    HIPCHK(hipEventRecord(s->ev_fork, st));                        // the row table, the tables and the copies are in place
+    HIPCHK(hipStreamWaitEvent(s->s2, s->ev_fork, 0));
+  }
   for (long long sidx = 0; sidx < steps; ++sidx) {
     const long long first = sidx * batch;
     const int brows = (int)std::min<long long>(batch, n - first);
@@ -448,6 +509,10 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
       CHK(gather_batch(t0, t0->d_x[0], din, t0->y_is_x[0] ? nullptr : t0->d_y[0], dout, t0->d_rw[0], d_idx, lo, rows));
     const float* yb = t0->y_is_x[0] ? t0->d_h[0] : t0->d_yb;
     CHK(sweep_step(s, yb, t0->y_is_x[0] ? p16(din) : p16(dout), rows, brows, sidx));
+  }
+  if (s->two_streams) {  // half B's launches end before the losses are read (and before anything else touches its members)
+    HIPCHK(hipEventRecord(s->ev_join, s->s2));
+    HIPCHK(hipStreamWaitEvent(st, s->ev_join, 0));
   }
   std::vector<float> h((size_t)steps * s->tr.size());
   for (size_t k = 0; k < s->tr.size(); ++k)

@@ -163,3 +163,39 @@ def test_sweep_of_variational_models_equals_individual_training(precision):
         np.testing.assert_allclose(hb.history["loss"], ha.history["loss"], rtol=ltol)
         for wa, wb in zip(a.get_weights(), b.get_weights()):
             np.testing.assert_allclose(wb, wa, atol=wtol, rtol=1e-3 if precision == "f16" else 1e-4)
+
+
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_sweep_on_two_streams_equals_one_stream_bit_for_bit(ctx, prec, monkeypatch):
+    """r5: a sweep of >= 4 members on one rank runs as TWO half-groups on two streams, the second one launch behind the first
+    (csrc/api_sweep.hip: one half's chain launch runs while the other half's gradient / Adam launch waits for HBM).  The
+    members are independent models and every member sees the same kernels on the same data: losses and weights after three
+    epochs (a permuted row table, a partial last batch) are IDENTICAL to the one-stream form (V21_SWEEP_STREAMS=1)."""
+    native = pkg("_native")
+    rng = np.random.default_rng(3)
+    n, batch = 700, 256
+    x = rng.normal(size=(n, 33)).astype(np.float32)
+    w = np.full(n, 1.0 / 33, np.float32)
+    perm = rng.permutation(n).astype(np.int32)
+
+    def run(streams):
+        monkeypatch.setenv("V21_SWEEP_STREAMS", streams)
+        trs = []
+        for k in range(9):
+            dims = [33, 16 + 24 * k, 4 + k, 8 + 16 * k, 33]
+            Ws, bs = ora.init_mlp(dims, seed=70 + k)
+            st = native.Stack(ctx, dims, [1, 0, 1, 0])
+            st.set_weights(ora.flatten_params(Ws, bs))
+            tr = native.Trainer(st, prec, batch)
+            tr.set_adam(lr=1e-3 * (1 + k % 3))
+            trs.append(tr)
+        trs[0].set_data(0, x, None, w)
+        sw = native.Sweep(trs)
+        losses = [sw.run_epoch(perm, batch) for _ in range(3)]
+        return losses, [t.stack.get_weights() for t in trs], [t.get_state()[0] for t in trs]
+    l1, w1, i1 = run("1")
+    l2, w2, i2 = run("2")
+    assert l1 == l2 and i1 == i2 == [9] * 9
+    for a, b in zip(w1, w2):
+        np.testing.assert_array_equal(a, b)
+    assert np.all(np.isfinite(np.array(l2)))
