@@ -28,7 +28,12 @@ struct v21_sweep {
   // character -- every member's chain (latency-bound per workgroup, little HBM traffic) and every member's gradients + Adam
   // (bound by the optimizer state's bytes: 390 MB per step of 32 members at 3.85 TB/s) -- and the members are independent
   // models: half B's chain runs while half A's Adam launch waits for HBM.  Same kernels on the same data per member:
-  // bit-identical results.  32 members, f16: 172 -> 148 us per group step (scripts/diag/sweep_two_streams_probe.py).
+  // bit-identical results.  Measured (one MI355X, f16, batch 256; gpurun_out/r5_sweep_f16_c.txt against r5_b5.json): 16 members
+  // 159-163 k -> 167 k model-steps/s, 64 members 170-173 k -> 180 k, 8 and 32 members within noise -- the two streams drift back
+  // into lock step (two Adam launches that share the HBM end together, then both chains start together).  Forcing the
+  // anti-phase order with events (A's Adam launch, then B's, then A's ...) was measured SLOWER (32 members: 183 against 168 us
+  // per group step: every cross-stream dependency is a ~5-us hand-over); two host threads on two contexts reached 148 us
+  // (scripts/diag/sweep_two_streams_probe.py) -- the kernels' own sum (44.6 + 101 us): what is left is enqueue jitter, not overlap.
   hipStream_t s2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_off = nullptr, ev_join = nullptr;
   bool two_streams = false;  // this epoch
