@@ -480,7 +480,7 @@ extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch,
     }
   }
   // r5: two half-groups on two streams (v21_sweep: s2) for the grouped chain launches of one rank; V21_SWEEP_STREAMS=1: one stream
-  s->two_streams = R == 1 && (s->chain || group32) && s->tr.size() >= 4 && RouteEnv::read().sweep_streams == 2;
+  s->two_streams = R == 1 && (s->chain || group32) && s->tr.size() >= 16 && RouteEnv::read().sweep_streams == 2;  // (below 16 members the second stream's hand-overs cost more than they hide: tiny members, 8 per group: 17.4 -> 23.6 us per step)
   if (s->two_streams) {
     if (!s->s2) {
       HIPCHK(hipStreamCreateWithFlags(&s->s2, hipStreamNonBlocking));
