@@ -615,11 +615,13 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_fwd(const FusedAr
     // after the wave's last output store has been ISSUED (the stores drain behind it; the next launch's start stamp
     // cannot precede them on an in-order stream)
     unsigned long long t1, r1;
-    unsigned xcc;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1), "=s"(xcc)::"memory");
+    unsigned xcc, hwid;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %3, hwreg(HW_REG_HW_ID)\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(t1), "=s"(r1), "=s"(xcc), "=s"(hwid)::"memory");
     if (a.dbg && wave == 0 && lane == 0) {
       unsigned long long* gd = a.dbg + (size_t)blockIdx.x * 5;
-      gd[0] = clk_t0; gd[1] = clk_r0; gd[2] = t1; gd[3] = r1; gd[4] = xcc & 0xF;
+      // word 4: XCD in bits 0-3, HW_REG_HW_ID (wave / SIMD / CU / shader array / shader engine of wave 0) in bits 8-39
+      gd[0] = clk_t0; gd[1] = clk_r0; gd[2] = t1; gd[3] = r1; gd[4] = (unsigned long long)(xcc & 0xF) | ((unsigned long long)hwid << 8);
     }
   }
 #ifdef V21_FUSED_STAMP

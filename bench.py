@@ -699,7 +699,7 @@ def _reduce_clock_stamps(st, ms_per_launch_events):
     dt = (st[..., 3] - st[..., 1]).astype(np.float64)          # ticks of 10 ns
     ok = (dt > 0) & (dc > 0)
     ghz = np.where(ok, dc / np.maximum(dt, 1) * 0.1, np.nan)
-    xcd = st[..., 4].astype(np.int64)
+    xcd = (st[..., 4] & np.uint64(0xF)).astype(np.int64)   # (bits 8-39: HW_REG_HW_ID of the workgroup's wave 0)
     per_xcd = []
     for x in range(8):
         m = ok & (xcd == x)

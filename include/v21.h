@@ -254,7 +254,7 @@ int v21_debug_clock_probe_start(v21_ctx* ctx, double duration_ms, double period_
  * S1; f16 / bf16) in a separate instantiation whose wave 0 of every workgroup reads s_memtime (shader-clock cycles),
  * s_memrealtime (constant 100 MHz) and HW_REG_XCC_ID when the workgroup starts and when it ends.  d_stamps (device
  * memory): five 64-bit words per workgroup = ceil(n / 128) workgroups: [cycles at start, 100-MHz ticks at start, cycles at
- * end, ticks at end, XCD 0-7].  (end - start) cycles / ticks * 0.1 = GHz as that workgroup's CU saw it; bench.py reports
+ * end, ticks at end, XCD 0-7 in bits 0-3 | HW_REG_HW_ID of the workgroup's wave 0 in bits 8-39].  (end - start) cycles / ticks * 0.1 = GHz as that workgroup's CU saw it; bench.py reports
  * mean / min / max per XCD over a repeat of its K timed launches.  Otherwise the arguments of v21_mlp_forward_dev. */
 int v21_debug_forward_clocked(v21_mlp* mlp, const float* d_x, int64_t ldx, int64_t n, float* d_y, int64_t ldy, int precision,
                               int flags, unsigned long long* d_stamps);

@@ -38,3 +38,23 @@ for q in range(k):
     span = float(s[:, 3].max() - s[:, 1].min()) * 0.01
     if q < 10 or q % 5 == 0:
         print("%.3f  %.3f  %.2f  %.1f" % (stamps_t[q], ghz, span, span * ghz))
+
+# ---- the last kept launch, workgroup by workgroup: do the two workgroups of a CU finish together?
+s = h[k - 1]
+dc = (s[:, 2] - s[:, 0]).astype(np.float64) / 1e3
+hw = (s[:, 4] >> np.uint64(8)).astype(np.int64)
+xcc = (s[:, 4] & np.uint64(0xF)).astype(np.int64)
+cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)      # cu_id | sh_id | se_id | xcd
+print("kcycles per workgroup of one launch: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f" % (dc.min(), np.percentile(dc, 10), np.median(dc), np.percentile(dc, 90), dc.max()))
+hist, edges = np.histogram(dc, bins=14)
+print("histogram:", " ".join("%.0f-%.0f:%d" % (edges[i], edges[i + 1], hist[i]) for i in range(len(hist))))
+ends = (s[:, 2]).astype(np.float64)
+pairs = {}
+for i in range(len(cu)):
+    pairs.setdefault(int(cu[i]), []).append(i)
+sizes = sorted(len(v) for v in pairs.values())
+print("distinct CUs (by XCD / SE / SH / CU id of wave 0): %d; workgroups per CU: min %d max %d" % (len(pairs), sizes[0], sizes[-1]))
+two = [v for v in pairs.values() if len(v) == 2]
+if two:
+    fast = np.array([min(dc[v[0]], dc[v[1]]) for v in two]); slow = np.array([max(dc[v[0]], dc[v[1]]) for v in two])
+    print("CUs with two workgroups: %d; the faster of the pair %.1f kcycles (mean), the slower %.1f; slower / faster %.2f" % (len(two), fast.mean(), slow.mean(), (slow / fast).mean()))
