@@ -978,6 +978,38 @@ def main():
             except Exception as e:  # pragma: no cover
                 modes[prec] = {"error": str(e)}
         out["other_precisions_1gpu"] = modes
+        # r5: consecutive INDEPENDENT batches on TWO streams (two contexts of the one GPU, a replica of the stack on each).  The
+        # headline launch is exactly two workgroups per CU, and on every CU one of the pair ends at ~2/3 of the launch and the
+        # other finishes alone: in one stream the next launch cannot start before the last workgroup has
+        # ended, on two streams its workgroups move in as soon as a slot is free.  NOT the headline (its roofline is defined
+        # per launch on one stream): what a server that alternates two contexts gets.
+        try:
+            ctx2 = native.Context(local_rank)
+            stack2 = native.Stack(ctx2, DIMS, ACT)
+            stack2.set_weights(wflat)
+            stack2.set_input_transform(ps.log_mask, ps.zero_floor, ps.lo, ps.hi)
+            stack2.set_output_transform(ss.std, ss.mean)
+            d_y2 = ctx2.malloc(B * DIMS[-1] * 4)
+            pairs = ((stack, ctx, d_y), (stack2, ctx2, d_y2))
+            n2 = max(20, args.steps)
+            t_s = time.perf_counter()
+            while time.perf_counter() - t_s < args.settle:
+                for i in range(100):
+                    pairs[i & 1][0].forward_dev(d_x, DIMS[0], B, pairs[i & 1][2], DIMS[-1], args.precision, flags)
+                ctx.sync(); ctx2.sync()
+            t0 = time.perf_counter()
+            for i in range(n2):
+                pairs[i & 1][0].forward_dev(d_x, DIMS[0], B, pairs[i & 1][2], DIMS[-1], args.precision, flags)
+            ctx.sync(); ctx2.sync()
+            dt = (time.perf_counter() - t0) / n2
+            out["predict_two_streams"] = {"signals_per_s": B / dt, "us_per_batch": dt * 1e6, "batches": n2,
+                                          "vs_headline": (B / dt) / value * world,
+                                          "frac_of_peak": FLOP_PER_SIGNAL * B / dt / 1e12 / PEAK_TFLOPS[args.precision],
+                                          "note": "independent 65,536-row batches alternating between two contexts (two streams, two output buffers); wall clock"}
+            ctx2.free(d_y2)
+            del stack2
+        except Exception as e:  # pragma: no cover
+            out["predict_two_streams"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # Stacks WITHOUT a compiled fused kernel (csrc/archs.h holds four): what a custom `hidden_dims`
         # (emulator.py:12-48) or a sweep member's predict() gets.  `predict_generic_S1`: the headline stack forced
         # down that route (V21_FWD_FORCE_GENERIC), same 65,536 rows; `predict_custom`: the sample notebook's
