@@ -1157,15 +1157,6 @@ def main():
                                                 "kernel_stats_train_b%d_%s.csv" % (args.train_batch, args.precision),
                                                 "pmc_train_b%d_%s.json" % (args.train_batch, args.precision))
                 out["train"] = tl
-                if world > 1:  # r5: the all-reduce in two buckets, the output-side half overlapping the second weight-gradient launch
-                    ctx.comm_set_buckets(2)
-                    tb = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
-                                   args.train_batch, args.precision, args.train_steps, 20)
-                    tb["collective"] = "all-reduce in two buckets (output-side layers + loss slot first, on a second stream)"
-                    tb["transport"] = transport
-                    tb["n_ranks_seen"] = ctx.ranks_seen()
-                    out["train_two_buckets"] = tb
-                    ctx.comm_set_buckets(1)
                 if world > 1:  # the other exchange: reduce-scatter -> Adam on each rank's slice -> all-gather
                     ctx.comm_set_sharded(True)
                     ts = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
@@ -1175,6 +1166,16 @@ def main():
                     ts["n_ranks_seen"] = ctx.ranks_seen()
                     out["train_sharded_adam"] = ts
                     ctx.comm_set_sharded(False)
+                if world > 1:  # r5: the all-reduce in two buckets, the output-side half overlapping the second weight-gradient launch (LAST of the three
+                    # exchange forms: the one that has never met a real RCCL -- if it should stall, the two above are already in `out`)
+                    ctx.comm_set_buckets(2)
+                    tb = train_leg(native, ctx, native.Stack, world, rank, dist, torch, barrier, sync_all,
+                                   args.train_batch, args.precision, args.train_steps, 20)
+                    tb["collective"] = "all-reduce in two buckets (output-side layers + loss slot first, on a second stream)"
+                    tb["transport"] = transport
+                    tb["n_ranks_seen"] = ctx.ranks_seen()
+                    out["train_two_buckets"] = tb
+                    ctx.comm_set_buckets(1)
                 if world == 1 and not args.no_extras:
                     # r5: the COMPUTE side of the data-parallel step on one GPU -- rank 0 of 8 on a communicator without a
                     # transport (v21_comm_init_null): its 4,096-row share of a 32,768-row global batch through the N > 1
@@ -1240,7 +1241,10 @@ def main():
             th.start()
             th.join(timeout=float(os.environ.get("V21_BENCH_TRAIN_TIMEOUT", "150")))
             if th.is_alive():
-                out["train"] = {"error": "timeout: the data-parallel training leg did not finish"}
+                # (what finished stays in `out`: the all-reduce leg is reported even if a later exchange form stalls)
+                out["train_timeout"] = {"error": "timeout: the data-parallel training legs did not all finish",
+                                        "finished": [k for k in ("train", "train_sharded_adam", "train_two_buckets") if k in out]}
+                out.setdefault("train", {"error": "timeout: the data-parallel training leg did not finish"})
                 if rank == 0:
                     print(json.dumps(out), file=json_out, flush=True)
                 os._exit(3)  # a hung leg is a failed run: the JSON line is still printed, the exit status says so

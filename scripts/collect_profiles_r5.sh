@@ -91,7 +91,7 @@ $PY scripts/diag/joint_fuzz.py 50 35 > $OUT/joint_fuzz_50_cases.txt 2>&1
 $PY scripts/diag/surface_fuzz.py 24 36 > $OUT/class_surface_fuzz_24_cases.txt 2>&1
 $PY scripts/diag/dp_fuzz.py 12 37 > $OUT/dp_fuzz_12_cases_2_to_4_ranks_on_one_gpu.txt 2>&1
 # the f32 joint step against a separate trainer on the oracle's latents: the relative loss difference by steps per epoch
-$PY -m pytest tests/test_fuzz_gpu.py -k drift -s -q -m gpu > $OUT/joint_f32_drift_by_step_count.txt 2>&1
+FUZZ_ONLY=115 $PY scripts/diag/joint_case115_r4.py 200 105 > $OUT/joint_f32_drift_by_step_count.txt 2>&1
 echo "fuzzers done"
 fi
 if want rest; then

@@ -66,23 +66,28 @@ def test_joint_fuzz_slice(ctx, k, clean_env):
     _check(*joint_fuzz.run_case(ctx, k), joint_fuzz.tag_of(k))
 
 
-def test_f32_joint_drift_against_the_separate_trainer_grows_with_the_step_count(ctx, clean_env):
-    """joint_fuzz case 115 (f32, 1,500 single-row steps per epoch, rel 5.4e-5) was answered by widening
-    the tolerance to 1e-4 with the explanation asserted, not shown.  Shown here: the same models, the same rows, batch 1,
-    after 100 / 500 / 1,500 steps per epoch -- the joint launch forms the emulator's targets (the frozen encoder's latents)
-    in fp32 arithmetic, the separate trainer is fed float32 roundings of the float64 oracle's; the targets differ by ~1e-7
-    relative, every Adam step passes that difference through 1 / (sqrt(v) + eps), and the two weight trajectories
-    separate step by step.  Asserted: the relative difference of the epoch losses stays under 2e-5 at 100 steps, under
-    1e-4 at 1,500, and does not shrink as the steps grow (it is accumulated, not a per-step error)."""
-    base = dict(c=115, D=100, lat=9, enc=[64], dec=[32], em_hid=[64, 32], prec="f32", batch=1, use_perm=True, data_seed=115)
-    rel = {}
-    for n in (100, 500, 1500):
-        lj, l2, frozen_ok, _ = joint_fuzz.frozen_encoder_run(ctx, dict(base, n=n), epochs=2)
-        assert frozen_ok
-        rel[n] = max(abs(a - b) / abs(b) for a, b in zip(lj, l2))
-    print("f32 joint vs separate trainer, relative epoch-loss difference by steps per epoch:", rel)
-    assert rel[100] <= 2e-5 and rel[500] <= 1e-4 and rel[1500] <= 1e-4, rel
-    assert rel[1500] >= 0.3 * rel[100], rel
+def test_f32_joint_drift_against_the_separate_trainer_grows_with_the_step_count(clean_env):
+    """joint_fuzz case 115 (seed 105: f32, autoencoder 33-352-288-16-16-512-33 frozen, emulator 7-400-16, 1,500
+    single-row steps per epoch) came out 5.4e-5 off the separate trainer on the oracle's latents, and r4 answered by widening the
+    tolerance to 1e-4 with "accumulated rounding" asserted, not shown.  Shown here, on the very case (scripts/diag/joint_case115_r4.py
+    keeps r4's generator so that it can be drawn again), epoch by epoch over four epochs: the two runs agree to ~6e-9 after the
+    first 1,500 steps and then SEPARATE -- 5e-5, 7e-5, 3e-4 -- until the emulator's weights differ by more than half their
+    range: two fp32 trajectories of batch-1 Adam steps (m / (sqrt(v) + eps) turns a 1e-8 difference of the targets -- fp32
+    latents formed on the device against float32 roundings of the float64 oracle's -- into different updates wherever a
+    gradient is small), not an error per step: fresh draws of the same shapes stay at 1e-8 for 3,000 steps (r5 runs).  The
+    invariant is therefore checked over TWO epochs, at 2e-5 for epochs of up to 64 steps and 1e-4 beyond (joint_fuzz.py)."""
+    import subprocess
+    env = dict(os.environ, FUZZ_ONLY="115")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "diag", "joint_case115_r4.py"), "200", "105"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("relative difference by epoch")]
+    assert line, r.stdout[-2000:]
+    rel = [float(v) for v in line[0].split("[")[1].rstrip("]").split(",")]
+    print("\n" + "\n".join(ln for ln in r.stdout.splitlines() if ln.startswith(("epoch losses", "relative difference", "emulator weights"))))
+    assert len(rel) == 4 and rel[0] < 1e-6                    # 1,500 steps: the same run to rounding
+    assert rel[1] < 1e-4                                      # the two epochs joint_fuzz.py compares: inside its bound
+    assert rel[3] > 10 * rel[0] and max(rel) < 5e-3           # ... and it GROWS with the steps: trajectories separating
 
 
 @pytest.mark.parametrize("k", list(sweep_fuzz.gen_cases(10, seed=21, max_count=64)), ids=lambda k: "c%d-%s-m%d-b%d" % (k["c"], k["prec"], k["count"], k["batch"]))
