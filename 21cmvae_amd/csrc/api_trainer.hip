@@ -756,8 +756,11 @@ int chain_prefetchers(int ncons, int models) {
 // Large steps (fused_train.h): the packed stream of the virtual stack -- forward layers, then the activation-gradient
 // layers with the transposed weights -- is rebuilt from the arena (the previous step's Adam moved it), then one launch
 // carries 128 rows per workgroup through forward pass, loss and activation gradients.
+// `xr` (or nullptr): filled when the step's rows lie in the resident training set -- the kernel then does NOT flush its layer-0
+// operand and the weight-gradient launch gathers the set's 16-bit rows instead (train_chain.h: DwXRows)
 static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, const float* y, long long ldy, const float* rw,
-                              const int* d_idx, long long first, int rows, int brows, long long row0, bool stream_fresh) {
+                              const int* d_idx, long long first, int rows, int brows, long long row0, bool stream_fresh,
+                              DwXRows* xr = nullptr) {
   v21_mlp* m = t->mlp;
   const int L = m->L;
   hipStream_t st = t->ctx->stream;
@@ -794,6 +797,10 @@ static int launch_fused_train(v21_trainer* t, const float* x, long long ldx, con
   // rows of the resident training set: the kernels gather their 16-bit copy
   if (t->d_x16 && ldx == m->dims[0] && x >= t->d_x[0] && x < t->d_x[0] + (size_t)t->n[0] * ldx && (x - t->d_x[0]) % ldx == 0) {
     a.x16 = t->d_x16 + (size_t)((x - t->d_x[0]) / ldx) * t->ldx16; a.ldx16 = t->ldx16;
+    if (xr) {
+      xr->x16 = a.x16; xr->ld = a.ldx16; xr->idx = d_idx; xr->first = first; xr->rows = rows;
+      a.lt[0].ht16 = nullptr;
+    }
   }
   if (t->train_arch < 0) {  // instantiated at run time (jit.hip)
     const hipError_t e = v21::jit_launch_train(t->train_jit, t->ctx->device, a, st);
@@ -943,16 +950,18 @@ static int dw16_attr(int prec) {  // (function attributes are per device; set ou
   bool* attr_done = attr_done_dev[dev & 63];
   if (!attr_done[prec]) {
     if (prec == V21_PREC_F16)
-      HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsTotal));
     else
-      HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsBytes));
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_dw16_lds_kernel<PrecBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLdsTotal));
     attr_done[prec] = true;
   }
   return V21_OK;
 }
-int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t st) {
+int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t st, const DwXRows* xr) {
   // large batches: 128x128 tiles staged through LDS (half the bytes pulled into a CU per MFMA)
   const bool big = !probs.empty() && probs[0].steps >= 64;
+  for (const Dw16Args& p : probs)
+    if (!p.A && !(big && xr && xr->x16)) return fail(V21_ERR_STATE, "weight-gradient problem without an operand");
   if (big) CHK(dw16_attr(prec));
   for (size_t o = 0; o < probs.size(); o += kNtMaxGroup) {
     Dw16Group grp{};
@@ -965,12 +974,13 @@ int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t st) {
       blocks += grp.p[i].nx * grp.p[i].ny;
     }
     grp.first[grp.count] = blocks;
+    if (xr) grp.xr = *xr;
     blocks *= grp.p[0].nz;
     if (blocks <= 0) continue;
     const dim3 grid((blocks + 7) / 8 * 8);  // whole rounds of the 8 XCDs (the kernels remap block ids XCD-wise)
     if (big) {
-      if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecF16>, grid, dim3(kDwThreads), kDwLdsBytes, st, grp);
-      else hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecBF16>, grid, dim3(kDwThreads), kDwLdsBytes, st, grp);
+      if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecF16>, grid, dim3(kDwThreads), kDwLdsTotal, st, grp);
+      else hipLaunchKernelGGL(gemm_dw16_lds_kernel<PrecBF16>, grid, dim3(kDwThreads), kDwLdsTotal, st, grp);
     } else {
       if (prec == V21_PREC_F16) hipLaunchKernelGGL(gemm_dw16_kernel<PrecF16>, grid, dim3(256), 0, st, grp);
       else hipLaunchKernelGGL(gemm_dw16_kernel<PrecBF16>, grid, dim3(256), 0, st, grp);
@@ -1219,6 +1229,7 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
   int fold = 1;
   if (rows > t->max_batch) return fail(V21_ERR_ARG, "batch of %d rows exceeds max_batch %d", rows, t->max_batch);
   bool fused_step = false;
+  DwXRows xrows{};  // x16 != nullptr: this step's layer-0 gradient operand is gathered from the resident rows
   const bool bucketed = dp_bucketed(t);
   const int ksplit = bucketed ? dp_split_layer(m) : 0;
   const size_t lo1 = bucketed ? (size_t)m->w_off[ksplit] : 0;  // bucket 1 = arena [lo1, P + 1), bucket 2 = [0, lo1)
@@ -1239,7 +1250,10 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     fused_step = fused;
     bool fused_done = false;
     if (fused) {
-      const int fr = launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, ts_fresh);
+      // (the LDS-staged gradient kernel only: launch_dw16 takes it from 64 batch steps of 16 rows on)
+      const bool want_xr = route.upd == UP_DW16_SPLITK && (rows + 15) / 16 >= 64 && RouteEnv::read().dw_xrows;
+      const int fr = launch_fused_train(t, x, ldx, y, ldy, rw, d_idx, first, rows, brows, row0, ts_fresh, want_xr ? &xrows : nullptr);
+      if (fr != V21_OK) xrows = DwXRows{};
       if (fr == V21_OK) fused_done = true;
       else if (t->train_arch >= 0) return fr;
       else {  // the run-time kernel could not be loaded (it spills: marked failed): this step and every later one take the chain
@@ -1271,6 +1285,8 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
     int nslice = 1;
     std::vector<Dw16Args> probs;
     dw16_problems(t, rows, brows, &nslice, probs);  // every weight gradient in one launch: [dW; db] = [H^T; 1^T] dZ
+    const DwXRows* xr = xrows.x16 ? &xrows : nullptr;
+    if (xr) probs[0].A = nullptr;
     if (bucketed) {
       // two launches, the upper layers first (their bucket also carries the loss slot: the batch loss is published by
       // whichever problem holds loss_acc -- the first of THIS launch); each problem's tiles are the same workgroups doing
@@ -1279,16 +1295,16 @@ static int train_on_rows(v21_trainer* t, const float* x, long long ldx, const fl
       pk.loss_acc = p0.loss_acc; pk.loss_out = p0.loss_out; pk.loss_out2 = p0.loss_out2; pk.sc = p0.sc;
       p0.loss_acc = nullptr; p0.loss_out = nullptr; p0.loss_out2 = nullptr;
       const std::vector<Dw16Args> upper(probs.begin() + ksplit, probs.end()), lower(probs.begin(), probs.begin() + ksplit);
-      CHK(launch_dw16(t->prec, upper, st));
+      CHK(launch_dw16(t->prec, upper, st, xr));
       if (nslice > 1) CHK(reduce_slabs_range(t, nslice, (long long)lo1, (long long)t->P));
       CHK(dp_exchange_bucket(t, 0, lo1, t->P + 1));
-      CHK(launch_dw16(t->prec, lower, st));
+      CHK(launch_dw16(t->prec, lower, st, xr));
       if (nslice > 1) CHK(reduce_slabs_range(t, nslice, 0, (long long)lo1));
       phase_mark(t, 2);
       CHK(dp_exchange_bucket(t, 1, 0, lo1));
       CHK(dp_exchange_join(t));
     } else {
-      CHK(launch_dw16(t->prec, probs, st));
+      CHK(launch_dw16(t->prec, probs, st, xr));
       fold = nslice > 1 && t->ctx->nranks == 1 ? nslice : 1;  // single rank: Adam sums the slabs itself
       if (nslice > 1 && fold == 1) {
         const long long n4 = ((long long)t->P + 3) / 4;

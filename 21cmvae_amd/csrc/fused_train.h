@@ -210,24 +210,26 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
   // phase S: two 1-KiB fragments (rows 0-15, 16-31 of the tile) as buffer stores: base = the operand buffer, scalar offset
   // = the tile, vector offset = (16-row group, lane); lanes whose feature lies past the operand get an offset beyond the
   // buffer and are dropped by the range check (exactly two store instructions per tile: TrainSched counts on it)
-  auto flush_s = [&](auto tile_, auto nfeat_, void* dst) __attribute__((always_inline)) {
+  auto flush_s = [&](auto tile_, auto nfeat_, void* dst, bool live = true) __attribute__((always_inline)) {
     constexpr int tile = decltype(tile_)::value, nfeat = decltype(nfeat_)::value;
     const chain_s8 v0 = {fr[0][0], fr[0][1], fr[0][2], fr[0][3], fr[1][0], fr[1][1], fr[1][2], fr[1][3]};
     const chain_s8 v1 = {fr[2][0], fr[2][1], fr[2][2], fr[2][3], fr[3][0], fr[3][1], fr[3][2], fr[3][3]};
     constexpr int ntile = (nfeat + 31) / 32;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(ntile * tile_bytes), 0x00020000);
-    unsigned vo = fvoff;
-    if constexpr (32 * tile + 32 > nfeat) vo = (32 * tile + (lane & 31) < nfeat) ? fvoff : 0xFFFFF000u;
+    unsigned vo = live ? fvoff : 0xFFFFF000u;
+    if constexpr (32 * tile + 32 > nfeat) vo = (32 * tile + (lane & 31) < nfeat) ? vo : 0xFFFFF000u;
 #ifdef V21_T_NOSTORE  // (diagnostic build: every lane's offset beyond the buffer -- the instructions issue, nothing is written)
     vo = 0xFFFFF000u;
 #endif
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rs, vo, tile * tile_bytes, 0);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rs, vo + 1024u, tile * tile_bytes, 0);
   };
-  auto flush_tile = [&](auto tile_, auto nfeat_, const unsigned (&w0)[4], const unsigned (&w1)[4], void* dst) __attribute__((always_inline)) {
+  // (`live` false -- wave-uniform -- : the two stores are issued with every lane's offset beyond the buffer, i.e. dropped by the
+  //  range check: TrainSched's operation counts stay as they are)
+  auto flush_tile = [&](auto tile_, auto nfeat_, const unsigned (&w0)[4], const unsigned (&w1)[4], void* dst, bool live = true) __attribute__((always_inline)) {
     flush_w(w0, w1);
     flush_r();
-    flush_s(tile_, nfeat_, dst);
+    flush_s(tile_, nfeat_, dst, live);
   };
 
   // ---- ring prologue, FIRST: its pieces land while the input rows below are gathered (the rows come from HBM, 59 MB per launch
@@ -273,11 +275,15 @@ __global__ void __launch_bounds__(64 * P::WAVES, V21_TRAIN_WPS) fused_train(cons
 #pragma unroll
       for (int wd = 0; wd < 4; ++wd) bufA[ks][wd] = P::pack2(v[2 * wd], v[2 * wd + 1]);
     });
+    // (ht16 of layer 0 == nullptr: the weight-gradient launch gathers this operand from the resident rows itself -- train_chain.h:
+    //  DwXRows -- and nothing is written here; the buffer descriptor's base is then the packed stream, never dereferenced)
+    const bool xlive = a.lt[0].ht16 != nullptr;
+    void* const xdst = xlive ? a.lt[0].ht16 : (void*)a.fw;
     static_for<(K0 + 31) / 32>([&](auto t_) __attribute__((always_inline)) {
       constexpr int t = decltype(t_)::value;
       const unsigned z[4] = {0u, 0u, 0u, 0u};
-      if constexpr (2 * t + 1 < G::ks_of(0)) flush_tile(t_, std::integral_constant<int, K0>{}, bufA[2 * t], bufA[2 * t + 1], a.lt[0].ht16);
-      else flush_tile(t_, std::integral_constant<int, K0>{}, bufA[2 * t], z, a.lt[0].ht16);
+      if constexpr (2 * t + 1 < G::ks_of(0)) flush_tile(t_, std::integral_constant<int, K0>{}, bufA[2 * t], bufA[2 * t + 1], xdst, xlive);
+      else flush_tile(t_, std::integral_constant<int, K0>{}, bufA[2 * t], z, xdst, xlive);
     });
   }
 

@@ -209,7 +209,10 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_train16(const Cha
   const unsigned short* const st_r = stg + (8 * ((lane >> 4) >> 1) + ((lane & 15) >> 2)) * kTrainStagePitch + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   const unsigned fvoff = (unsigned)(((m0 >> 4) * 64 + lane) * 16);  // this wave's 16-row group, this lane's 16 bytes
   const unsigned tile_bytes = (unsigned)a.BS * 1024u;               // one 32-feature tile of an operand buffer
-  auto flush_item = [&](auto tile_, auto nfeat_, const unsigned (&w)[4], void* dst) __attribute__((always_inline)) {
+  // (`live` false -- wave-uniform -- : the store is issued with every lane's offset beyond the buffer, i.e. dropped by the range
+  //  check: the counted waits of the stream keep their operation counts.  The staging round trip stays -- a branch around it
+  //  made the compiler duplicate and interleave the fifteen items of the input layer; it is two LDS writes and two reads)
+  auto flush_item = [&](auto tile_, auto nfeat_, const unsigned (&w)[4], void* dst, bool live = true) __attribute__((always_inline)) {
     constexpr int tile = decltype(tile_)::value, nfeat = decltype(nfeat_)::value;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     *reinterpret_cast<u32x2*>(st_w + 0) = u32x2{w[0], w[1]};
@@ -218,8 +221,8 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_train16(const Cha
     const chain_s8 v0 = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
     constexpr int ntile = (nfeat + 31) / 32;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(ntile * tile_bytes), 0x00020000);
-    unsigned vo = fvoff;
-    if constexpr (32 * tile + 32 > nfeat) vo = (32 * tile + (lane & 31) < nfeat) ? fvoff : 0xFFFFF000u;
+    unsigned vo = live ? fvoff : 0xFFFFF000u;
+    if constexpr (32 * tile + 32 > nfeat) vo = (32 * tile + (lane & 31) < nfeat) ? vo : 0xFFFFF000u;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rs, vo, tile * tile_bytes, 0);
   };
 
@@ -262,8 +265,12 @@ __global__ void __launch_bounds__(64 * P::WAVES, P::WPS) fused_train16(const Cha
 #pragma unroll
       for (int wd = 0; wd < 4; ++wd) bufA[ks][wd] = P::pack2(v[2 * wd], v[2 * wd + 1]);
     });
+    // (ht16 of layer 0 == nullptr: the weight-gradient launch gathers this operand from the resident rows itself -- train_chain.h:
+    //  DwXRows -- and nothing is written here; the buffer descriptor's base is then the packed stream, never dereferenced)
+    const bool xlive = a.lt[0].ht16 != nullptr;
+    void* const xdst = xlive ? a.lt[0].ht16 : (void*)a.fw;
     static_for<G::ks_of(0)>([&](auto t_) __attribute__((always_inline)) {
-      flush_item(t_, std::integral_constant<int, K0>{}, bufA[decltype(t_)::value], a.lt[0].ht16);
+      flush_item(t_, std::integral_constant<int, K0>{}, bufA[decltype(t_)::value], xdst, xlive);
     });
   }
 

@@ -62,6 +62,7 @@ struct RouteEnv {
   int dw32_lds = 1;           // V21_DW32_LDS=0: no LDS-staged fp32 gradient launch
   int dw32_adam = 1;          // V21_DW32_ADAM=0: no Adam in the fp32 gradient launch's epilogue
   int jit = 1;                // V21_JIT=0: no run-time compilation (cached code objects are still used)
+  int dw_xrows = 0;           // V21_DW_XROWS=1: a fused large step does not flush its layer-0 operand, the gradient launch gathers the resident rows (fewer bytes, measured slower)
   int sweep_streams = 2;      // V21_SWEEP_STREAMS=1: a sweep's grouped launches on one stream (default 2: two half-groups, api_sweep.hip)
   static RouteEnv read() {
     RouteEnv e;
@@ -77,6 +78,7 @@ struct RouteEnv {
     e.dw32_lds = flag("V21_DW32_LDS", 1);
     e.dw32_adam = flag("V21_DW32_ADAM", 1);
     e.jit = flag("V21_JIT", 1);
+    e.dw_xrows = flag("V21_DW_XROWS", 0);
     e.sweep_streams = num("V21_SWEEP_STREAMS", 2) == 1 ? 1 : 2;
     return e;
   }

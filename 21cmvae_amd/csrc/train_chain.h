@@ -703,10 +703,23 @@ struct Dw16Args {
   unsigned long long* loss_acc; float* loss_out; float* loss_out2;
   StepCtx sc;  // replayed step: the loss also goes to loss_out2[slot of the step]
 };
+// r5 (opt-in, V21_DW_XROWS=1): the layer-0 operand of a step on rows of the RESIDENT training set is not a flushed copy but
+// the set's 16-bit rows themselves (v21_trainer::d_x16: [row][feature], pitch `ld` halves, a multiple of 32), gathered
+// through the step's row table by gemm_dw16_lds_kernel's loader waves.  The problem of the group whose A is nullptr reads
+// it.  Measured (autoencoder stack, f16, 16,384 rows, profiles/r5/layer0_operand_gathered_vs_flushed/): 15 MB fewer bytes
+// per step and the fused kernel 1.5 us shorter, but this launch 23.1 -> 29.1 us -- with only the loaders gathering 27.9,
+// with only the compute waves on transposed 8-byte reads 26.0: the launch moves 96 KB through LDS per 32-KB stage and is
+// sensitive to both -- hence opt-in.
+struct DwXRows {
+  const unsigned short* x16; long long ld;
+  const int* idx; long long first;  // batch row i = set row idx[first + i] (idx == nullptr: first + i)
+  int rows;                         // batch rows of the step (rows past it repeat the last one: their dZ is zero)
+};
 struct Dw16Group {
   Dw16Args p[kNtMaxGroup];     // all with the same nz
   int first[kNtMaxGroup + 1];  // output tiles (nx * ny) of the problems before this one
   int count;
+  DwXRows xr;
 };
 template <class P>
 __global__ void __launch_bounds__(256) gemm_dw16_kernel(const Dw16Group grp) {
@@ -802,13 +815,15 @@ __global__ void __launch_bounds__(256) gemm_dw16_kernel(const Dw16Group grp) {
 // Eight more waves do nothing but issue the LDS-DMA: an in-order wave that issues 16 DMA pieces (60-180 cycles
 // each) cannot issue MFMAs meanwhile, and with one workgroup per CU nobody else covers for it (r1: 16 us for
 // ~2 us of MFMA work; with four loaders a stage still took 910 cycles against 512 of MFMAs).  Loader q moves
-// fragment q of every batch step; the loaders run two stages ahead through a ring of four 32-KiB stages (4
+// fragment q of every batch step; the loaders run three stages ahead through a ring of four 32-KiB stages (4
 // batch steps each) behind a counted vmcnt -- they issue nothing else, so the count is exact -- and one barrier
 // per stage hands a stage over.
 constexpr int kDwStageSteps = 4;
 constexpr int kDwRing = 4;
 constexpr int kDwStageBytes = kDwStageSteps * 8 * kFragBytes;
 constexpr int kDwLdsBytes = kDwRing * kDwStageBytes;
+constexpr int kDwIdxSlots = 8;                                // row tables of a gathering loader wave (DwXRows): 64 ints per stage
+constexpr int kDwLdsTotal = kDwLdsBytes + 4 * kDwIdxSlots * 256;  // the operand ring + four loaders' row-table rings
 constexpr int kDwThreads = 768;  // 4 compute + 8 loader waves
 template <class P>
 __global__ void __launch_bounds__(kDwThreads) gemm_dw16_lds_kernel(const Dw16Group grp) {
@@ -845,6 +860,72 @@ __global__ void __launch_bounds__(kDwThreads) gemm_dw16_lds_kernel(const Dw16Gro
     const int q = wave - 4;
     const int mt = (g.M + 31) / 32, nt = (g.N + 31) / 32;
     const int tile = q < 4 ? min(4 * by + q, mt - 1) : min(4 * bx + q - 4, nt - 1);
+    if (q < 4 && g.A == nullptr) {
+      // ---- the A tiles from the resident rows (DwXRows).  The workgroup's four feature tiles are 256 contiguous bytes of a
+      // row, and a DMA instruction that takes them whole moves as many full cache lines as a flushed fragment does (first
+      // form: a piece = one tile of 16 rows = sixteen 64-byte runs -- twice the requests per byte, the launch 23 -> 30 us).
+      // Loader q moves rows q, q + 4, q + 8, q + 12 of every batch step: lane l = (row q + 4 (l / 16), 16-byte slot l % 16),
+      // and the slot holds feature chunk (l % 16 + 4 q) % 16 of the 256 bytes -- the rotation puts the four rows of a
+      // transposed read (one from each loader's piece, 1 KiB apart) on four different bank groups.  A stage is 64
+      // consecutive batch rows: lane i fetches the set row of batch row 64 st + i (ONE operation per stage, counted with the
+      // pieces).  Columns past the row pitch (the bias feature's tile of a stack whose input width is a multiple of 32) are
+      // clamped: the compute waves overwrite that feature, the others are never stored.
+      const DwXRows& xr = grp.xr;
+      int col = 128 * by + 8 * (((lane & 15) + 4 * q) & 15);
+      col = min(col, (int)xr.ld - 8);
+      const unsigned short* const colbase = xr.x16 + col;
+      const int R0 = 16 * sbeg;
+      const int* const ip = xr.idx ? xr.idx + xr.first : nullptr;
+      // The row table of a stage travels by LDS-DMA too (64 x 4 bytes into this wave's own eight-slot ring behind the
+      // operand ring): a load into a REGISTER that is still on its way must not be copied, and the compiler does copy
+      // registers around inline asm and across loop edges (first form of this loop: a v_mov of the destination ahead of
+      // the counted wait).  Nothing is in flight in a register here; the wave reads its rows with plain LDS loads once the
+      // counted wait has covered the DMA.
+      unsigned char* const itab = dw_smem + kDwLdsBytes + q * (kDwIdxSlots * 256);
+      auto fetch = [&](int st) __attribute__((always_inline)) {
+        if (!ip) return;
+        const int rr = min(R0 + 64 * st + lane, xr.rows - 1);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(ip + rr), "s"(lds_addr(itab) + (st % kDwIdxSlots) * 256) : "memory");
+      };
+      auto issue_x = [&](int st) __attribute__((always_inline)) {
+        const unsigned base = lds_addr(dw_smem) + (st % kDwRing) * kDwStageBytes;
+        const int* tab = reinterpret_cast<const int*>(itab + (st % kDwIdxSlots) * 256);
+#pragma unroll
+        for (int s = 0; s < kDwStageSteps; ++s) {
+          const int j = 16 * s + q + 4 * (lane >> 4);
+          const int srow = ip ? tab[j] : (int)xr.first + min(R0 + 64 * st + j, xr.rows - 1);
+          const unsigned short* p = colbase + (long long)srow * xr.ld;
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(p), "s"(base + (s * 8 + q) * kFragBytes) : "memory");
+        }
+      };
+      // DMA three stages ahead (slot (st + 3) % 4 is the slot of stage st - 1, which every compute wave has finished reading
+      // when barrier st completes); row tables five stages ahead -- with the table only one iteration ahead of its use every
+      // iteration of this loop waited for a dependent load (measured: the launch 23.9 -> 28.8 us at 16,384 rows).
+      // In flight at the top of iteration st, oldest first:
+      //   [pieces st] [table st+3] [pieces st+1] [table st+4] [pieces st+2]          (iteration st issues table st+5, pieces st+3)
+      // so "at most pieces st+1, table st+4, pieces st+2 left" = stage st has landed and so has the row table of stage st+3.
+      fetch(0);
+      if (nst > 1) fetch(1);
+      if (nst > 2) fetch(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (nst > 3) fetch(3);
+      if (nst > 4) fetch(4);
+      issue_x(0);
+      if (nst > 1) issue_x(1);
+      if (nst > 2) issue_x(2);
+      for (int st = 0; st < nst; ++st) {
+        const int left = (st + 1 < nst ? 4 : 0) + (st + 2 < nst ? 4 : 0) + ((ip && st > 0 && st + 4 < nst) ? 1 : 0);
+        switch (left) {
+          case 9: asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory"); break;
+          case 8: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        }
+        if (st + 5 < nst) fetch(st + 5);
+        if (st + 3 < nst) issue_x(st + 3);
+      }
+      return;
+    }
     const unsigned char* src = reinterpret_cast<const unsigned char*>(q < 4 ? g.A : g.B) + ((long long)tile * g.BS) * kFragBytes;
     auto issue = [&](int st) __attribute__((always_inline)) {
       const unsigned base = lds_addr(dw_smem) + (st % kDwRing) * kDwStageBytes;
@@ -856,13 +937,16 @@ __global__ void __launch_bounds__(kDwThreads) gemm_dw16_lds_kernel(const Dw16Gro
     };
     issue(0);
     if (nst > 1) issue(1);
+    if (nst > 2) issue(2);
     for (int st = 0; st < nst; ++st) {
-      // stage st has landed (this wave's share) once at most stage st+1's pieces are outstanding; after the
-      // barrier the compute waves are done with stage st-1, hence with the ring slot of stage st+2 as well
-      static_assert(kDwStageSteps == 4, "the counted wait below is one stage of pieces");
-      if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      // stage st has landed (this wave's share) once at most the pieces of stages st+1 and st+2 are outstanding; after the
+      // barrier the compute waves are done with stage st-1, i.e. with the ring slot of stage st+3 (r5: three stages ahead,
+      // two until r4)
+      static_assert(kDwStageSteps == 4 && kDwRing == 4, "the counted waits below are whole stages of four pieces; slot (st + 3) % 4 = slot of st - 1");
+      if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      else if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (st + 2 < nst) issue(st + 2);
+      if (st + 3 < nst) issue(st + 3);
     }
     // The loader waves END here, before the compute waves' last s_barrier (the epilogue's): on gfx950 an ended wave no
     // longer counts towards its workgroup's barrier, so the compute waves meet among themselves.  (Do not add a barrier
@@ -879,35 +963,68 @@ __global__ void __launch_bounds__(kDwThreads) gemm_dw16_lds_kernel(const Dw16Gro
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  for (int st = 0; st < nst; ++st) {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage st is in LDS; this wave's reads of st-1 are done
-    const unsigned char* buf = dw_smem + (st % kDwRing) * kDwStageBytes + lane * 16;
-    const int ns = min(kDwStageSteps, send - sbeg - st * kDwStageSteps);
-    // the fragments of step s+1 are read under the MFMAs of step s (steps past the slice hold a re-read of its
-    // last step: reading them is harmless, they are not multiplied)
-    frag fa[2][2], fb[2][2];
+  // (xg: this problem's A tiles come as row images of the resident set -- DwXRows -- and are read through the hardware
+  // transpose: lane = (8-row group kh, feature f) as in a flushed fragment, rows 8 kh + 0..3 and 8 kh + 4..7 in two reads,
+  // i.e. the very 16 bytes a flushed fragment holds for that lane; the bias feature M - 1 is a constant one)
+  auto contract = [&](auto xg_) __attribute__((always_inline)) {
+    constexpr bool XG = decltype(xg_)::value;
+    // (the image of a batch step, DwXRows: piece qq = rows qq + 4 r at r * 256 bytes, feature chunk c of the workgroup's 256
+    //  bytes in slot (c - 4 qq) % 16; a transposed read takes rows 4 b + 0..3 -- lane 4 qq + p of a 16-lane group supplies row
+    //  qq, columns 4 p .. 4 p + 3 of the group's 16 features -- with b = 2 kh for the first read, 2 kh + 1 for the second)
+    const int gi = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    int tr_off[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      fa[0][t] = *reinterpret_cast<const frag*>(buf + (2 * wi + t) * kFragBytes);
-      fb[0][t] = *reinterpret_cast<const frag*>(buf + (4 + 2 * wj + t) * kFragBytes);
-    }
+    for (int t = 0; t < 2; ++t)
+      tr_off[t] = qq * 1024 + 2 * (gi >> 1) * 256 + (((4 * (2 * wi + t) + 2 * (gi & 1) + (pp >> 1) - 4 * qq) & 15) << 4) + 8 * (pp & 1);
+    const int mt = (g.M + 31) / 32;
+    const unsigned one2 = P::pack2(1.f, 1.f);
+    bool is_one[2];
 #pragma unroll
-    for (int s = 0; s < kDwStageSteps; ++s) {
-      if (s + 1 < kDwStageSteps) {
+    for (int t = 0; t < 2; ++t) is_one[t] = XG && (4 * by + 2 * wi + t == mt - 1) && ((lane & 31) == ((g.M - 1) & 31));
+    auto read_a = [&](const unsigned char* stage, int s, int t) __attribute__((always_inline)) -> frag {
+      if constexpr (!XG) return *reinterpret_cast<const frag*>(stage + lane * 16 + (s * 8 + 2 * wi + t) * kFragBytes);
+      else {
+        const unsigned char* img = stage + s * 8 * kFragBytes + tr_off[t];
+        const chain_s4 f0 = chain_tr_read(img), f1 = chain_tr_read(img + 256);
+        const chain_s8 v = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+        u32x4 w = __builtin_bit_cast(u32x4, v);
+        if (is_one[t]) w = u32x4{one2, one2, one2, one2};
+        return __builtin_bit_cast(frag, w);
+      }
+    };
+    for (int st = 0; st < nst; ++st) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // stage st is in LDS; this wave's reads of st-1 are done
+      const unsigned char* stage = dw_smem + (st % kDwRing) * kDwStageBytes;
+      const unsigned char* buf = stage + lane * 16;
+      const int ns = min(kDwStageSteps, send - sbeg - st * kDwStageSteps);
+      // the fragments of step s+1 are read under the MFMAs of step s (steps past the slice hold a re-read of its last
+      // step: reading them is harmless, they are not multiplied)
+      frag fa[2][2], fb[2][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          fa[(s + 1) & 1][t] = *reinterpret_cast<const frag*>(buf + ((s + 1) * 8 + 2 * wi + t) * kFragBytes);
-          fb[(s + 1) & 1][t] = *reinterpret_cast<const frag*>(buf + ((s + 1) * 8 + 4 + 2 * wj + t) * kFragBytes);
+      for (int t = 0; t < 2; ++t) {
+        fa[0][t] = read_a(stage, 0, t);
+        fb[0][t] = *reinterpret_cast<const frag*>(buf + (4 + 2 * wj + t) * kFragBytes);
+      }
+#pragma unroll
+      for (int s = 0; s < kDwStageSteps; ++s) {
+        if (s + 1 < kDwStageSteps) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            fa[(s + 1) & 1][t] = read_a(stage, s + 1, t);
+            fb[(s + 1) & 1][t] = *reinterpret_cast<const frag*>(buf + ((s + 1) * 8 + 4 + 2 * wj + t) * kFragBytes);
+          }
+        }
+        if (s < ns) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = P::template mfma<false>(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
         }
       }
-      if (s < ns) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = P::template mfma<false>(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
-      }
     }
-  }
+  };
+  if (g.A == nullptr) contract(std::true_type{});
+  else contract(std::false_type{});
   // ---- epilogue.  Straight from the accumulators a lane would store one float per instruction (lane = column,
   // registers = rows): 64 store instructions per wave, and a row-per-lane store tail is ISSUE-bound (~170 cycles
   // each: measured 10.9k cycles here, more than the whole contraction).  So the 64x64 quadrant goes through

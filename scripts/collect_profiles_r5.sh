@@ -77,6 +77,9 @@ $PY scripts/diag/jit_fuzz.py 40 1 > $OUT/jit_fuzz_40_random_stacks.txt 2>&1
 for n in 9216 12288 16384 32768; do $PY scripts/diag/fused_train_probe.py $n f16 > $OUT/fused_train_probe_b${n}_f16.txt 2>&1; done
 V21_FUSED_TRAIN16=0 $PY scripts/diag/fused_train_probe.py 16384 f16 > $OUT/fused_train_probe_b16384_f16_forced_32_rows_per_wave.txt 2>&1
 V21_FUSED_TRAIN16=1 $PY scripts/diag/fused_train_probe.py 32768 f16 > $OUT/fused_train_probe_b32768_f16_forced_16_rows_per_wave.txt 2>&1
+# r5, VERDICT r4 item 7: the layer-0 gradient operand flushed (default) against gathered from the resident rows (V21_DW_XROWS=1)
+bash $ROOT/scripts/diag/xrows_ab.sh > $OUT/layer0_operand_ab.log 2>&1
+cd $ROOT
 $PY scripts/power_probe.py > $OUT/power_probe_fused_random_vs_zero_operands.txt 2>&1
 fi
 if want fuzz; then

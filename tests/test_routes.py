@@ -40,7 +40,7 @@ _tid = lambda r: "%s-%s-mb%d-rows%d-r%d%s" % (r["stack"], r["prec"], r["max_batc
 _fid = lambda r: "%s-%s-rows%d-%s" % (r["stack"], r["prec"], r["rows"], "rt" if r["rt"] else "nort")
 ROUTE_ENV = ["V21_TRAIN_CHAIN", "V21_FUSED_TRAIN", "V21_FUSED_TRAIN16", "V21_FUSED_TRAIN_ROWS", "V21_DW_SPLIT_ROWS", "V21_CHAIN32S",
              "V21_C32S_ROWS", "V21_DW32_LDS", "V21_DW32_ADAM", "V21_JIT", "V21_TRAIN_X16", "V21_SWEEP32_GROUP", "V21_CHAIN_PLAIN",
-             "V21_DW_BLOCKS", "V21_CHAIN_PREF"]
+             "V21_DW_BLOCKS", "V21_CHAIN_PREF", "V21_DW_XROWS", "V21_SWEEP_STREAMS"]
 
 
 @pytest.fixture

@@ -1472,3 +1472,37 @@ def test_fused_training_gathers_the_resident_16_bit_copy_with_identical_results(
     for (la, ga), (lb, gb) in zip(oa, ob):
         assert la == lb and np.array_equal(ga, gb)
     assert np.array_equal(wa, wb)
+
+
+@pytest.mark.parametrize("name,dims,act,prec,rows,use_perm,max_batch", [
+    ("AE", None, None, "f16", 16384, True, 16384),       # fused_train16, two rounds of workgroups
+    ("AE", None, None, "bf16", 16389, False, 16400),     # ragged, no row table
+    ("D1", None, None, "f16", 8197, True, 16384),        # input width 7: one feature tile that also holds the bias feature
+    ("AE", None, None, "f16", 24581, True, 32768),       # the 32-rows-per-wave kernel
+    ("X64", [64, 96, 64], [1, 0], "f16", 9000, True, 16384),  # run-time kernel; input width a multiple of 32: the bias feature's tile lies past the row pitch
+])
+def test_layer0_gradient_operand_gathered_from_resident_rows_is_bit_identical(ctx, monkeypatch, name, dims, act, prec, rows, use_perm, max_batch):
+    """r5: a fused large step on rows of the resident training set no longer flushes a duplicate of its
+    input rows as the layer-0 weight-gradient operand; gemm_dw16_lds_kernel's loader waves gather the set's 16-bit rows through
+    the step's row table and the compute waves read them through the hardware transpose (train_chain.h: DwXRows).  The operand
+    values and the order of every sum are those of the flushed form (V21_DW_XROWS=0): loss, FULL gradient and weights after two
+    more epochs must be identical bit for bit -- and match the float64 oracle."""
+    from helpers import STACKS, stack_data, twin_steps, assert_step_matches_oracle
+    if dims is None:
+        dims, act = STACKS[name]
+    n = rows   # the first epoch is ONE step of all rows (through the row table when there is one); the later epochs take steps of
+    x, y, w = stack_data(dims, n, seed=31)   # 9,000 / 8,200 rows out of the set and a partial last step
+    rng = np.random.default_rng(9)
+    perm = rng.permutation(n).astype(np.int32) if use_perm else None
+    more = ((perm, 9000), (None, 8200))
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("V21_DW_XROWS", flag)
+        twins, weights = twin_steps(ctx, dims, act, prec, max_batch, x, y, w, perm, rows, more=more, wait_jit=name == "X64")
+        assert twins[0][3][0] in ("fused64", "fused128") and twins[0][3][1] == "dw16_splitk", twins[0][3]
+        assert_step_matches_oracle((name, prec, rows, flag), twins, weights, act, x, y, w, perm, rows, prec)
+        res[flag] = twins[0]
+    (l1, g1, w1, _, _), (l0, g0, w0, _, _) = res["1"], res["0"]
+    assert l1 == l0
+    assert np.array_equal(g1, g0), "gradient differs: max %.3e" % np.abs(g1 - g0).max()
+    assert np.array_equal(w1, w0)
