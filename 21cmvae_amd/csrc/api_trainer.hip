@@ -1067,8 +1067,15 @@ int launch_dw_adam_group(const std::vector<v21_trainer*>& tr, const DwAdamModel*
     maxblk = std::max(maxblk, h_tab[k].nblk);
   }
   const dim3 grid((maxblk + 7) / 8 * 8, (unsigned)tr.size());
-  if (tr[0]->prec == V21_PREC_F16) hipLaunchKernelGGL(dw16_adam_group_kernel<PrecF16>, grid, dim3(64 * kDwAdamWaves), 0, st, d_tab, stp);
-  else hipLaunchKernelGGL(dw16_adam_group_kernel<PrecBF16>, grid, dim3(64 * kDwAdamWaves), 0, st, d_tab, stp);
+  const bool small = stp.steps <= 32;  // (dw_adam.h: U)
+  const bool f16 = tr[0]->prec == V21_PREC_F16;
+  if (small) {
+    if (f16) hipLaunchKernelGGL((dw16_adam_group_kernel<PrecF16, 2>), grid, dim3(64 * kDwAdamWaves), 0, st, d_tab, stp);
+    else hipLaunchKernelGGL((dw16_adam_group_kernel<PrecBF16, 2>), grid, dim3(64 * kDwAdamWaves), 0, st, d_tab, stp);
+  } else {
+    if (f16) hipLaunchKernelGGL((dw16_adam_group_kernel<PrecF16, kDwAdamInFlight>), grid, dim3(64 * kDwAdamWaves), 0, st, d_tab, stp);
+    else hipLaunchKernelGGL((dw16_adam_group_kernel<PrecBF16, kDwAdamInFlight>), grid, dim3(64 * kDwAdamWaves), 0, st, d_tab, stp);
+  }
   HIPCHK(hipGetLastError());
   for (v21_trainer* t : tr) {
     t->copies_ok = true; t->nt_ok = false;

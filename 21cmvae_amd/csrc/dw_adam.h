@@ -61,11 +61,11 @@ static_assert(sizeof(DwAdamModel) + sizeof(DwAdamStep) <= 4096, "dw16_adam_kerne
 #else
 #define DWFINE(i)
 #endif
-template <class P>
+template <class P, int U = kDwAdamInFlight>
 __device__ __forceinline__ void dw16_adam_body(const DwAdamModel& md, const int lb, const float alpha, const float out_scale,
                                                const int steps, const int slot, const StepCtx& sc) {
   using frag = typename P::frag;
-  constexpr int NW = kDwAdamWaves, U = kDwAdamInFlight;
+  constexpr int NW = kDwAdamWaves;
   __shared__ __attribute__((aligned(16))) float part[NW][16][64];
   __shared__ __attribute__((aligned(16))) unsigned short pk[32 * kDwAdamPitch];
   DWFINE(0);
@@ -209,13 +209,18 @@ __global__ void __launch_bounds__(64 * kDwAdamWaves) dw16_adam_kernel(const DwAd
   if (lb >= md.nblk) return;
   dw16_adam_body<P>(md, lb, st.sc.desc ? st.sc.desc[*st.sc.cur].alpha : st.alpha[0], st.out_scale[0], st.steps, st.slot, st.sc);
 }
-// a group (sweep, joint step): blockIdx.y = model, the per-model blocks in device memory
-template <class P>
-__global__ void __launch_bounds__(64 * kDwAdamWaves) dw16_adam_group_kernel(const DwAdamModel* __restrict__ tab, const DwAdamStep st) {
+// a group (sweep, joint step): blockIdx.y = model, the per-model blocks in device memory.
+// U: fragment pairs in flight per wave.  A group step of <= 512 rows gives a wave at most four batch steps: with U = 2 the
+// kernel needs half the registers (63 against 116), four workgroups fit a CU instead of two, and twice as many of the arena
+// reads that bound a large group's step (12 MB per member) are in flight -- r5, f16 sweeps of 8 / 16 /
+// 32 / 64 members: 110 -> 119, 160 -> 185, 198 -> 207-214, 183 -> 197-199 k model-steps/s; same sums in the same order.
+// (A single model's launch -- 315 workgroups -- does not change: 31.5 against 31.7 us per 256-row step; it keeps U = 8.)
+template <class P, int U>
+__global__ void __launch_bounds__(64 * kDwAdamWaves, U == 2 ? 8 : 1) dw16_adam_group_kernel(const DwAdamModel* __restrict__ tab, const DwAdamStep st) {
   const DwAdamModel& md = tab[blockIdx.y];
   const int lb = dw_adam_logical_block(md.nblk);
   if (lb >= md.nblk) return;
-  dw16_adam_body<P>(md, lb, st.alpha[blockIdx.y], st.out_scale[blockIdx.y], st.steps, st.slot, st.sc);
+  dw16_adam_body<P, U>(md, lb, st.alpha[blockIdx.y], st.out_scale[blockIdx.y], st.steps, st.slot, st.sc);
 }
 
 }  // namespace v21
