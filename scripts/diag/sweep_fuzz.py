@@ -77,7 +77,70 @@ def run_case(ctx, k):
     twin = all(np.array_equal(a, b) for a, b in zip(gw, gw2)) and gl == gl2
     finite = all(np.isfinite(a).all() for a in gw)
     ok = worst_l <= ltol and worst_w <= wtol and twin and finite
-    return ("OK" if ok else "BAD"), "loss rel %.1e (tol %.0e) weights max diff %.1e (tol %.0e) twin identical %s" % (worst_l, ltol, worst_w, wtol, twin)
+    msg = "loss rel %.1e (tol %.0e) weights max diff %.1e (tol %.0e) twin identical %s" % (worst_l, ltol, worst_w, wtol, twin)
+    if not ok and worst_l <= ltol and twin and finite and worst_w > wtol:
+        # weights apart, losses together: a ReLU on the other side of zero in one of the two runs?  (Two f32 kernels that sum
+        # in different orders may disagree on the sign of a pre-activation of size 1e-7; the unit's whole column of [W; b]
+        # then gets another gradient for that row, and Adam turns ANY gradient difference into a step of up to lr.)  Not
+        # assumed: the first diverging step is looked up and the pre-activation shown, or the case stays BAD.
+        j = int(np.argmax([float(np.abs(gw[i] - solo[i].stack.get_weights()).max()) for i in range(len(solo))]))
+        why = explain_by_relu_kink(ctx, k, j, build, x, y, w, perm)
+        if why:
+            return "OK", msg + " | member %d EXPLAINED: %s" % (j, why)
+        msg += " | member %d: no pre-activation at zero found in the first diverging step" % j
+    return ("OK" if ok else "BAD"), msg
+
+
+def explain_by_relu_kink(ctx, k, j, build, x, y, w, perm):
+    """Steps member j alone and inside the group, one optimizer step at a time, up to the first step whose GRADIENTS differ by
+    more than summation noise; there, in float64 and with the weights both runs still share, looks for the pre-activation at
+    zero that explains it: the top-most layer whose gradient blocks differ must be a ReLU layer, differ in few columns only,
+    and one of those units must have |z| < 1e-5 of the layer's largest for a row of the step.  -> text or None."""
+    native = importlib.import_module("21cmvae_amd._native")
+    n, batch, act, dims = k["n"], k["batch"], k["act"], k["members"][j]
+    offs = np.cumsum([0] + [a * b + b for a, b in zip(dims[:-1], dims[1:])])
+    alone = build()[j]
+    grp = build()
+    sw = None
+    order = perm if perm is not None else np.arange(n, dtype=np.int32)
+    step = 0
+    for epoch in range(2):
+        for first in range(0, n, batch):
+            rows = order[first:first + batch].astype(np.int32)
+            w_before = alone.stack.get_weights().astype(np.float64)
+            # (one optimizer step = an epoch over a training set that is this step's rows)
+            xs, ys, ws_ = x[rows], (None if y is None else y[rows]), w[rows]
+            alone.set_data(0, xs, ys, ws_); grp[0].set_data(0, xs, ys, ws_)
+            if sw is None:
+                sw = native.Sweep(grp)
+            alone.run_epoch(None, len(rows)); sw.run_epoch(None, len(rows))
+            ga, gg = alone.get_grad(), grp[j].get_grad()
+            scale = float(np.abs(ga).max())
+            if float(np.abs(ga - gg).max()) <= 1e-6 * scale:
+                step += 1
+                continue
+            # the top-most layer whose blocks differ
+            top = max(l for l in range(len(dims) - 1) if float(np.abs(ga[offs[l]:offs[l + 1]] - gg[offs[l]:offs[l + 1]]).max()) > 1e-6 * scale)
+            if not act[top]:
+                return None
+            K, N = dims[top], dims[top + 1]
+            d = np.abs(ga[offs[top]:offs[top + 1]] - gg[offs[top]:offs[top + 1]]).reshape(K + 1, N)
+            cols = np.where(d.max(0) > 1e-6 * scale)[0]
+            if cols.size > 4:
+                return None
+            h = x[rows].astype(np.float64)
+            for l in range(top + 1):
+                Wl = w_before[offs[l]:offs[l] + dims[l] * dims[l + 1]].reshape(dims[l], dims[l + 1])
+                bl = w_before[offs[l] + dims[l] * dims[l + 1]:offs[l + 1]]
+                z = h @ Wl + bl
+                h = np.maximum(z, 0) if act[l] else z
+            zc = np.abs(z[:, cols])
+            r = np.unravel_index(np.argmin(zc), zc.shape)
+            if zc[r] > 1e-5 * float(np.abs(z).max()):
+                return None
+            return ("optimizer step %d: the gradients differ in column(s) %s of layer %d's [W; b] only; float64 pre-activation of unit %d, row %d of the step: %.2e (largest of the layer %.2e) -- a ReLU at its kink"
+                    % (step, cols.tolist(), top, int(cols[r[1]]), int(r[0]), float(z[r[0], cols[r[1]]]), float(np.abs(z).max())))
+    return None
 
 
 if __name__ == "__main__":
