@@ -106,9 +106,21 @@ def run_case(ctx, k, setenv=os.environ.__setitem__, delenv=lambda n: os.environ.
     ratio = float(np.linalg.norm(g1) / max(1e-300, np.linalg.norm(go)))
     ok_oracle = abs(l1 - lo) <= tol_l * abs(lo) and cos > tol_c and abs(ratio - 1) < 10 * tol_l and bool(np.isfinite(g1).all())
     ok_twin = l1 == l2 and np.array_equal(g1, g2) and np.array_equal(w1, w2)
-    msg = "loss rel %.1e cos %.7f ratio %.5f | twin: grad max diff %.1e weights max diff %.1e | %s" % (
-        abs(l1 - lo) / abs(lo), cos, ratio, np.abs(g1 - g2).max(), np.abs(w1 - w2).max(), rc)
-    return ("OK" if ok_oracle and ok_twin else "BAD"), msg
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import layer_errors, per_layer_gradient_check
+    le = layer_errors(dims, g1, go)
+    ok_layers, note_layers = per_layer_gradient_check(dims, act, Ws, bs, x[idx], g1, go, prec)
+    worst_l2, worst_el = max(e[0] for e in le), max(e[1] for e in le)
+    if os.environ.get("FUZZ_LAYERS") == "1":   # per layer: (relative L2, worst element / largest), columns of [W; b] off by > 1e-5 of the layer's largest
+        offs = np.cumsum([0] + [a * b + b for a, b in zip(dims[:-1], dims[1:])])
+        for i, e in enumerate(le):
+            d = np.abs(g1[offs[i]:offs[i + 1]] - go[offs[i]:offs[i + 1]]).reshape(dims[i] + 1, dims[i + 1])
+            sc = float(np.abs(go[offs[i]:offs[i + 1]]).max())
+            print("    layer %d %4d -> %-4d rel L2 %.1e element %.1e: %d of %d columns hold an element off by > 1e-5 of the layer's largest gradient" % (
+                i, dims[i], dims[i + 1], e[0], e[1], int((d.max(0) > 1e-5 * sc).sum()), dims[i + 1]))
+    msg = "loss rel %.1e cos %.7f ratio %.5f | %s | twin: grad max diff %.1e weights max diff %.1e | %s" % (
+        abs(l1 - lo) / abs(lo), cos, ratio, note_layers, np.abs(g1 - g2).max(), np.abs(w1 - w2).max(), rc)
+    return ("OK" if ok_oracle and ok_layers and ok_twin else "BAD"), msg
 
 
 if __name__ == "__main__":

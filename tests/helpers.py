@@ -41,6 +41,59 @@ def oracle_step(Ws, bs, act, x, tgt, w):
     return lo, ora.flatten_params(dWs, dbs)
 
 
+def layer_errors(dims, g, go):
+    """Per layer's [W; b] block of the flat arena: (||g - go|| / ||go||, max |g - go| / max |go|).  The cosine over the WHOLE arena
+    cannot see a small layer: the autoencoder's 9 -> 32 layer is 320 of 332,000 elements (r5; a first-layer gradient that lacked
+    one row of 257 would have passed at cosine 0.9999995)."""
+    offs = np.cumsum([0] + [a * b + b for a, b in zip(dims[:-1], dims[1:])])
+    out = []
+    for i in range(len(dims) - 1):
+        a, b = np.asarray(g[offs[i]:offs[i + 1]], np.float64), np.asarray(go[offs[i]:offs[i + 1]], np.float64)
+        out.append((float(np.linalg.norm(a - b) / max(1e-300, np.linalg.norm(b))), float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))))
+    return out
+
+
+def per_layer_gradient_check(dims, act, Ws, bs, xrows, g, go, prec):
+    """-> (ok, note).  Every layer's block of the gradient against the float64 oracle's, by relative L2 norm.
+    f32: summation noise only (2e-6: measured 1.2e-7 to 4e-7 from 1 to 32,768 rows) -- unless a ReLU sits on
+    the other side of zero than in float64: a unit whose pre-activation is ~1e-7 of the layer's largest for one row gets that
+    row's contribution or not; its column of [W; b] is then off by one row's worth and every layer BELOW it by what flows back
+    through that unit (r5: 2,047 rows of the latent emulator -- one column of layer 2 off, half the columns of layers 1 and 0,
+    layers 3 and 4 exact to 2e-7).  That case is accepted only when it is shown: the top-most layer that is off must be a ReLU
+    layer, be off in at most 8 columns, and each of those units must have such a pre-activation in float64.
+    f16 / bf16: 0.1 / 0.25 (operands rounded to 11 / 8 bits, and 16-bit pre-activations cross zero routinely; steps of fewer
+    than 64 rows: 0.5) -- loose, but a layer that is WRONG is off by ~1, and the whole-arena cosine does not see a small layer."""
+    rows = len(xrows)
+    le = layer_errors(dims, g, go)
+    worst = max(e[0] for e in le)
+    if prec != "f32":
+        tol = 0.5 if rows < 64 else (0.1 if prec == "f16" else 0.25)
+        return worst <= tol, "per-layer rel L2 <= %.1e (tol %.2g)" % (worst, tol)
+    tol = 2e-6
+    if worst <= tol:
+        return True, "per-layer rel L2 <= %.1e (tol %.1e)" % (worst, tol)
+    L = len(dims) - 1
+    offs = np.cumsum([0] + [a * b + b for a, b in zip(dims[:-1], dims[1:])])
+    top = max(l for l in range(L) if le[l][0] > tol)
+    if not act[top]:
+        return False, "layer %d (linear) off by rel L2 %.1e (tol %.1e)" % (top, le[top][0], tol)
+    d = np.abs(np.asarray(g[offs[top]:offs[top + 1]], np.float64) - go[offs[top]:offs[top + 1]]).reshape(dims[top] + 1, dims[top + 1])
+    sc = float(np.abs(go[offs[top]:offs[top + 1]]).max())
+    cols = np.where(d.max(0) > 1e-5 * sc)[0]
+    if cols.size == 0 or cols.size > 8:
+        return False, "layer %d off by rel L2 %.1e (tol %.1e) in %d columns" % (top, le[top][0], tol, cols.size)
+    h = np.asarray(xrows, np.float64)
+    for l in range(top + 1):
+        z = h @ Ws[l].astype(np.float64) + bs[l].astype(np.float64)
+        h = np.maximum(z, 0) if act[l] else z
+    zmax = float(np.abs(z).max())
+    near = [float(np.abs(z[:, c]).min()) for c in cols]
+    if max(near) > 1e-5 * zmax:
+        return False, "layer %d off in columns %s, no pre-activation at zero there (closest %.1e of %.1e)" % (top, cols.tolist(), max(near), zmax)
+    return True, "per-layer rel L2 %.1e: ReLU at its kink -- layer %d unit(s) %s, |z| %s of %.1e; layers above exact to %.1e" % (
+        worst, top, cols.tolist(), ["%.1e" % v for v in near], zmax, max([e[0] for e in le[top + 1:]] or [0.0]))
+
+
 def stack_data(dims, n, seed):
     """(x, y or None, row weights): the reference's data shapes -- an autoencoder trains on pre-processed signals against
     themselves with the relative-MSE row weights (emulator.py:732-747), a direct emulator on parameters in [-1, 1] against
@@ -103,6 +156,10 @@ def assert_step_matches_oracle(tag, twins, weights, act, x, y, w, perm, rows, pr
     cos = float(g1 @ go / max(1e-300, np.linalg.norm(g1) * np.linalg.norm(go)))
     ratio = float(np.linalg.norm(g1) / max(1e-300, np.linalg.norm(go)))
     assert cos > tol_c and abs(ratio - 1) < 10 * tol_l, (tag, "gradient vs float64 oracle: cos %.7f norm ratio %.5f" % (cos, ratio))
+    dims = [Ws[0].shape[0]] + [W.shape[1] for W in Ws]
+    if 2 not in act:   # (a variational head's oracle is not this plain stack)
+        ok, note = per_layer_gradient_check(dims, act, Ws, bs, x[idx], g1, go, prec)
+        assert ok, (tag, note)
     assert l1 == l2 and np.array_equal(g1, g2) and np.array_equal(w1, w2), (
         tag, "bitwise twin differs: loss %r %r, grad max diff %.2e, weights max diff %.2e" % (l1, l2, np.abs(g1 - g2).max(), np.abs(w1 - w2).max()))
     return cos

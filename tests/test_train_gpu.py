@@ -155,6 +155,9 @@ def test_reference_architecture_step_all_precisions(ctx):
         print("%s: loss rel err %.2e, grad cosine %.7f" % (prec, abs(loss - ref[0]) / ref[0], cos))
         assert cos > cos_min
         assert abs(loss - ref[0]) / ref[0] < (1e-5 if prec == "f32" else 2e-2)
+        from helpers import per_layer_gradient_check   # (r5: layer by layer -- the cosine of the whole arena cannot see a small layer)
+        ok, note = per_layer_gradient_check(dims, [1, 1, 1, 1, 0], Ws, bs, x, g, ref[1], prec)
+        assert ok, (prec, note)
 
 
 def test_loss_decreases_and_state_roundtrip(ctx):
@@ -376,6 +379,9 @@ def test_fused_training_kernel_matches_chain_route_and_oracle(ctx, case, prec, r
         assert abs(l1 - lo) / lo < tol_l, (name, route, l1, lo)
         cos = float(g1 @ go / (np.linalg.norm(g1) * np.linalg.norm(go)))
         assert cos > tol_c and abs(np.linalg.norm(g1) / np.linalg.norm(go) - 1) < 10 * tol_l, (name, route, cos)
+        from helpers import per_layer_gradient_check
+        ok, note = per_layer_gradient_check(dims, act, Ws, bs, x, g1, go, prec)
+        assert ok, (name, route, note)
     (lc, gc, lc2, wc), (lf, gf, lf2, wf) = res["chain"], res["fused"]
     # the two routes round the same operands to 16 bits and sum in fp32: they agree far better than either meets float64
     assert abs(lf - lc) / lc < 1e-5 and abs(lf2 - lc2) / lc2 < 1e-3, (name, lf, lc, lf2, lc2)
