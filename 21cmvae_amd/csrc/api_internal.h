@@ -305,7 +305,7 @@ float grad_opscale(int brows, int dout);  // api_trainer.hip
 void invalidate_streams(v21_mlp* m);  // api_forward.hip
 int launch_chain32_args(ChainArgs& a, hipStream_t st, bool small = false, int rows_per_wg = 0 /* 4 / 8: the caller decided (routes.h); 0: by the row count */);  // api_trainer.hip
 int launch_dw16(int prec, const std::vector<Dw16Args>& probs, hipStream_t st, const DwXRows* xr = nullptr);  // api_trainer.hip
-int launch_dw32_group(const std::vector<v21_trainer*>& trs, const Dw32Model* d_tab, int rows, long long step_index, int max_blocks, hipStream_t st);  // api_sweep.hip
+int launch_dw32_group(const std::vector<v21_trainer*>& trs, const Dw32Model* d_tab, int rows, long long step_index, int max_blocks, hipStream_t st, bool small_slabs = false);  // api_sweep.hip
 int launch_dw_adam_group(const std::vector<v21_trainer*>& tr, const DwAdamModel* d_tab, const std::vector<DwAdamModel>& h_tab, int rows, int brows, long long slot, hipStream_t st);  // api_trainer.hip
 void launch_joint32_kernel(int rpw, bool gauss, dim3 grid, dim3 block, hipStream_t st, const ChainModel* tab, const ChainStep& sa, const ChainStep& sb);  // api_trainer.hip
 void launch_joint_kernel(int prec, bool gauss, dim3 grid, dim3 block, hipStream_t st, const ChainModel* tab, const ChainStep& sa, const ChainStep& sb);  // api_trainer.hip

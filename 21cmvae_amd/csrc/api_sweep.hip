@@ -325,8 +325,10 @@ static bool build_dw32_model(v21_trainer* t, Dw32Model& md, int& blocks) {
   return true;
 }
 // every weight gradient + Adam + packed streams + batch loss of several f32 models in one launch (dw_adam32.h)
+// small_slabs: the 128-row instantiation (dw_adam32.h: SLAB) -- decided by the caller for the WHOLE sweep, not per launch: a
+// member must see the same sums whether its half-group or the whole group is launched
 int launch_dw32_group(const std::vector<v21_trainer*>& trs, const Dw32Model* d_tab, int rows, long long step_index, int max_blocks,
-                             hipStream_t st) {
+                             hipStream_t st, bool small_slabs) {
   const int G = (int)trs.size();
   Dw32Step ds{};
   ds.rows = rows; ds.slot = (int)step_index;
@@ -335,7 +337,8 @@ int launch_dw32_group(const std::vector<v21_trainer*>& trs, const Dw32Model* d_t
     t->iter += 1;
     ds.alpha[k] = adam_alpha(t->adam, t->iter);
   }
-  hipLaunchKernelGGL(dwadam32_group_kernel, dim3(max_blocks, G), dim3(256), 0, st, d_tab, ds);
+  if (small_slabs) hipLaunchKernelGGL(dwadam32_group_kernel<128>, dim3(max_blocks, G), dim3(256), 0, st, d_tab, ds);
+  else hipLaunchKernelGGL(dwadam32_group_kernel<256>, dim3(max_blocks, G), dim3(256), 0, st, d_tab, ds);
   HIPCHK(hipGetLastError());
   for (v21_trainer* t : trs) {
     t->copies_ok = true; t->nt_ok = false;
@@ -392,6 +395,9 @@ static int sweep_step_chain32(v21_sweep* s, const ChainStep& cs, long long step_
   ChainStep csp = cs;
   csp.ncons = ((rows + rpw - 1) / rpw + 7) / 8 * 8;
   csp.npref = 0;
+  // (dw_adam32.h: SLAB -- from 8 members on the gradient launch is deep enough for four or five workgroups per CU to pay: r5,
+  //  f32, batch 256, 8 / 16 / 32 / 64 members 60 / 70-72 / 70 / 64-67 k -> 62-66 / 79 / 77-79 / 72-73 k model-steps/s)
+  const bool small_slabs = G >= 8;
   if (s->two_streams) {  // (as sweep_step_chain: half B one launch behind half A)
     const int GA = (G + 1) / 2;
     const std::vector<v21_trainer*> pa(s->tr.begin(), s->tr.begin() + GA), pb(s->tr.begin() + GA, s->tr.end());
@@ -401,11 +407,11 @@ static int sweep_step_chain32(v21_sweep* s, const ChainStep& cs, long long step_
       HIPCHK(hipStreamWaitEvent(s->s2, s->ev_off, 0));
     }
     CHK(sweep_chain32_launch(s, csp, rpw, GA, G, s->s2));
-    CHK(launch_dw32_group(pa, s->d_dw32, rows, step_index, max_blocks, st));
-    return launch_dw32_group(pb, s->d_dw32 + GA, rows, step_index, max_blocks, s->s2);
+    CHK(launch_dw32_group(pa, s->d_dw32, rows, step_index, max_blocks, st, small_slabs));
+    return launch_dw32_group(pb, s->d_dw32 + GA, rows, step_index, max_blocks, s->s2, small_slabs);
   }
   CHK(sweep_chain32_launch(s, csp, rpw, 0, G, st));
-  return launch_dw32_group(s->tr, s->d_dw32, rows, step_index, max_blocks, st);
+  return launch_dw32_group(s->tr, s->d_dw32, rows, step_index, max_blocks, st, small_slabs);
 }
 
 extern "C" int v21_sweep_run_epoch(v21_sweep* s, const int32_t* perm, int batch, double* losses) {

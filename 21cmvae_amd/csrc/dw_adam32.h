@@ -34,8 +34,13 @@ constexpr int kDw32MaxRows = 2048;  // (slabs of 256 rows; = kC32sMaxBatch, the 
 struct Dw32Model { NtGroupBig grp; NtAdamInfo ad; };
 struct Dw32Step { int rows; int slot; float alpha[kSweepMax]; };
 // `kov` >= 0: a sweep's launch -- the contraction length, the step size and the loss slot come from the step block
+// SLAB: batch rows that pass through LDS at a time.  256 (64 KB: two workgroups per CU) for a single model, whose ~380
+// workgroups are resident at once and want the shortest chain of dependent waits; 128 (32 KB: four per CU) for the grouped
+// launch of a LARGE sweep, which is thousands of workgroups deep and bound by how many operand rows are in flight (r5, end).
+template <int SLAB>
 __device__ __forceinline__ void dwadam32_body(const NtGroupBig& grp, const NtAdamInfo& ad, const int blk, const int kov, const float alpha_ov, const int slot_ov) {
-  __shared__ __attribute__((aligned(16))) float smem[64 * 256];  // operand rows, then the four partial tiles
+  static_assert(SLAB == 256 || SLAB == 128, "a wave instruction is one row of 256 floats or two of 128");
+  __shared__ __attribute__((aligned(16))) float smem[64 * SLAB];  // operand rows, then the four partial tiles
   D32FINE(0);
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   if (ad.loss_acc && blk == 0 && threadIdx.x == 0) {
@@ -91,11 +96,12 @@ __device__ __forceinline__ void dwadam32_body(const NtGroupBig& grp, const NtAda
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const float* arow = smem + li * 256;
-  const float* brow = smem + (32 + li) * 256;
+  const float* arow = smem + li * SLAB;
+  const float* brow = smem + (32 + li) * SLAB;
   const int swz = li & 15;
-  for (int koff = 0; koff < K; koff += 256) {
+  for (int koff = 0; koff < K; koff += SLAB) {
   if (koff > 0) __syncthreads();  // every wave is done with the previous slab
+  if constexpr (SLAB == 256) {
   unsigned voffA[4], voffB[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -117,11 +123,34 @@ __device__ __forceinline__ void dwadam32_body(const NtGroupBig& grp, const NtAda
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)(row + voffB[i & 3]),
                                      (__attribute__((address_space(3))) void*)(smem + (32 + r) * 256), 16, 0, 0);
   }
+  } else {
+  // two rows of 128 floats per wave instruction: lanes 0-31 row 2 ri, lanes 32-63 row 2 ri + 1 (adjacent in LDS); position p of
+  // row r holds chunk p ^ (r & 15), as above
+  const int rsub = lane >> 5, pch = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 2 * (wave + 4 * i) + rsub;
+    const int c = pch ^ (r & 15);
+    const unsigned vo = koff + 4 * c + 4 > lda ? 0u : 4u * koff + 16u * c;
+    const char* row = reinterpret_cast<const char*>(gA + (long long)min(m0 + r, M - 1) * lda);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)(row + vo),
+                                     (__attribute__((address_space(3))) void*)(smem + 2 * (wave + 4 * i) * 128), 16, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 2 * (wave + 4 * i) + rsub;
+    const int c = pch ^ (r & 15);
+    const unsigned vo = koff + 4 * c + 4 > ldb ? 0u : 4u * koff + 16u * c;
+    const char* row = reinterpret_cast<const char*>(gB + (long long)min(n0 + r, N - 1) * ldb);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(unsigned long long)(row + vo),
+                                     (__attribute__((address_space(3))) void*)(smem + (32 + 2 * (wave + 4 * i)) * 128), 16, 0, 0);
+  }
+  }
   D32FINE(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // ---- contraction: wave w takes its quarter of the slab's k-steps of 8
-  const int nsteps = (min(K - koff, 256) + 7) >> 3, per = (nsteps + 3) >> 2;
+  const int nsteps = (min(K - koff, SLAB) + 7) >> 3, per = (nsteps + 3) >> 2;
   const int s0 = wave * per, s1 = min(nsteps, s0 + per);
   for (int s = s0; s < s1; ++s) {
     const int q = ((2 * s + lh) ^ swz) << 2;
@@ -210,15 +239,16 @@ __device__ __forceinline__ void dwadam32_body(const NtGroupBig& grp, const NtAda
 #endif
   D32FINE(5);
 }
-static __global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, const NtAdamInfo ad) { dwadam32_body(grp, ad, (int)blockIdx.x, -1, 0.f, -1); }
+static __global__ void __launch_bounds__(256) dwadam32_kernel(const NtGroupBig grp, const NtAdamInfo ad) { dwadam32_body<256>(grp, ad, (int)blockIdx.x, -1, 0.f, -1); }
 // a sweep of f32 models: blockIdx.y = model (its problem and Adam blocks in device memory), blockIdx.x = tile of the model.
 // (One model per XCD -- workgroup b = tile b / models of model b % models, as train_chain32s_group_kernel deals its row
 // blocks -- was slower: 59.8 against 53.3 us for 8 autoencoders of 128 .. 512 hidden units; the XCD with the largest
 // model's tiles ends last.)
+template <int SLAB>
 static __global__ void __launch_bounds__(256) dwadam32_group_kernel(const Dw32Model* __restrict__ tab, const Dw32Step st) {
   const Dw32Model& md = tab[blockIdx.y];
   if ((int)blockIdx.x >= md.grp.first[md.grp.count]) return;
-  dwadam32_body(md.grp, md.ad, (int)blockIdx.x, st.rows, st.alpha[blockIdx.y], st.slot);
+  dwadam32_body<SLAB>(md.grp, md.ad, (int)blockIdx.x, st.rows, st.alpha[blockIdx.y], st.slot);
 }
 
 }  // namespace v21
