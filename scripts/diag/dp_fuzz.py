@@ -76,7 +76,10 @@ def tag_of(cfg):
 
 def run_case(cfg):
     """-> ("OK" | "BAD", message).  Starts cfg["world"] processes (spawn) on the one GPU, then repeats the fit in THIS process."""
-    import torch.multiprocessing as mp
+    # (the standard library's multiprocessing, not torch's: THIS process must not import torch after it has used libv21.so --
+    #  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so, and a torch imported second brings a
+    #  second HIP runtime into the process: `double free or corruption` at exit, r5.  The ranks import torch first.)
+    import multiprocessing as mp
     world = cfg["world"]
     mpc = mp.get_context("spawn")
     q = mpc.Queue()

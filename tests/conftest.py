@@ -13,6 +13,24 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Code objects compiled at run time go to a directory of THIS session (unless the caller names one): a kernel left in
+    # ~/.cache/21cmvae_amd by an earlier process is "ready at once" and changes the route of the first calls -- the table test's
+    # "no run-time kernel yet" rows then fail for a reason that is not in the tree (r5: four pytest processes on one box).
+    # The kernels build() put next to the library (kernel_cache/, read-only) are found as before.
+    if not os.environ.get("V21_KERNEL_CACHE"):
+        import tempfile
+        d = tempfile.mkdtemp(prefix="v21_kernels_")
+        os.chmod(d, 0o700)
+        os.environ["V21_KERNEL_CACHE"] = d
+        config._v21_kernel_dir = d
+
+
+def pytest_unconfigure(config):
+    d = getattr(config, "_v21_kernel_dir", None)
+    if d:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+        os.environ.pop("V21_KERNEL_CACHE", None)
 
 
 def pkg(sub=None):

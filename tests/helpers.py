@@ -60,7 +60,7 @@ def per_layer_gradient_check(dims, act, Ws, bs, xrows, g, go, prec):
     row's contribution or not; its column of [W; b] is then off by one row's worth and every layer BELOW it by what flows back
     through that unit (r5: 2,047 rows of the latent emulator -- one column of layer 2 off, half the columns of layers 1 and 0,
     layers 3 and 4 exact to 2e-7).  That case is accepted only when it is shown: the top-most layer that is off must be a ReLU
-    layer, be off in at most 8 columns, and each of those units must have such a pre-activation in float64.
+    layer, be off in a few columns only (8 + rows / 2,000), and each of those units must have such a pre-activation in float64.
     f16 / bf16: 0.1 / 0.25 (operands rounded to 11 / 8 bits, and 16-bit pre-activations cross zero routinely; steps of fewer
     than 64 rows: 0.5) -- loose, but a layer that is WRONG is off by ~1, and the whole-arena cosine does not see a small layer."""
     rows = len(xrows)
@@ -77,11 +77,23 @@ def per_layer_gradient_check(dims, act, Ws, bs, xrows, g, go, prec):
     top = max(l for l in range(L) if le[l][0] > tol)
     if not act[top]:
         return False, "layer %d (linear) off by rel L2 %.1e (tol %.1e)" % (top, le[top][0], tol)
-    d = np.abs(np.asarray(g[offs[top]:offs[top + 1]], np.float64) - go[offs[top]:offs[top + 1]]).reshape(dims[top] + 1, dims[top + 1])
-    sc = float(np.abs(go[offs[top]:offs[top + 1]]).max())
-    cols = np.where(d.max(0) > 1e-5 * sc)[0]
-    if cols.size == 0 or cols.size > 8:
-        return False, "layer %d off by rel L2 %.1e (tol %.1e) in %d columns" % (top, le[top][0], tol, cols.size)
+    # the columns that carry the difference: the fewest whose removal leaves the layer within the noise bound (a flipped unit
+    # changes its own column of [W; b] by one row's contribution -- at 20,000 rows that is 5e-5 of an element, far below any
+    # fixed element threshold, but it still stands out against the other columns' 1e-7)
+    gb = np.asarray(go[offs[top]:offs[top + 1]], np.float64).reshape(dims[top] + 1, dims[top + 1])
+    d = np.asarray(g[offs[top]:offs[top + 1]], np.float64).reshape(dims[top] + 1, dims[top + 1]) - gb
+    cn = np.linalg.norm(d, axis=0)
+    order = np.argsort(cn)[::-1]
+    ref = float(np.linalg.norm(gb))
+    cols = None
+    max_cols = 8 + rows // 2000   # (a 40,000-row step has 14 M pre-activations per 352-wide layer: a few within 1e-8 of zero are expected)
+    for j in range(1, max_cols + 1):
+        rest = np.sqrt(max(0.0, float((cn ** 2).sum() - (cn[order[:j]] ** 2).sum())))
+        if rest <= tol * ref:
+            cols = np.sort(order[:j])
+            break
+    if cols is None:
+        return False, "layer %d off by rel L2 %.1e (tol %.1e), not confined to %d columns" % (top, le[top][0], tol, max_cols)
     h = np.asarray(xrows, np.float64)
     for l in range(top + 1):
         z = h @ Ws[l].astype(np.float64) + bs[l].astype(np.float64)
