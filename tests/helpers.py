@@ -55,7 +55,8 @@ def layer_errors(dims, g, go):
 
 def per_layer_gradient_check(dims, act, Ws, bs, xrows, g, go, prec):
     """-> (ok, note).  Every layer's block of the gradient against the float64 oracle's, by relative L2 norm.
-    f32: summation noise only (2e-6: measured 1.2e-7 to 4e-7 from 1 to 32,768 rows) -- unless a ReLU sits on
+    f32: summation noise only (2e-6, or 1e-7 sqrt(rows) above 400 rows: mostly 1.2e-7 to 4e-7 from 1 to 32,768 rows, but a layer
+    whose gradient is what is left of heavy cancellation reached 1.0e-5 at 40,001 rows, in every column alike) -- unless a ReLU sits on
     the other side of zero than in float64: a unit whose pre-activation is ~1e-7 of the layer's largest for one row gets that
     row's contribution or not; its column of [W; b] is then off by one row's worth and every layer BELOW it by what flows back
     through that unit (r5: 2,047 rows of the latent emulator -- one column of layer 2 off, half the columns of layers 1 and 0,
@@ -69,7 +70,7 @@ def per_layer_gradient_check(dims, act, Ws, bs, xrows, g, go, prec):
     if prec != "f32":
         tol = 0.5 if rows < 64 else (0.1 if prec == "f16" else 0.25)
         return worst <= tol, "per-layer rel L2 <= %.1e (tol %.2g)" % (worst, tol)
-    tol = 2e-6
+    tol = max(2e-6, 1e-7 * float(np.sqrt(rows)))
     if worst <= tol:
         return True, "per-layer rel L2 <= %.1e (tol %.1e)" % (worst, tol)
     L = len(dims) - 1
