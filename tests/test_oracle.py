@@ -304,3 +304,40 @@ def test_vae_without_noise_and_kl_is_the_plain_autoencoder():
     gW1 = g[o:o + Ws[1].size].reshape(8, 6)
     np.testing.assert_allclose(gW1[:, :3], dW1, atol=1e-14)
     assert np.all(gW1[:, 3:] == 0)
+
+
+def test_kink_adjusted_oracle_recovers_a_relu_on_the_other_side_of_zero():
+    """tests/helpers.py: the gradient check the GPU tests use for f32 accepts a difference from the float64 oracle only when it
+    is the oracle's own gradient with d relu / dz taken the other way at pre-activations that are zero to rounding -- and only
+    then.  Built here on the CPU: a stack whose unit (layer 0, row 3, unit 2) has z = +1e-9; the same stack with z = -1e-9 gives
+    the 'device' gradient (everything else identical to ~1e-9)."""
+    from helpers import oracle_step, per_layer_gradient_check
+    rng = np.random.default_rng(0)
+    dims, act = [5, 8, 6, 3], [1, 1, 0]
+    Ws, bs = ora.init_mlp(dims, seed=4)
+    bs = [rng.normal(scale=0.1, size=b.shape).astype(np.float64) for b in bs]
+    Ws = [W.astype(np.float64) for W in Ws]
+    x = rng.uniform(-1, 1, size=(20, 5))
+    y = rng.normal(size=(20, 3))
+    w = rng.uniform(0.5, 1.5, size=20) / 3
+    r0, u0 = 3, 2
+
+    def with_z(target):
+        b0 = bs[0].copy()
+        b0[u0] += target - (x[r0] @ Ws[0][:, u0] + b0[u0])
+        return [b0] + bs[1:]
+    bs_pos, bs_neg = with_z(1e-9), with_z(-1e-9)
+    _, go = oracle_step(Ws, bs_pos, act, x, y, w)
+    _, g_dev = oracle_step(Ws, bs_neg, act, x, y, w)
+    assert np.abs(g_dev - go).max() > 1e-4 * np.abs(go).max()          # the flip is visible ...
+    ok, note = per_layer_gradient_check(dims, act, Ws, bs_pos, x, g_dev, go, "f32", tgt=y, w=w)
+    assert ok and "1 ReLU(s) at their kink" in note and "layer 0 row 3 unit 2" in note, note   # ... and explained
+    ok, note = per_layer_gradient_check(dims, act, Ws, bs_pos, x, g_dev, go, "f32")            # without the data to show it: refused
+    assert not ok, note
+    bad = g_dev.copy(); bad[7] *= 1.01                                   # a wrong element is not a kink
+    ok, note = per_layer_gradient_check(dims, act, Ws, bs_pos, x, bad, go, "f32", tgt=y, w=w)
+    assert not ok, note
+    g_row = go.copy()                                                    # one row's contribution missing from the first layer
+    g_row[:5 * 8] -= (np.outer(x[7], np.ones(8)) * 1e-3).ravel()
+    ok, note = per_layer_gradient_check(dims, act, Ws, bs_pos, x, g_row, go, "f32", tgt=y, w=w)
+    assert not ok, note
